@@ -1,0 +1,249 @@
+"""ctypes binding of include/bbg.h (libbbg.so).  Host arrays are numpy uint64 in the reference's layout:
+scalars / coefficients (n, 4); affine points (n, 8); Jacobian points (n, 12) or (12,)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libbbg.so")
+
+# op codes of bbg_ntt (include/bbg.h)
+FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
+FFT_WITH_CONSTANT, COSET_FFT_WITH_CONSTANT, COSET_FFT_WITH_GENERATOR_SHIFT, IFFT_WITH_CONSTANT = 4, 5, 6, 7
+
+
+class BbgError(RuntimeError):
+    pass
+
+
+def build_library(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "-j4"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libbbg.so and declare prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BbgError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, u64p, cint = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int
+    protos = {
+        "bbg_device_count": (cint, []),
+        "bbg_init": (cint, [cint, ctypes.POINTER(vp)]),
+        "bbg_destroy": (None, [vp]),
+        "bbg_last_error": (ctypes.c_char_p, []),
+        "bbg_sync": (cint, [vp]),
+        "bbg_set_stream": (cint, [vp, vp]),
+        "bbg_srs_register": (cint, [vp, vp, sz, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_register_device": (cint, [vp, vp, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_synth_linear": (cint, [vp, ctypes.c_uint64, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_load_transcript": (cint, [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_num_points": (sz, [vp]),
+        "bbg_srs_read": (cint, [vp, sz, sz, vp]),
+        "bbg_srs_free": (None, [vp]),
+        "bbg_msm": (cint, [vp, vp, vp, sz, sz, vp]),
+        "bbg_msm_device": (cint, [vp, vp, vp, sz, sz, vp]),
+        "bbg_g1_sum": (cint, [vp, vp, sz, vp]),
+        "bbg_g1_normalize": (cint, [vp, vp, sz, vp]),
+        "bbg_ntt": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
+        "bbg_ntt_device": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
+        "bbg_ntt_prepare": (cint, [vp, ctypes.c_uint]),
+        "bbg_coset_fft_split": (cint, [vp, vp, ctypes.c_uint, sz]),
+        "bbg_coset_fft_split_device": (cint, [vp, vp, ctypes.c_uint, sz]),
+        "bbg_dev_alloc": (cint, [vp, sz, ctypes.POINTER(vp)]),
+        "bbg_dev_free": (cint, [vp, vp]),
+        "bbg_dev_upload": (cint, [vp, vp, vp, sz]),
+        "bbg_dev_download": (cint, [vp, vp, vp, sz]),
+        "bbg_set_option": (cint, [vp, ctypes.c_char_p, ctypes.c_long]),
+        "bbg_field_op": (cint, [vp, cint, cint, vp, vp, vp, sz]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError here == a symbol declared in bbg.h is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_set_stream", "bbg_srs_register",
+    "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
+    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
+    "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_dev_alloc", "bbg_dev_free",
+    "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op",
+]
+
+
+def _u64(a, shape_last):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, shape_last)
+    if a.shape[-1] != shape_last:
+        raise ValueError(f"expected (*, {shape_last}) uint64 limbs, got {a.shape}")
+    return a
+
+
+class Srs:
+    def __init__(self, owner, handle):
+        self._owner, self.handle = owner, handle
+
+    @property
+    def num_points(self):
+        return int(self._owner.lib.bbg_srs_num_points(self.handle))
+
+    def read(self, start=0, count=None):
+        count = self.num_points - start if count is None else count
+        out = np.empty((count, 8), dtype=np.uint64)
+        self._owner._ck(self._owner.lib.bbg_srs_read(self.handle, start, count, out.ctypes.data))
+        return out
+
+    def free(self):
+        if self.handle:
+            self._owner.lib.bbg_srs_free(self.handle)
+            self.handle = None
+
+
+class Bbg:
+    """One context per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.bbg_device_count() <= 0:
+            raise BbgError("no HIP device visible: libbbg has no CPU fallback")
+        h = ctypes.c_void_p()
+        rc = self.lib.bbg_init(device, ctypes.byref(h))
+        if rc != 0:
+            raise BbgError(f"bbg_init failed ({rc}): {self.lib.bbg_last_error().decode()}")
+        self.ctx = h
+        self.device = device
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise BbgError(f"libbbg error {rc}: {self.lib.bbg_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.bbg_destroy(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        self._ck(self.lib.bbg_sync(self.ctx))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.bbg_set_stream(self.ctx, ctypes.c_void_p(stream_ptr)))
+
+    def set_option(self, key, value):
+        self._ck(self.lib.bbg_set_option(self.ctx, key.encode(), int(value)))
+
+    # ---- SRS
+    def srs_register(self, points, stride_bytes=64):
+        pts = np.ascontiguousarray(points, dtype=np.uint64)
+        n = pts.size * 8 // stride_bytes
+        h = ctypes.c_void_p()
+        self._ck(self.lib.bbg_srs_register(self.ctx, pts.ctypes.data, n, stride_bytes, ctypes.byref(h)))
+        return Srs(self, h)
+
+    def srs_register_device(self, d_points, n):
+        h = ctypes.c_void_p()
+        self._ck(self.lib.bbg_srs_register_device(self.ctx, ctypes.c_void_p(d_points), n, ctypes.byref(h)))
+        return Srs(self, h)
+
+    def srs_synth_linear(self, a, s, n):
+        h = ctypes.c_void_p()
+        self._ck(self.lib.bbg_srs_synth_linear(self.ctx, a, s, n, ctypes.byref(h)))
+        return Srs(self, h)
+
+    def srs_load_transcript(self, directory, num_points):
+        h = ctypes.c_void_p()
+        self._ck(self.lib.bbg_srs_load_transcript(self.ctx, str(directory).encode(), num_points, ctypes.byref(h)))
+        return Srs(self, h)
+
+    # ---- MSM
+    def msm(self, srs, scalars, start=0):
+        sc = _u64(scalars, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self.lib.bbg_msm(self.ctx, srs.handle, sc.ctypes.data, start, sc.shape[0], out.ctypes.data))
+        return out
+
+    def msm_device(self, srs, d_scalars, n, d_out, start=0):
+        self._ck(self.lib.bbg_msm_device(self.ctx, srs.handle, ctypes.c_void_p(d_scalars), start, n, ctypes.c_void_p(d_out)))
+
+    def g1_sum(self, jacobians):
+        j = _u64(jacobians, 12)
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self.lib.bbg_g1_sum(self.ctx, j.ctypes.data, j.shape[0], out.ctypes.data))
+        return out
+
+    def g1_normalize(self, jacobians):
+        j = _u64(jacobians, 12)
+        out = np.zeros((j.shape[0], 8), dtype=np.uint64)
+        self._ck(self.lib.bbg_g1_normalize(self.ctx, j.ctypes.data, j.shape[0], out.ctypes.data))
+        return out
+
+    # ---- NTT
+    def ntt(self, coeffs, op=FFT, generator_size=0, constant=None):
+        a = _u64(coeffs, 4).copy()
+        n = a.shape[0]
+        log2n = n.bit_length() - 1
+        if n == 0 or (1 << log2n) != n:
+            raise ValueError("NTT size must be a power of two")
+        c = None if constant is None else np.ascontiguousarray(constant, dtype=np.uint64)
+        self._ck(self.lib.bbg_ntt(self.ctx, a.ctypes.data, log2n, op, generator_size, None if c is None else c.ctypes.data))
+        return a
+
+    def ntt_device(self, d_coeffs, log2n, op=FFT, generator_size=0, constant=None):
+        c = None if constant is None else np.ascontiguousarray(constant, dtype=np.uint64)
+        self._ck(self.lib.bbg_ntt_device(self.ctx, ctypes.c_void_p(d_coeffs), log2n, op, generator_size,
+                                         None if c is None else c.ctypes.data))
+
+    def ntt_prepare(self, log2n):
+        self._ck(self.lib.bbg_ntt_prepare(self.ctx, log2n))
+
+    def coset_fft_split(self, coeffs, ext):
+        a = _u64(coeffs, 4)
+        n = a.shape[0]
+        log2n = n.bit_length() - 1
+        buf = np.zeros((n * ext, 4), dtype=np.uint64)
+        buf[:n] = a
+        self._ck(self.lib.bbg_coset_fft_split(self.ctx, buf.ctypes.data, log2n, ext))
+        return buf
+
+    # ---- raw device memory (for hosts without torch)
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._ck(self.lib.bbg_dev_alloc(self.ctx, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._ck(self.lib.bbg_dev_free(self.ctx, ctypes.c_void_p(ptr)))
+
+    def dev_upload(self, ptr, array):
+        a = np.ascontiguousarray(array)
+        self._ck(self.lib.bbg_dev_upload(self.ctx, ctypes.c_void_p(ptr), a.ctypes.data, a.nbytes))
+
+    def dev_download(self, ptr, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        self._ck(self.lib.bbg_dev_download(self.ctx, out.ctypes.data, ctypes.c_void_p(ptr), out.nbytes))
+        return out
+
+    def field_op(self, which, op, a, b=None):
+        a = _u64(a, 4)
+        out = np.empty_like(a)
+        bp = None
+        if b is not None:
+            b = _u64(b, 4)
+            bp = b.ctypes.data
+        self._ck(self.lib.bbg_field_op(self.ctx, which, op, a.ctypes.data, bp, out.ctypes.data, a.shape[0]))
+        return out

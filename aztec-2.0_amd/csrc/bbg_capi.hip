@@ -1,0 +1,438 @@
+// C ABI of libbbg.so (declared in include/bbg.h).  Host-side plumbing only: contexts, device buffers, the SRS
+// registry and the Ignition-transcript reader.  All arithmetic runs in the HIP kernels of ntt.hip / msm.hip.
+#include "bbg_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace bbg {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_last_error = buf;
+    return e == hipErrorOutOfMemory ? BBG_E_NOMEM : BBG_E_HIP;
+}
+int ensure_buffer(void** buf, size_t* have, size_t need)
+{
+    if (*have >= need && *buf) return BBG_OK;
+    if (*buf) {
+        BBG_HIP(hipDeviceSynchronize());
+        BBG_HIP(hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    BBG_HIP(hipMalloc(buf, need));
+    *have = need;
+    return BBG_OK;
+}
+int srs_build_tables(const void* d_points, size_t n, void* d_table, hipStream_t st);
+int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st);
+
+static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs** out)
+{
+    bbg_srs* s = new bbg_srs;
+    s->ctx = ctx;
+    s->s.n = n;
+    s->s.device = ctx->device;
+    if (n) {
+        hipError_t e = hipMalloc(&s->s.points, n * 16 * 64);
+        if (e != hipSuccess) {
+            delete s;
+            return hip_fail(e, "hipMalloc(SRS window tables)", __FILE__, __LINE__);
+        }
+        int rc = srs_build_tables(d_plain_points, n, s->s.points, ctx->stream);
+        if (rc == BBG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = hip_fail(hipGetLastError(), "SRS table build", __FILE__, __LINE__);
+        if (rc) {
+            (void)hipFree(s->s.points);
+            delete s;
+            return rc;
+        }
+    }
+    *out = s;
+    return BBG_OK;
+}
+} // namespace bbg
+
+using namespace bbg;
+
+#define CHECK_CTX(ctx)                                                                                               \
+    do {                                                                                                             \
+        if (!(ctx)) { set_error("null bbg_ctx"); return BBG_E_INVALID; }                                             \
+        hipError_t _e = hipSetDevice((ctx)->device);                                                                 \
+        if (_e != hipSuccess) return hip_fail(_e, "hipSetDevice", __FILE__, __LINE__);                               \
+    } while (0)
+
+extern "C" {
+
+const char* bbg_last_error(void) { return g_last_error.c_str(); }
+
+int bbg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bbg_init(int device, bbg_ctx** out)
+{
+    if (!out) { set_error("bbg_init: null out"); return BBG_E_INVALID; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error("bbg_init: no HIP device visible (this library has no CPU fallback)");
+        return BBG_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("bbg_init: device index out of range"); return BBG_E_INVALID; }
+    BBG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BBG_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error(std::string("bbg_init: device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
+        return BBG_E_NODEVICE;
+    }
+    bbg_ctx* c = new bbg_ctx;
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+    c->own_stream = true;
+    *out = c;
+    return BBG_OK;
+}
+
+void bbg_destroy(bbg_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : ctx->domains) ntt_free_domain(kv.second);
+    if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
+    if (ctx->staging) (void)hipFree(ctx->staging);
+    if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int bbg_sync(bbg_ctx* ctx)
+{
+    CHECK_CTX(ctx);
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+int bbg_set_stream(bbg_ctx* ctx, void* hip_stream)
+{
+    CHECK_CTX(ctx);
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return BBG_OK;
+}
+
+int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
+{
+    CHECK_CTX(ctx);
+    if (!key) { set_error("bbg_set_option: null key"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(key, "ntt_tile_log")) {
+        if (value < 9 || value > 12) { set_error("ntt_tile_log must be 9..12"); return BBG_E_INVALID; }
+        ctx->ntt_tile_log = (int)value;
+    } else if (!strcmp(key, "ntt_max_logr")) {
+        if (value < 4 || value > 10) { set_error("ntt_max_logr must be 4..10"); return BBG_E_INVALID; }
+        ctx->ntt_max_logr = (int)value;
+    } else {
+        set_error(std::string("bbg_set_option: unknown key ") + key);
+        return BBG_E_INVALID;
+    }
+    // plans are per domain: drop cached domains so the new plan takes effect
+    BBG_HIP(hipDeviceSynchronize());
+    for (auto& kv : ctx->domains) ntt_free_domain(kv.second);
+    ctx->domains.clear();
+    return BBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ memory helpers
+int bbg_dev_alloc(bbg_ctx* ctx, size_t bytes, void** d_ptr)
+{
+    CHECK_CTX(ctx);
+    if (!d_ptr) { set_error("bbg_dev_alloc: null out"); return BBG_E_INVALID; }
+    BBG_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return BBG_OK;
+}
+int bbg_dev_free(bbg_ctx* ctx, void* d_ptr)
+{
+    CHECK_CTX(ctx);
+    BBG_HIP(hipFree(d_ptr));
+    return BBG_OK;
+}
+int bbg_dev_upload(bbg_ctx* ctx, void* d_dst, const void* src, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    BBG_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    BBG_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SRS
+int bbg_srs_register(bbg_ctx* ctx, const uint64_t* points, size_t n, size_t stride_bytes, bbg_srs** out)
+{
+    CHECK_CTX(ctx);
+    if (!out || (!points && n)) { set_error("bbg_srs_register: null argument"); return BBG_E_INVALID; }
+    if (stride_bytes != 64 && stride_bytes != 128) {
+        set_error("bbg_srs_register: stride_bytes must be 64 (plain points) or 128 (interleaved endomorphism table)");
+        return BBG_E_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void* d_plain = nullptr;
+    BBG_HIP(hipMalloc(&d_plain, n ? n * 64 : 64));
+    hipError_t e;
+    if (stride_bytes == 64)
+        e = hipMemcpyAsync(d_plain, points, n * 64, hipMemcpyHostToDevice, ctx->stream);
+    else
+        e = hipMemcpy2DAsync(d_plain, 64, points, 128, 64, n, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_plain); return hip_fail(e, "SRS upload", __FILE__, __LINE__); }
+    int rc = make_srs(ctx, d_plain, n, out);
+    (void)hipFree(d_plain);
+    return rc;
+}
+
+int bbg_srs_register_device(bbg_ctx* ctx, const void* d_points, size_t n, bbg_srs** out)
+{
+    CHECK_CTX(ctx);
+    if (!out || (!d_points && n)) { set_error("bbg_srs_register_device: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return make_srs(ctx, d_points, n, out);
+}
+
+int bbg_srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, bbg_srs** out)
+{
+    CHECK_CTX(ctx);
+    if (!out) { set_error("bbg_srs_synth_linear: null out"); return BBG_E_INVALID; }
+    if (s == 0 || a == 0) { set_error("bbg_srs_synth_linear: a and s must be non-zero"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void* d_plain = nullptr;
+    BBG_HIP(hipMalloc(&d_plain, n ? n * 64 : 64));
+    int rc = srs_synth_linear(ctx, a, s, n, d_plain, ctx->stream);
+    if (rc == BBG_OK) rc = make_srs(ctx, d_plain, n, out);
+    (void)hipFree(d_plain);
+    return rc;
+}
+
+// Ignition transcript reader: restates io::read_transcript_g1 (reference srs/io.cpp:134-162): manifest of seven
+// big-endian u32 (:11-19,31-45), then num_g1_points x 64 B, every 8-byte limb big-endian, limbs least-significant
+// first, values NOT in Montgomery form (:47-67).  monomials[0] = G, file points follow; files transcript00.dat,
+// transcript01.dat, ... are consumed until num_points are read (:123-126).  Conversion to Montgomery form runs
+// on the device.
+int bbg_srs_load_transcript(bbg_ctx* ctx, const char* dir, size_t num_points, bbg_srs** out)
+{
+    CHECK_CTX(ctx);
+    if (!dir || !out || num_points == 0) { set_error("bbg_srs_load_transcript: bad argument"); return BBG_E_INVALID; }
+    std::vector<uint64_t> pts(num_points * 8);
+    size_t num_read = 1;
+    for (size_t num = 0; num_read < num_points; num++) {
+        char name[64];
+        snprintf(name, sizeof(name), "/transcript%02zu.dat", num);
+        std::string path = std::string(dir) + name;
+        std::ifstream f(path, std::ifstream::binary);
+        if (!f.good()) break;
+        unsigned char m[28];
+        f.read((char*)m, 28);
+        if (f.gcount() != 28) { set_error("bbg_srs_load_transcript: short manifest in " + path); return BBG_E_INVALID; }
+        auto be32 = [&](int k) { return ((uint32_t)m[4 * k] << 24) | ((uint32_t)m[4 * k + 1] << 16) | ((uint32_t)m[4 * k + 2] << 8) | m[4 * k + 3]; };
+        const size_t num_g1 = be32(4);
+        const size_t take = std::min(num_g1, num_points - num_read);
+        f.read((char*)&pts[num_read * 8], (std::streamsize)(take * 64));
+        if ((size_t)f.gcount() != take * 64) { set_error("bbg_srs_load_transcript: short read in " + path); return BBG_E_INVALID; }
+        for (size_t i = num_read * 8; i < (num_read + take) * 8; i++) pts[i] = __builtin_bswap64(pts[i]);
+        num_read += take;
+    }
+    if (num_read < num_points) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "Only read %zu points but require %zu. Is your srs large enough?", num_read, num_points);
+        set_error(buf);
+        return BBG_E_INVALID;
+    }
+    // generator (1, 2), plain form; converted with the rest
+    for (int i = 0; i < 8; i++) pts[i] = 0;
+    pts[0] = 1;
+    pts[4] = 2;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void* d_plain = nullptr;
+    BBG_HIP(hipMalloc(&d_plain, num_points * 64));
+    hipError_t e = hipMemcpyAsync(d_plain, pts.data(), num_points * 64, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_plain); return hip_fail(e, "transcript upload", __FILE__, __LINE__); }
+    int rc = field_op_device(1, 5 /* to_montgomery */, d_plain, nullptr, d_plain, num_points * 2, ctx->stream);
+    if (rc == BBG_OK) rc = make_srs(ctx, d_plain, num_points, out);
+    (void)hipFree(d_plain);
+    return rc;
+}
+
+size_t bbg_srs_num_points(const bbg_srs* srs) { return srs ? srs->s.n : 0; }
+
+int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points)
+{
+    if (!srs || !out_points) { set_error("bbg_srs_read: null argument"); return BBG_E_INVALID; }
+    CHECK_CTX(srs->ctx);
+    if (from > srs->s.n || count > srs->s.n - from) { set_error("bbg_srs_read: range out of bounds"); return BBG_E_INVALID; }
+    BBG_HIP(hipMemcpy(out_points, (const char*)srs->s.points + from * 64, count * 64, hipMemcpyDeviceToHost));
+    return BBG_OK;
+}
+
+void bbg_srs_free(bbg_srs* srs)
+{
+    if (!srs) return;
+    (void)hipSetDevice(srs->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (srs->s.points) (void)hipFree(srs->s.points);
+    delete srs;
+}
+
+// ------------------------------------------------------------------------------------------------ MSM
+int bbg_msm_device(bbg_ctx* ctx, bbg_srs* srs, const void* d_scalars, size_t from, size_t n, void* d_out_jacobian)
+{
+    CHECK_CTX(ctx);
+    if (!srs || (!d_scalars && n) || !d_out_jacobian) { set_error("bbg_msm_device: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return msm_run(ctx, srs->s, d_scalars, from, n, d_out_jacobian, ctx->stream);
+}
+
+int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, size_t n, uint64_t out_jacobian[12])
+{
+    CHECK_CTX(ctx);
+    if (!srs || (!scalars && n) || !out_jacobian) { set_error("bbg_msm: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * 32 + 256);
+    if (rc) return rc;
+    char* st = (char*)ctx->staging;
+    if (n) BBG_HIP(hipMemcpyAsync(st + 256, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = msm_run(ctx, srs->s, st + 256, from, n, st, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(out_jacobian, st, 96, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+int bbg_g1_sum(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t out_jacobian[12])
+{
+    CHECK_CTX(ctx);
+    if ((!jacobians && n) || !out_jacobian) { set_error("bbg_g1_sum: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * 96 + 256);
+    if (rc) return rc;
+    char* st = (char*)ctx->staging;
+    if (n) BBG_HIP(hipMemcpyAsync(st + 256, jacobians, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    rc = g1_sum_device(ctx, st + 256, n, st, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(out_jacobian, st, 96, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+int bbg_g1_normalize(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t* out_affine)
+{
+    CHECK_CTX(ctx);
+    if ((!jacobians || !out_affine) && n) { set_error("bbg_g1_normalize: null argument"); return BBG_E_INVALID; }
+    if (n == 0) return BBG_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * 160);
+    if (rc) return rc;
+    char* st = (char*)ctx->staging;
+    BBG_HIP(hipMemcpyAsync(st, jacobians, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    rc = g1_normalize_device(st, n, st + n * 96, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(out_affine, st + n * 96, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NTT
+int bbg_ntt_prepare(bbg_ctx* ctx, unsigned log2n)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_prepare(ctx, log2n);
+}
+
+int bbg_ntt_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_run(ctx, d_coeffs, log2n, op, generator_size, constant, ctx->stream);
+}
+
+int bbg_ntt(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant)
+{
+    CHECK_CTX(ctx);
+    if (!coeffs) { set_error("bbg_ntt: null coeffs"); return BBG_E_INVALID; }
+    if (log2n > 28) { set_error("bbg_ntt: log2n > 28 exceeds the 2-adicity of BN254 Fr (fr.hpp:27-30)"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t bytes = ((size_t)1 << log2n) * 32;
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, bytes);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(ctx->staging, coeffs, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = ntt_run(ctx, ctx->staging, log2n, op, generator_size, constant, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(coeffs, ctx->staging, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext)
+{
+    CHECK_CTX(ctx);
+    if (!d_coeffs) { set_error("bbg_coset_fft_split: null coeffs"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_coset_split(ctx, d_coeffs, log2n, ext, ctx->stream);
+}
+
+int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t ext)
+{
+    CHECK_CTX(ctx);
+    if (!coeffs) { set_error("bbg_coset_fft_split: null coeffs"); return BBG_E_INVALID; }
+    if (ext == 0 || log2n > 28 || ext > ((size_t)1 << 28)) { set_error("bbg_coset_fft_split: bad size"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t n = (size_t)1 << log2n;
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * ext * 32);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(ctx->staging, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = ntt_coset_split(ctx, ctx->staging, log2n, ext, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(coeffs, ctx->staging, n * ext * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+int bbg_field_op(bbg_ctx* ctx, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n)
+{
+    CHECK_CTX(ctx);
+    if (!a || !out) { set_error("bbg_field_op: null argument"); return BBG_E_INVALID; }
+    if (n == 0) return BBG_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * 96);
+    if (rc) return rc;
+    char* st = (char*)ctx->staging;
+    BBG_HIP(hipMemcpyAsync(st, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (b) BBG_HIP(hipMemcpyAsync(st + n * 32, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = field_op_device(which, op, st, b ? st + n * 32 : nullptr, st + n * 64, n, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(out, st + n * 64, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+} // extern "C"

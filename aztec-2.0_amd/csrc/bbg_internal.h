@@ -1,0 +1,88 @@
+// Internal declarations shared by the HIP translation units of libbbg.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bbg.h"
+
+namespace bbg {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define BBG_HIP(expr)                                                                                                \
+    do {                                                                                                             \
+        hipError_t _e = (expr);                                                                                      \
+        if (_e != hipSuccess) return ::bbg::hip_fail(_e, #expr, __FILE__, __LINE__);                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- NTT
+constexpr int NTT_MAX_PASSES = 4;
+
+// Per-domain-size device tables: the GPU counterpart of evaluation_domain::compute_lookup_table()
+// (reference polynomials/evaluation_domain.cpp:33-55,169-175).  Built once per log2(n), cached in the context.
+struct NttDomain {
+    unsigned log2n = 0;
+    int passes = 0;
+    int logR[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
+    int logW[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
+    void* consts = nullptr;                          // DomainConsts (device)
+    void* tw_inter[2][NTT_MAX_PASSES] = {};          // [inverse][pass]: omega_{N_q}^{i*lo}, N_q entries (passes 0..p-2)
+    void* tw_radix[2][NTT_MAX_PASSES] = {};          // [inverse][pass]: omega_{R_q}^j, R_q/2 entries
+    void* coset_fwd = nullptr;                       // g^j, j < n
+    void* coset_inv = nullptr;                       // n^-1 * g^-j, j < n
+    size_t bytes = 0;
+};
+
+// ---------------------------------------------------------------------------------------------- MSM
+struct Srs {
+    size_t n = 0;          // number of (plain) points
+    void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical
+    int device = 0;
+};
+
+struct MsmScratch {
+    void* buf = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace bbg
+
+struct bbg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+    std::map<unsigned, bbg::NttDomain> domains;
+    void* ntt_scratch = nullptr;
+    size_t ntt_scratch_bytes = 0;
+    void* staging = nullptr; // device staging for host-pointer entry points
+    size_t staging_bytes = 0;
+    bbg::MsmScratch msm;
+    int ntt_tile_log = 12; // log2(elements per LDS tile)
+    int ntt_max_logr = 9;
+};
+
+struct bbg_srs {
+    bbg::Srs s;
+    bbg_ctx* ctx = nullptr;
+};
+
+namespace bbg {
+int ensure_buffer(void** buf, size_t* have, size_t need);
+int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
+            hipStream_t stream);
+void ntt_free_domain(NttDomain& d);
+int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);
+int ntt_prepare(bbg_ctx* ctx, unsigned log2n);
+int field_op_device(int which, int op, const void* a, const void* b, void* out, size_t n, hipStream_t stream);
+int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
+            hipStream_t stream);
+int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
+int g1_sum_device(bbg_ctx* ctx, const void* d_jacs, size_t n, void* d_out, hipStream_t stream);
+} // namespace bbg

@@ -1,0 +1,296 @@
+// BN254 Fr / Fq arithmetic for gfx950 (CDNA4).
+//
+// Restates the arithmetic of the reference's field<Params> template
+// (barretenberg/src/aztec/ecc/fields/field_impl.hpp:34-157, generic bodies
+// field_impl_generic.hpp:171-442) for a 32-bit-multiplier GPU: 8 x u32 limbs,
+// little-endian, Montgomery form with R = 2^256 -- the SAME residues as the
+// reference's 4 x u64 limbs, so device buffers are byte-identical to the host
+// `fr` / `fq` arrays.  Like the reference ("small modulus" branches,
+// field_impl_generic.hpp:213-271) values are kept coarsely reduced in [0, 2p);
+// canonicalisation happens at the boundary (reduce_once()).
+//
+// All multiply work is v_mad_u64_u32 (32x32+64 -> 64); there is no MFMA use:
+// this is 256-bit modular integer arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bbg {
+
+// ---------------------------------------------------------------- parameters
+// Moduli / constants: reference ecc/curves/bn254/fr.hpp:12-42, fq.hpp:11-41
+// (re-derived with Python big-ints; 32-bit limb split of the same numbers).
+struct FrP {
+    static constexpr uint32_t MOD[8] = { 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u };
+    static constexpr uint32_t MOD2[8] = { 0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u,
+                                          0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u };
+    static constexpr uint32_t ONE[8] = { 0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                         0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u };
+    static constexpr uint32_t R2[8] = { 0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                        0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u };
+    static constexpr uint32_t INV = 0xefffffffu; // -p^-1 mod 2^32
+};
+struct FqP {
+    static constexpr uint32_t MOD[8] = { 0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u };
+    static constexpr uint32_t MOD2[8] = { 0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u,
+                                          0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u };
+    static constexpr uint32_t ONE[8] = { 0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                         0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u };
+    static constexpr uint32_t R2[8] = { 0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                        0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u };
+    static constexpr uint32_t INV = 0xe4866389u;
+};
+
+// ------------------------------------------------------------------- element
+template <class P> struct alignas(16) Fe {
+    uint32_t v[8];
+
+    __device__ __forceinline__ static Fe zero()
+    {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = 0;
+        return r;
+    }
+    __device__ __forceinline__ static Fe one()
+    {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = P::ONE[i];
+        return r;
+    }
+    __device__ __forceinline__ bool is_zero_raw() const
+    {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= v[i];
+        return o == 0;
+    }
+};
+
+// r = a - m, returns borrow (1 if a < m)
+template <class P> __device__ __forceinline__ uint32_t sub_limbs(uint32_t* r, const uint32_t* a, const uint32_t* m)
+{
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t d = (uint64_t)a[i] - m[i] - br;
+        r[i] = (uint32_t)d;
+        br = (d >> 32) & 1u;
+    }
+    return (uint32_t)br;
+}
+
+// coarse add: inputs in [0,2p) -> output in [0,2p)   (field_impl_generic.hpp:196-234)
+template <class P> __device__ __forceinline__ Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b)
+{
+    Fe<P> s, d;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        s.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)s.v[i] - P::MOD2[i] - br;
+        d.v[i] = (uint32_t)x;
+        br = (x >> 32) & 1u;
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = br ? s.v[i] : d.v[i];
+    return r;
+}
+
+// coarse sub: inputs in [0,2p) -> output in [0,2p)   (field_impl_generic.hpp:254-271)
+template <class P> __device__ __forceinline__ Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b)
+{
+    Fe<P> d;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)a.v[i] - b.v[i] - br;
+        d.v[i] = (uint32_t)x;
+        br = (x >> 32) & 1u;
+    }
+    uint32_t mask = 0u - (uint32_t)br;
+    uint64_t c = 0;
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)d.v[i] + (P::MOD2[i] & mask);
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+// 2p - a (a in [0,2p]); maps 0 -> 2p which reduce_once() canonicalises (field_impl.hpp:148-157)
+template <class P> __device__ __forceinline__ Fe<P> fe_neg(const Fe<P>& a)
+{
+    Fe<P> r;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)P::MOD2[i] - a.v[i] - br;
+        r.v[i] = (uint32_t)x;
+        br = (x >> 32) & 1u;
+    }
+    return r;
+}
+
+template <class P> __device__ __forceinline__ Fe<P> fe_dbl(const Fe<P>& a) { return fe_add(a, a); }
+
+// one conditional subtraction of p: [0,2p) -> [0,p)   (field_impl.hpp:100-112 reduce_once)
+template <class P> __device__ __forceinline__ Fe<P> fe_reduce_once(const Fe<P>& a)
+{
+    Fe<P> d, r;
+    uint32_t br = sub_limbs<P>(d.v, a.v, P::MOD);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
+    return r;
+}
+
+// full canonicalisation of any 256-bit value < 4p
+template <class P> __device__ __forceinline__ Fe<P> fe_canon(const Fe<P>& a)
+{
+    return fe_reduce_once(fe_reduce_once(fe_reduce_once(a)));
+}
+
+// Montgomery product a*b*R^-1.  For inputs < 2p (even a < 4p with b < p) the result is < 2p
+// with no final subtraction because 4p < 2^256 -- the same bound the reference relies on
+// (field_impl_generic.hpp:392-442 montgomery_mul, "coarse" form).
+//
+// Formulation: product scanning (FIPS).  Column k accumulates a_i*b_(k-i) and m_i*p_(k-i) into a
+// 96-bit accumulator {c2:acc}; v_mad_u64_u32 adds the 64-bit product into acc and its carry-out
+// is counted into c2 by one v_addc -- 2 VALU ops per limb product, which measured 138 Gmul/s on
+// MI355X against 104 Gmul/s for the compiler's CIOS lowering (bench_micro/mulbench.hip;
+// v_mad_u64_u32 issues at half rate, ~28 T/s chip-wide, so 136 mads alone bound a multiplication
+// at ~206 G/s).
+#define BBG_MAC(acc, c2, x, y)                                                                                       \
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                                     \
+        : "+v"(acc), "+v"(c2)                                                                                        \
+        : "v"(x), "v"(y)                                                                                             \
+        : "vcc")
+template <class P> __device__ __forceinline__ Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b)
+{
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    uint32_t m[8];
+    Fe<P> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) BBG_MAC(acc, c2, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) BBG_MAC(acc, c2, m[i], P::MOD[k - i]);
+        m[k] = (uint32_t)acc * P::INV;
+        BBG_MAC(acc, c2, m[k], P::MOD[0]);
+        acc = (acc >> 32) | ((uint64_t)c2 << 32);
+        c2 = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+#pragma unroll
+        for (int i = k - 7; i < 8; i++) BBG_MAC(acc, c2, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = k - 7; i < 8; i++) BBG_MAC(acc, c2, m[i], P::MOD[k - i]);
+        r.v[k - 8] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)c2 << 32);
+        c2 = 0;
+    }
+    return r;
+}
+
+// Reference formulation kept for cross-checking the asm path in tests (CIOS over 32-bit limbs;
+// running value T < 3p < 2^256 after each row, so 9 words suffice).
+template <class P> __device__ __forceinline__ Fe<P> fe_mul_cios(const Fe<P>& a, const Fe<P>& b)
+{
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t x = (uint64_t)a.v[j] * bi + t[j] + c;
+            t[j] = (uint32_t)x;
+            c = x >> 32;
+        }
+        t[8] = (uint32_t)c;
+        const uint32_t m = t[0] * P::INV;
+        uint64_t x = (uint64_t)m * P::MOD[0] + t[0];
+        c = x >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            x = (uint64_t)m * P::MOD[j] + t[j] + c;
+            t[j - 1] = (uint32_t)x;
+            c = x >> 32;
+        }
+        t[7] = t[8] + (uint32_t)c;
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return r;
+}
+
+template <class P> __device__ __forceinline__ Fe<P> fe_sqr(const Fe<P>& a) { return fe_mul(a, a); }
+
+template <class P> __device__ __forceinline__ Fe<P> fe_from_mont(const Fe<P>& a)
+{
+    Fe<P> o = Fe<P>::zero();
+    o.v[0] = 1;
+    return fe_reduce_once(fe_mul(a, o));
+}
+
+template <class P> __device__ __forceinline__ Fe<P> fe_to_mont(const Fe<P>& a)
+{
+    Fe<P> r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.v[i] = P::R2[i];
+    return fe_mul(a, r2);
+}
+
+template <class P> __device__ __forceinline__ bool fe_eq(const Fe<P>& a, const Fe<P>& b)
+{
+    Fe<P> x = fe_reduce_once(a), y = fe_reduce_once(b);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= x.v[i] ^ y.v[i];
+    return o == 0;
+}
+
+template <class P> __device__ __forceinline__ bool fe_is_zero(const Fe<P>& a)
+{
+    return fe_reduce_once(a).is_zero_raw();
+}
+
+// 16-byte vector loads/stores: two dwordx4 per element.
+template <class P> __device__ __forceinline__ Fe<P> fe_load(const void* p)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    Fe<P> r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+template <class P> __device__ __forceinline__ void fe_store(void* p, const Fe<P>& a)
+{
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+using Fr = Fe<FrP>;
+using Fq = Fe<FqP>;
+
+} // namespace bbg

@@ -1,0 +1,448 @@
+// Bucket-method multi-scalar multiplication over BN254 G1 for gfx950.
+//
+// Computes what scalar_multiplication::pippenger / pippenger_unsafe compute (reference
+// ecc/curves/bn254/scalar_multiplication/scalar_multiplication.cpp:853-929): sum_i s_i * P_i.
+//
+// The reference pipeline is: GLV split + signed-window recode (compute_wnaf_states :188-252) -> per-round radix
+// sort by bucket (organize_buckets :260-271, process_buckets.cpp:7-62) -> affine-trick bucket accumulation
+// (reduce_buckets :445-521, add_affine_points :305-340) -> running-sum + `w` doublings per round
+// (evaluate_pippenger_rounds :720-838).  The GPU pipeline keeps the bucket method but is re-designed around what
+// the SRS being FIXED and resident in 288 GB of HBM allows:
+//
+//   * registration (bbg_srs_register, the Pippenger-constructor hook) precomputes the window tables
+//     T[w][i] = 2^(16 w) * P_i, w = 0..15, in affine form.  They play the role of the reference's endomorphism
+//     table (generate_pippenger_point_table :104-112): more precomputation instead of the GLV split, and -- because
+//     every window's weight is already in the table -- all 16 windows share ONE set of 2^15 buckets: no per-round
+//     running sums, no inter-round doublings.
+//   * k_recode: scalar -> from_montgomery -> 16 signed 16-bit digits d in [-2^15, 2^15]; entry key = |d|
+//     (0 = no contribution), value = sign | window | point index.
+//   * radix sort of the (key, value) pairs by key: bucket b's contributions become one contiguous run.
+//   * k_accumulate: each bucket's run is split between T lanes; every lane gathers its table points (64-byte
+//     loads) and sums them with complete mixed XYZZ additions (curve.hip.h) -> T partial sums per bucket.
+//   * k_bucket_sum, k_rowcol, k_final: sum_b b * B_b evaluated as 256 * sum_hi hi*Row_hi + sum_lo (lo+1)*Col_lo
+//     with LDS tree reductions (short dependency chains; a single EC addition is ~6 us of latency on one wave).
+//
+// All exceptional cases of the group law are handled (the reference's handle_edge_cases = true behaviour), so
+// pippenger_unsafe's "attempted to invert zero" failure mode (:317-318) does not exist here.
+#include "bbg_internal.h"
+#include "curve.hip.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace bbg {
+
+constexpr int MSM_WINDOWS = 16;     // 16-bit windows over a 254-bit scalar
+constexpr int MSM_C = 16;
+constexpr int MSM_BUCKETS = 1 << 15; // |digit| in [1, 2^15]
+constexpr int MSM_T = 8;             // lanes per bucket in the accumulation kernel
+constexpr int MSM_IDX_BITS = 26;     // point index bits in an entry value (n <= 2^26 per call)
+
+static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
+
+// ---------------------------------------------------------------------------------- SRS precomputation
+// table[w * n + i] = 2^(16 w) * P_i (affine, canonical).  One thread per point: 15 x 16 doublings in XYZZ,
+// then one shared inversion (Montgomery's trick over the 15 Z-products) to normalise.
+__global__ void __launch_bounds__(128) k_precompute_tables(const Affine* __restrict__ points, Affine* table, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p = aff_load(points + i);
+    if (aff_is_inf(p)) {
+        for (int w = 0; w < MSM_WINDOWS; w++) aff_store(table + (size_t)w * n + i, aff_inf());
+        return;
+    }
+    p.x = fe_reduce_once(p.x);
+    p.y = fe_reduce_once(p.y);
+    aff_store(table + i, p);
+    // the 15 multiples live in per-thread scratch (one-off kernel: simplicity over registers)
+    Xyzz pts[MSM_WINDOWS - 1];
+    Fq prod[MSM_WINDOWS - 1];
+    Xyzz q = xyzz_dbl_affine(p);
+    for (int k = 1; k < MSM_C; k++) q = xyzz_dbl(q);
+    Fq acc = Fq::one();
+    for (int w = 1; w < MSM_WINDOWS; w++) {
+        pts[w - 1] = q;
+        prod[w - 1] = acc;
+        acc = fe_mul(acc, fe_mul(q.zz, q.zzz));
+        if (w < MSM_WINDOWS - 1)
+            for (int k = 0; k < MSM_C; k++) q = xyzz_dbl(q);
+    }
+    Fq inv = fq_invert(acc);
+    for (int w = MSM_WINDOWS - 1; w >= 1; w--) {
+        const Xyzz& t = pts[w - 1];
+        Fq iz = fe_mul(inv, prod[w - 1]); // 1 / (ZZ * ZZZ) of point w
+        inv = fe_mul(inv, fe_mul(t.zz, t.zzz));
+        Affine a;
+        a.x = fe_reduce_once(fe_mul(t.x, fe_mul(iz, t.zzz))); // X / ZZ
+        a.y = fe_reduce_once(fe_mul(t.y, fe_mul(iz, t.zz)));  // Y / ZZZ
+        aff_store(table + (size_t)w * n + i, a);
+    }
+}
+
+// P_i = (a + i*s) * G : thread t owns CH consecutive points; start by double-and-add, then madd steps, normalise
+// with one inversion per thread.
+constexpr int SYNTH_CH = 16;
+__device__ Xyzz g1_mul_u64(const Affine& g, uint64_t k)
+{
+    Xyzz acc = xyzz_inf();
+    for (int i = 63; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k >> i) & 1) acc = xyzz_madd(acc, g);
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(128) k_srs_synth(Affine* out, size_t n, uint64_t a, uint64_t s)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i0 = t * SYNTH_CH;
+    if (i0 >= n) return;
+    Affine G;
+    G.x = Fq::one();
+    Fq two = Fq::zero();
+    two.v[0] = 2;
+    G.y = fe_reduce_once(fe_to_mont(two));
+    Affine S = xyzz_to_affine(g1_mul_u64(G, s));
+    Xyzz q = g1_mul_u64(G, a + (uint64_t)i0 * s);
+    Xyzz pts[SYNTH_CH];
+    Fq prod[SYNTH_CH];
+    Fq acc = Fq::one();
+    int cnt = 0;
+    for (int e = 0; e < SYNTH_CH && i0 + e < n; e++) {
+        pts[e] = q;
+        prod[e] = acc;
+        acc = fe_mul(acc, fe_mul(q.zz, q.zzz));
+        q = xyzz_madd(q, S);
+        cnt++;
+    }
+    Fq inv = fq_invert(acc);
+    for (int e = cnt - 1; e >= 0; e--) {
+        Fq iz = fe_mul(inv, prod[e]);
+        inv = fe_mul(inv, fe_mul(pts[e].zz, pts[e].zzz));
+        Affine o;
+        o.x = fe_reduce_once(fe_mul(pts[e].x, fe_mul(iz, pts[e].zzz)));
+        o.y = fe_reduce_once(fe_mul(pts[e].y, fe_mul(iz, pts[e].zz)));
+        aff_store(out + i0 + e, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------- scalar recoding
+// scalar (Montgomery, any rep < 2^256) -> canonical integer k -> digits d_w in [-2^15, 2^15], k = sum d_w 2^(16 w).
+// Replaces compute_wnaf_states + fixed_wnaf_with_counts (scalar_multiplication.cpp:188-252, wnaf.hpp:230-283):
+// same idea (signed windows halve the bucket count), but plain signed digits with carry instead of the
+// odd-digit + skew form, and zero digits produce no work.
+__global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* keys,
+                                                uint32_t* vals)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fe_load<FrP>(scalars + i);
+    // from_montgomery = Montgomery product with the integer 1: (s + m*r) / 2^256 <= r for ANY 256-bit s, so one
+    // conditional subtraction canonicalises (from_montgomery_form, field_impl.hpp:245-255)
+    Fr k = fe_from_mont(s); // canonical integer < r < 2^254
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < MSM_WINDOWS; w++) {
+        uint32_t limb = k.v[w >> 1];
+        uint32_t d = ((w & 1) ? (limb >> 16) : (limb & 0xffffu)) + carry; // 0 .. 2^16
+        uint32_t neg = d > 0x8000u;
+        uint32_t mag = neg ? (0x10000u - d) : d; // |digit| in [0, 2^15]
+        carry = neg;
+        keys[(size_t)w * n + i] = mag;
+        vals[(size_t)w * n + i] = (neg << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
+    }
+    // top window: k < 2^254 so the last digit is < 2^14 + 1 and never produces a carry
+}
+
+// offsets[b] = first sorted position with key >= b, for b = 0 .. MSM_BUCKETS + 1
+__global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint32_t* offsets)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > total) return;
+    if (e == total) {
+        uint32_t last = total ? keys[total - 1] : 0;
+        if (total == 0) offsets[0] = 0;
+        for (uint32_t b = last + 1; b <= MSM_BUCKETS + 1; b++) offsets[b] = (uint32_t)total;
+        return;
+    }
+    uint32_t k = keys[e];
+    if (e == 0) {
+        for (uint32_t b = 0; b <= k; b++) offsets[b] = 0;
+    } else {
+        uint32_t kp = keys[e - 1];
+        for (uint32_t b = kp + 1; b <= k; b++) offsets[b] = (uint32_t)e;
+    }
+}
+
+// ---------------------------------------------------------------------------------- bucket accumulation
+// thread (b, t): sums its 1/T share of bucket b's sorted run.  Values address the window tables:
+// point = table[w * n_srs + idx], negated when bit 31 is set.
+__global__ void __launch_bounds__(256)
+k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
+             size_t n_srs, Xyzz* partials)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = gid / MSM_T + 1; // bucket 1 .. 2^15
+    const uint32_t t = gid % MSM_T;
+    if (b > MSM_BUCKETS) return;
+    const uint32_t s = offsets[b], e = offsets[b + 1];
+    const uint32_t cnt = e - s;
+    const uint32_t lo = s + (uint32_t)(((uint64_t)cnt * t) / MSM_T);
+    const uint32_t hi = s + (uint32_t)(((uint64_t)cnt * (t + 1)) / MSM_T);
+    Xyzz acc = xyzz_inf();
+    if (lo < hi) {
+        uint32_t v = vals[lo];
+        Affine p = aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
+        for (uint32_t q = lo; q < hi; q++) {
+            const uint32_t vc = v;
+            Affine pc = p;
+            if (q + 1 < hi) { // software prefetch of the next gather
+                v = vals[q + 1];
+                p = aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
+            }
+            acc = xyzz_madd(acc, aff_neg_if(pc, (vc >> 31) != 0));
+        }
+    }
+    xyzz_store(partials + (size_t)(b - 1) * MSM_T + t, acc);
+}
+
+// bucket[b-1] = sum_t partials[b-1][t]
+__global__ void __launch_bounds__(256) k_bucket_sum(const Xyzz* __restrict__ partials, Xyzz* buckets)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= MSM_BUCKETS) return;
+    Xyzz acc = xyzz_load(partials + (size_t)b * MSM_T);
+    for (int t = 1; t < MSM_T; t++) acc = xyzz_add(acc, xyzz_load(partials + (size_t)b * MSM_T + t));
+    xyzz_store(buckets + b, acc);
+}
+
+// LDS tree reduction of one point per thread; result valid in thread 0.
+__device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads)
+{
+    const int tid = threadIdx.x;
+    for (int stride = nthreads >> 1; stride >= 1; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) sm[tid - stride] = v;
+        __syncthreads();
+        if (tid < stride) v = xyzz_add(v, sm[tid]);
+        __syncthreads();
+    }
+    return v;
+}
+
+// weight of bucket index idx (0-based) is idx + 1 = hi*256 + lo + 1.
+// blocks 0..127: Row_hi = sum_lo B[hi][lo] ; blocks 128..383: Col_lo = sum_hi B[hi][lo].
+__global__ void __launch_bounds__(256) k_rowcol(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
+{
+    __shared__ Xyzz sm[128];
+    const int tid = threadIdx.x;
+    if (blockIdx.x < 128) {
+        const int hi = blockIdx.x;
+        Xyzz v = xyzz_load(buckets + hi * 256 + tid);
+        v = block_reduce(v, sm, 256);
+        if (tid == 0) xyzz_store(rows + hi, v);
+    } else {
+        const int lo = blockIdx.x - 128;
+        Xyzz v = tid < 128 ? xyzz_load(buckets + tid * 256 + lo) : xyzz_inf();
+        v = block_reduce(v, sm, 256);
+        if (tid == 0) xyzz_store(cols + lo, v);
+    }
+}
+
+__device__ Xyzz xyzz_mul_small(const Xyzz& p, uint32_t k)
+{
+    Xyzz acc = xyzz_inf();
+    for (int i = 31 - __clz(k | 1); i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k >> i) & 1) acc = xyzz_add(acc, p);
+    }
+    return k ? acc : xyzz_inf();
+}
+
+// one block of 512 threads: threads 0..127 weigh rows by hi, 256..511 weigh columns by lo+1; result =
+// 256 * sum(rows) + sum(cols), optionally added to `accumulate_into`, written as the reference's Jacobian.
+__global__ void __launch_bounds__(512) k_final(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Jacobian* out)
+{
+    __shared__ Xyzz sm[256];
+    __shared__ Xyzz rowsum;
+    const int tid = threadIdx.x;
+    Xyzz v = xyzz_inf();
+    if (tid < 128) v = xyzz_mul_small(xyzz_load(rows + tid), (uint32_t)tid);
+    else if (tid >= 256) v = xyzz_mul_small(xyzz_load(cols + (tid - 256)), (uint32_t)(tid - 256 + 1));
+    // reduce the two halves separately: lanes [0,256) and [256,512)
+    const int half = tid >> 8, l = tid & 255;
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        // two independent trees sharing the barrier; each half uses its own 128-entry region of sm
+        if (l >= stride && l < 2 * stride) sm[half * 128 + (l - stride)] = v;
+        __syncthreads();
+        if (l < stride) v = xyzz_add(v, sm[half * 128 + l]);
+        __syncthreads();
+    }
+    if (tid == 0) rowsum = v;
+    __syncthreads();
+    if (tid == 256) {
+        Xyzz r = rowsum;
+        for (int k = 0; k < 8; k++) r = xyzz_dbl(r);
+        r = xyzz_add(r, v);
+        Jacobian j = xyzz_to_jacobian(r);
+        fe_store<FqP>(&out->x, j.x);
+        fe_store<FqP>(&out->y, j.y);
+        fe_store<FqP>(&out->z, j.z);
+    }
+}
+
+// sum of n Jacobian points (g1_sum, reference c_bind.cpp:39-46): one block, serial per thread then tree.
+__global__ void __launch_bounds__(256) k_g1_sum(const Jacobian* __restrict__ pts, size_t n, Jacobian* out)
+{
+    __shared__ Xyzz sm[128];
+    Xyzz acc = xyzz_inf();
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        Jacobian j;
+        j.x = fe_load<FqP>(&pts[i].x);
+        j.y = fe_load<FqP>(&pts[i].y);
+        j.z = fe_load<FqP>(&pts[i].z);
+        acc = xyzz_add(acc, xyzz_from_jacobian(j));
+    }
+    acc = block_reduce(acc, sm, 256);
+    if (threadIdx.x == 0) {
+        Jacobian j = xyzz_to_jacobian(acc);
+        fe_store<FqP>(&out->x, j.x);
+        fe_store<FqP>(&out->y, j.y);
+        fe_store<FqP>(&out->z, j.z);
+    }
+}
+// g1::affine_element(element) (element_impl.hpp:51-68) for n points
+__global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ pts, size_t n, Affine* out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jacobian j;
+    j.x = fe_load<FqP>(&pts[i].x);
+    j.y = fe_load<FqP>(&pts[i].y);
+    j.z = fe_load<FqP>(&pts[i].z);
+    if ((j.x.v[7] >> 31) != 0) {
+        aff_store(out + i, aff_inf());
+        return;
+    }
+    // bring arbitrary 256-bit representatives into range first
+    j.x = fe_reduce_once(fe_reduce_once(j.x));
+    j.y = fe_reduce_once(fe_reduce_once(j.y));
+    j.z = fe_reduce_once(fe_reduce_once(j.z));
+    aff_store(out + i, xyzz_to_affine(xyzz_from_jacobian(j)));
+}
+
+// ---------------------------------------------------------------------------------- host side
+struct MsmLayout {
+    size_t entries;
+    size_t off_keys0, off_keys1, off_vals0, off_vals1, off_offsets, off_partials, off_buckets, off_rows, off_cols, off_sort;
+    size_t sort_bytes;
+    size_t total;
+};
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int msm_layout(size_t n, MsmLayout& L)
+{
+    L.entries = n * MSM_WINDOWS;
+    size_t tmp = 0;
+    rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C);
+    if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs(size query)", __FILE__, __LINE__);
+    L.sort_bytes = tmp;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.off_keys0 = take(L.entries * 4);
+    L.off_keys1 = take(L.entries * 4);
+    L.off_vals0 = take(L.entries * 4);
+    L.off_vals1 = take(L.entries * 4);
+    L.off_offsets = take((MSM_BUCKETS + 2) * 4);
+    L.off_partials = take((size_t)MSM_BUCKETS * MSM_T * sizeof(Xyzz));
+    L.off_buckets = take((size_t)MSM_BUCKETS * sizeof(Xyzz));
+    L.off_rows = take(128 * sizeof(Xyzz));
+    L.off_cols = take(256 * sizeof(Xyzz));
+    L.off_sort = take(L.sort_bytes);
+    L.total = o;
+    return BBG_OK;
+}
+
+int srs_build_tables(const void* d_points, size_t n, void* d_table, hipStream_t st)
+{
+    if (n == 0) return BBG_OK;
+    hipLaunchKernelGGL(k_precompute_tables, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Affine*)d_points,
+                       (Affine*)d_table, n);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+int srs_synth_linear(bbg_ctx*, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t st)
+{
+    if (n == 0) return BBG_OK;
+    hipLaunchKernelGGL(k_srs_synth, dim3(grid_for((n + SYNTH_CH - 1) / SYNTH_CH, 128)), dim3(128), 0, st, (Affine*)d_points, n, a,
+                       s);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st)
+{
+    if (from > srs.n || n > srs.n - from) {
+        set_error("bbg_msm: range [from, from+n) exceeds the registered SRS");
+        return BBG_E_INVALID;
+    }
+    if (srs.n > ((size_t)1 << MSM_IDX_BITS)) {
+        set_error("bbg_msm: SRS larger than 2^26 points per device is not supported (shard it across devices)");
+        return BBG_E_INVALID;
+    }
+    if (n == 0) {
+        // pippenger(): n == 0 -> point at infinity (scalar_multiplication.cpp:868-872)
+        uint64_t inf[12] = { 0, 0, 0, 1ULL << 63, 0, 0, 0, 0, 0, 0, 0, 0 };
+        BBG_HIP(hipMemcpyAsync(d_out_jac, inf, 96, hipMemcpyHostToDevice, st));
+        BBG_HIP(hipStreamSynchronize(st));
+        return BBG_OK;
+    }
+    MsmLayout L;
+    int rc = msm_layout(n, L);
+    if (rc) return rc;
+    rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
+    if (rc) return rc;
+    char* base = (char*)ctx->msm.buf;
+    uint32_t* keys0 = (uint32_t*)(base + L.off_keys0);
+    uint32_t* keys1 = (uint32_t*)(base + L.off_keys1);
+    uint32_t* vals0 = (uint32_t*)(base + L.off_vals0);
+    uint32_t* vals1 = (uint32_t*)(base + L.off_vals1);
+    uint32_t* offsets = (uint32_t*)(base + L.off_offsets);
+    Xyzz* partials = (Xyzz*)(base + L.off_partials);
+    Xyzz* buckets = (Xyzz*)(base + L.off_buckets);
+    Xyzz* rows = (Xyzz*)(base + L.off_rows);
+    Xyzz* cols = (Xyzz*)(base + L.off_cols);
+
+    hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
+    rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
+    size_t tmp = L.sort_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C, st);
+    if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
+    const uint32_t* skeys = dk.current();
+    const uint32_t* svals = dv.current();
+    hipLaunchKernelGGL(k_offsets, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for((size_t)MSM_BUCKETS * MSM_T, 256)), dim3(256), 0, st, svals, offsets,
+                       (const Affine*)srs.points, srs.n, partials);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(grid_for(MSM_BUCKETS, 256)), dim3(256), 0, st, partials, buckets);
+    hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, st, buckets, rows, cols);
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(512), 0, st, rows, cols, (Jacobian*)d_out_jac);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+int g1_sum_device(bbg_ctx*, const void* d_jacs, size_t n, void* d_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(256), 0, st, (const Jacobian*)d_jacs, n, (Jacobian*)d_out);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st)
+{
+    if (n == 0) return BBG_OK;
+    hipLaunchKernelGGL(k_normalize, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Jacobian*)d_jacs, n, (Affine*)d_out);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+} // namespace bbg

@@ -1,0 +1,643 @@
+// Radix-2^r multi-pass NTT over BN254 Fr for gfx950.
+//
+// Computes what the reference's polynomial_arithmetic::fft family computes
+// (polynomials/polynomial_arithmetic.cpp:140-255 fft_inner_parallel, :374-484 the public variants):
+// A_i = sum_j a_j w^(ij), natural order in, natural order out, in place from the caller's view.
+//
+// The reference runs log2(n) radix-2 stages over the whole array (one OpenMP barrier per stage).  Here the
+// transform of size n = R_1 * R_2 * ... * R_p is split into p passes (p <= 4); pass q performs R_q-point
+// sub-transforms entirely inside LDS, so the array crosses HBM p times instead of log2(n) times:
+//
+//   storage position = d_1*(n/R_1) + d_2*(n/(R_1 R_2)) + ...      (d_q = digit owned by pass q)
+//   pass q < p ("column" pass):  for fixed higher digits and W consecutive lower positions `lo`, transform over d_q
+//        (stride S_q = n / (R_1..R_q)), multiply by the inter-pass twiddle w_{R_q S_q}^(i_q * lo), write back in place.
+//   pass p   ("row" pass):       contiguous R_p-point transforms; result i_p of row (d_1..d_{p-1}) goes to natural
+//        index  d_1 + R_1*(d_2 + R_2*(... + R_{p-1}*i_p)), i.e. the digit reversal is folded into the last store.
+//        A tile holds W rows with consecutive d_1 so the stores are W*32-byte runs.
+//
+// Inside a tile the R-point transform is decimation-in-frequency on an LDS tile laid out [column][k] in two
+// 16-byte planes (conflict-free ds_read_b128 along k); the bit-reversed result order is undone when the tile is
+// written out.  Butterfly: u = a + b, v = (a - b) * w  (1 Montgomery mul, skipped in the last stage where w = 1).
+//
+// Roofline note: one Fr multiplication is ~136 v_mad_u64_u32; the pass kernels are integer-ALU bound,
+// not HBM bound -- the 64n algorithmic bytes cross HBM p (2..3) times plus one twiddle-table read.
+#include "bbg_internal.h"
+#include "field.hip.h"
+
+namespace bbg {
+
+struct DomainConsts {
+    Fr root, root_inv, n_inv, gen, gen_inv;
+    Fr pow2_root[32];     // root^(2^b)
+    Fr pow2_root_inv[32]; // root_inv^(2^b)
+    Fr pow2_tmp[32];      // scratch table for arbitrary bases (generator shift paths)
+    Fr constant;          // staged caller constant (ops 4..7)
+    Fr gk;                // running generator of the split coset FFT
+};
+
+// Primitive 2^28-th root of unity, Montgomery form (reference ecc/curves/bn254/fr.hpp:27-30).
+__device__ __constant__ uint32_t FR_PRIMITIVE_ROOT_28[8] = { 0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u,
+                                                             0x1eb203d8u, 0x56452ac0u, 0x2963f9e7u, 0x1860ef94u };
+
+__device__ Fr fr_pow_u256(Fr a, const uint32_t* e)
+{
+    Fr acc = Fr::one();
+    for (int i = 255; i >= 0; i--) {
+        acc = fe_sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
+    }
+    return acc;
+}
+__device__ Fr fr_invert(Fr a)
+{
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = FrP::MOD[i];
+    e[0] -= 2; // p - 2 (low limb 0xf0000001, no borrow)
+    return fr_pow_u256(a, e);
+}
+
+// evaluation_domain constructor restated on device (polynomials/evaluation_domain.cpp:57-76;
+// get_root_of_unity: ecc/fields/field_impl.hpp:496-503; coset_generator(0) = 5: fr.hpp:44-59).
+__global__ void k_domain_init(DomainConsts* c, unsigned log2n)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fr root;
+#pragma unroll
+    for (int i = 0; i < 8; i++) root.v[i] = FR_PRIMITIVE_ROOT_28[i];
+    for (unsigned i = 28; i > log2n; i--) root = fe_sqr(root);
+    Fr root_inv = fr_invert(root);
+    Fr nn = Fr::zero();
+    // n = 2^log2n as a plain integer (log2n <= 28 fits limb 0), then to Montgomery form
+    nn.v[0] = 1u << log2n;
+    Fr n_inv = fr_invert(fe_to_mont(nn));
+    Fr five = Fr::zero();
+    five.v[0] = 5;
+    Fr gen = fe_to_mont(five);
+    c->root = fe_reduce_once(root);
+    c->root_inv = fe_reduce_once(root_inv);
+    c->n_inv = fe_reduce_once(n_inv);
+    c->gen = fe_reduce_once(gen);
+    c->gen_inv = fe_reduce_once(fr_invert(gen));
+    Fr a = c->root, b = c->root_inv;
+    for (int i = 0; i < 32; i++) {
+        c->pow2_root[i] = a;
+        c->pow2_root_inv[i] = b;
+        a = fe_reduce_once(fe_sqr(a));
+        b = fe_reduce_once(fe_sqr(b));
+    }
+}
+
+// pow2[b] = base^(2^b)
+__global__ void k_pow2_table(Fr* pow2, const Fr* base_a, const Fr* base_b)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fr a = *base_a;
+    if (base_b) a = fe_mul(a, *base_b);
+    a = fe_reduce_once(a);
+    for (int i = 0; i < 32; i++) {
+        pow2[i] = a;
+        a = fe_reduce_once(fe_sqr(a));
+    }
+}
+
+__device__ __forceinline__ Fr pow_from_table(const Fr* __restrict__ pow2, uint64_t e)
+{
+    Fr acc = Fr::one();
+    int b = 0;
+    while (e) {
+        if (e & 1) acc = fe_mul(acc, pow2[b]);
+        e >>= 1;
+        b++;
+    }
+    return acc;
+}
+
+// out[(i << logS) + lo] = w^(i * lo)   (inter-pass twiddles, canonical so that a < 4p operand bound holds)
+__global__ void k_twiddle_2d(Fr* out, const Fr* pow2, int logR, int logS, const Fr* scale)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)1 << (logR + logS);
+    if (idx >= total) return;
+    uint64_t i = idx >> logS, lo = idx & (((size_t)1 << logS) - 1);
+    Fr w = pow_from_table(pow2, i * lo);
+    if (scale) w = fe_mul(w, *scale);
+    fe_store<FrP>(out + idx, fe_reduce_once(w));
+}
+// out[j] = w^(j * step), j < count   (radix twiddles: step = n / R)
+__global__ void k_twiddle_1d(Fr* out, const Fr* pow2, size_t count, uint64_t step)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    fe_store<FrP>(out + idx, fe_reduce_once(pow_from_table(pow2, idx * step)));
+}
+// out[j] = start * base^j, j < count, `pow2` = table of base^(2^b).  Each thread does E consecutive entries.
+constexpr int POW_E = 16;
+__global__ void k_powers(Fr* out, const Fr* pow2, const Fr* start, size_t count)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t j0 = t * POW_E;
+    if (j0 >= count) return;
+    Fr g = pow_from_table(pow2, j0);
+    if (start) g = fe_mul(g, *start);
+    const Fr base = pow2[0];
+    for (int e = 0; e < POW_E && j0 + e < count; e++) {
+        fe_store<FrP>(out + j0 + e, fe_reduce_once(g));
+        g = fe_mul(g, base);
+    }
+}
+// a[j] *= table[j], j < count
+__global__ void k_scale_table(Fr* a, const Fr* __restrict__ table, size_t count)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    fe_store<FrP>(a + j, fe_mul(fe_load<FrP>(a + j), fe_load<FrP>(table + j)));
+}
+// a[j] *= c
+__global__ void k_scale_const(Fr* a, const Fr* c, size_t count)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    fe_store<FrP>(a + j, fe_mul(fe_load<FrP>(a + j), *c));
+}
+// a[j] *= start * base^j computed on the fly (arbitrary generator: coset_fft_with_generator_shift / _with_constant)
+__global__ void k_scale_powers(Fr* a, const Fr* pow2, const Fr* start, size_t count)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t j0 = t * POW_E;
+    if (j0 >= count) return;
+    Fr g = pow_from_table(pow2, j0);
+    if (start) g = fe_mul(g, *start);
+    const Fr base = pow2[0];
+    for (int e = 0; e < POW_E && j0 + e < count; e++) {
+        fe_store<FrP>(a + j0 + e, fe_mul(fe_load<FrP>(a + j0 + e), g));
+        g = fe_mul(g, base);
+    }
+}
+// d[j] = reduce_once(a[j]): canonical output like the reference's operator== / serialisation sees it
+__global__ void k_canon(Fr* a, size_t count)
+{
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    fe_store<FrP>(a + j, fe_reduce_once(fe_load<FrP>(a + j)));
+}
+// interleave ext sub-results: out[ext*i + k] = in[k*n + i]   (coset_fft 4-way split, polynomial_arithmetic.cpp:432-455)
+__global__ void k_interleave(const Fr* in, Fr* out, int log2n, int logext)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)1 << (log2n + logext);
+    if (idx >= total) return;
+    size_t k = idx & (((size_t)1 << logext) - 1), i = idx >> logext;
+    fe_store<FrP>(out + idx, fe_load<FrP>(in + (k << log2n) + i));
+}
+__global__ void k_replicate(Fr* buf, int log2n, int ext)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)1 << log2n;
+    if (idx >= n) return;
+    Fr v = fe_load<FrP>(buf + idx);
+    for (int k = 1; k < ext; k++) fe_store<FrP>(buf + (size_t)k * n + idx, v);
+}
+
+// ------------------------------------------------------------------------------------------ pass kernel
+struct PassParams {
+    const Fr* in;
+    Fr* out;
+    const Fr* tw_inter; // [R][S] table or nullptr
+    const Fr* tw_radix; // R/2 entries
+    const Fr* post;     // optional per-output-element multiplier table indexed by natural output index (row pass only)
+    int logR, logW, logS; // logS = log2(stride) (0 for the row pass)
+    int row_pass;
+    int log2n;
+    int logR1;   // row pass: log2 of the first digit's radix (rows of a tile differ in d_1)
+    int nmid;    // row pass: number of middle digits (0..2)
+    int logMid[2];
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
+
+__global__ void __launch_bounds__(1024) k_ntt_pass(PassParams p)
+{
+    extern __shared__ uint4 lds[];
+    const int R = 1 << p.logR, W = 1 << p.logW;
+    const int pitch = R + 1;
+    uint4* plo = lds;
+    uint4* phi = lds + W * pitch;
+    uint4* tlo = phi + W * pitch;
+    uint4* thi = tlo + (R >> 1);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t tile = blockIdx.x;
+    const int tile_elems = R * W;
+
+    for (int i = tid; i < (R >> 1); i += nt) {
+        const uint4* q = reinterpret_cast<const uint4*>(p.tw_radix + i);
+        tlo[i] = q[0];
+        thi[i] = q[1];
+    }
+
+    // ---- load tile: LDS element (k, c) lives at plane[c * pitch + k]
+    size_t base = 0;      // column pass: position of (k=0, c=0)
+    size_t lo0 = 0;       // column pass: first low position of the tile
+    size_t d1_0 = 0, rest = 0; // row pass
+    if (!p.row_pass) {
+        const int tiles_per_hi_log = p.logS - p.logW;
+        const size_t hi = tile >> tiles_per_hi_log;
+        lo0 = (tile & (((size_t)1 << tiles_per_hi_log) - 1)) << p.logW;
+        base = (hi << (p.logR + p.logS)) + lo0;
+        for (int e = tid; e < tile_elems; e += nt) {
+            const int c = e & (W - 1), k = e >> p.logW;
+            const uint4* q = reinterpret_cast<const uint4*>(p.in + base + ((size_t)k << p.logS) + c);
+            plo[c * pitch + k] = q[0];
+            phi[c * pitch + k] = q[1];
+        }
+    } else {
+        // rows are indexed by hi = d_1 * (rows / R_1) + rest ; a tile takes W consecutive d_1 for one `rest`
+        const int logRows = p.log2n - p.logR;         // total rows = n / R
+        const int logRestCount = logRows - p.logR1;   // rows per d_1
+        rest = tile & (((size_t)1 << logRestCount) - 1);
+        d1_0 = (tile >> logRestCount) << p.logW;
+        for (int e = tid; e < tile_elems; e += nt) {
+            const int k = e & (R - 1), c = e >> p.logR;
+            const size_t row = ((d1_0 + c) << logRestCount) + rest;
+            const uint4* q = reinterpret_cast<const uint4*>(p.in + (row << p.logR) + k);
+            plo[c * pitch + k] = q[0];
+            phi[c * pitch + k] = q[1];
+        }
+    }
+    __syncthreads();
+
+    // ---- decimation-in-frequency stages, half-size m = R/2 ... 1
+    const int half = R >> 1;
+    const int nbf = half * W;
+    for (int s = p.logR - 1; s >= 0; s--) {
+        const int m = 1 << s;
+        for (int b = tid; b < nbf; b += nt) {
+            const int c = b >> (p.logR - 1);
+            const int bb = b & (half - 1);
+            const int j = bb & (m - 1);
+            const int k = ((bb >> s) << (s + 1)) + j;
+            const int ia = c * pitch + k, ib = ia + m;
+            uint4 alo = plo[ia], ahi = phi[ia], blo = plo[ib], bhi = phi[ib];
+            Fr a, bv;
+            a.v[0] = alo.x; a.v[1] = alo.y; a.v[2] = alo.z; a.v[3] = alo.w;
+            a.v[4] = ahi.x; a.v[5] = ahi.y; a.v[6] = ahi.z; a.v[7] = ahi.w;
+            bv.v[0] = blo.x; bv.v[1] = blo.y; bv.v[2] = blo.z; bv.v[3] = blo.w;
+            bv.v[4] = bhi.x; bv.v[5] = bhi.y; bv.v[6] = bhi.z; bv.v[7] = bhi.w;
+            Fr u = fe_add(a, bv);
+            Fr v = fe_sub(a, bv);
+            if (s > 0) {
+                const int ti = j << (p.logR - 1 - s);
+                uint4 wlo = tlo[ti], whi = thi[ti];
+                Fr w;
+                w.v[0] = wlo.x; w.v[1] = wlo.y; w.v[2] = wlo.z; w.v[3] = wlo.w;
+                w.v[4] = whi.x; w.v[5] = whi.y; w.v[6] = whi.z; w.v[7] = whi.w;
+                v = fe_mul(v, w);
+            }
+            plo[ia] = make_uint4(u.v[0], u.v[1], u.v[2], u.v[3]);
+            phi[ia] = make_uint4(u.v[4], u.v[5], u.v[6], u.v[7]);
+            plo[ib] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            phi[ib] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store: LDS row k holds result index i = bitrev(k); lanes run along c (consecutive global positions)
+    for (int e = tid; e < tile_elems; e += nt) {
+        const int c = e & (W - 1), k = e >> p.logW;
+        const uint32_t i = bitrev((uint32_t)k, p.logR);
+        uint4 xlo = plo[c * pitch + k], xhi = phi[c * pitch + k];
+        Fr x;
+        x.v[0] = xlo.x; x.v[1] = xlo.y; x.v[2] = xlo.z; x.v[3] = xlo.w;
+        x.v[4] = xhi.x; x.v[5] = xhi.y; x.v[6] = xhi.z; x.v[7] = xhi.w;
+        size_t dst;
+        if (!p.row_pass) {
+            if (p.tw_inter) x = fe_mul(x, fe_load<FrP>(p.tw_inter + ((size_t)i << p.logS) + lo0 + c));
+            dst = base + ((size_t)i << p.logS) + c;
+        } else {
+            // natural index = d_1 + R_1 * (mid digits, least significant = first middle digit) + (n / R) * i
+            size_t acc = 0;
+            int shift = 0;
+            size_t r = rest;
+            // rest = d_2 * R_3 + d_3 (most significant first); output wants d_2 + R_2 * d_3
+            if (p.nmid == 1) {
+                acc = r;
+                shift = p.logMid[0];
+            } else if (p.nmid == 2) {
+                const size_t d3 = r & (((size_t)1 << p.logMid[1]) - 1), d2 = r >> p.logMid[1];
+                acc = d2 + (d3 << p.logMid[0]);
+                shift = p.logMid[0] + p.logMid[1];
+            }
+            dst = (d1_0 + c) + (acc << p.logR1) + ((size_t)i << (p.logR1 + shift));
+            if (p.post) x = fe_mul(x, fe_load<FrP>(p.post + dst));
+        }
+        fe_store<FrP>(p.out + dst, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
+
+static void plan_passes(bbg_ctx* ctx, NttDomain& d)
+{
+    const int L = (int)d.log2n;
+    const int tile = ctx->ntt_tile_log;
+    int maxr = ctx->ntt_max_logr;
+    if (maxr > tile) maxr = tile;
+    if (maxr > 10) maxr = 10; // LDS: 2 planes + R/2 radix twiddles must fit 160 KiB
+    if (L <= 11) {
+        d.passes = 1;
+        d.logR[0] = L;
+        d.logW[0] = 0;
+        return;
+    }
+    int p = (L + maxr - 1) / maxr;
+    if (p < 2) p = 2;
+    d.passes = p;
+    int rem = L;
+    for (int q = 0; q < p; q++) {
+        int r = (rem + (p - q) - 1) / (p - q);
+        d.logR[q] = r;
+        rem -= r;
+    }
+    for (int q = 0; q < p; q++) {
+        int w = tile - d.logR[q];
+        // column pass q: W <= S_q ; row pass: W <= R_1
+        int logS = L;
+        for (int k = 0; k <= q; k++) logS -= d.logR[k];
+        if (q < p - 1 && w > logS) w = logS;
+        if (q == p - 1 && w > d.logR[0]) w = d.logR[0];
+        d.logW[q] = w;
+    }
+}
+
+void ntt_free_domain(NttDomain& d)
+{
+    if (d.consts) (void)hipFree(d.consts);
+    for (int inv = 0; inv < 2; inv++)
+        for (int q = 0; q < NTT_MAX_PASSES; q++) {
+            if (d.tw_inter[inv][q]) (void)hipFree(d.tw_inter[inv][q]);
+            if (d.tw_radix[inv][q]) (void)hipFree(d.tw_radix[inv][q]);
+        }
+    if (d.coset_fwd) (void)hipFree(d.coset_fwd);
+    if (d.coset_inv) (void)hipFree(d.coset_inv);
+    d = NttDomain();
+}
+
+static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
+{
+    auto it = ctx->domains.find(log2n);
+    if (it != ctx->domains.end()) {
+        *out = &it->second;
+        return BBG_OK;
+    }
+    NttDomain d;
+    d.log2n = log2n;
+    plan_passes(ctx, d);
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log2n;
+    BBG_HIP(hipMalloc(&d.consts, sizeof(DomainConsts)));
+    d.bytes += sizeof(DomainConsts);
+    hipLaunchKernelGGL(k_domain_init, dim3(1), dim3(64), 0, st, (DomainConsts*)d.consts, log2n);
+    DomainConsts* dc = (DomainConsts*)d.consts;
+    for (int inv = 0; inv < 2; inv++) {
+        const Fr* pow2 = inv ? dc->pow2_root_inv : dc->pow2_root;
+        int logS = (int)log2n;
+        for (int q = 0; q < d.passes; q++) {
+            const int logR = d.logR[q];
+            logS -= logR;
+            // radix twiddles w_R^j = w_n^(j * n/R)
+            const size_t half = (size_t)1 << (logR > 0 ? logR - 1 : 0);
+            BBG_HIP(hipMalloc(&d.tw_radix[inv][q], half * sizeof(Fr)));
+            d.bytes += half * sizeof(Fr);
+            hipLaunchKernelGGL(k_twiddle_1d, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix[inv][q], pow2, half,
+                               (uint64_t)(n >> logR));
+            if (q < d.passes - 1) {
+                // inter-pass twiddles w_{N_q}^(i*lo), N_q = R*S ; w_{N_q} = w_n^(n/N_q): use the pow2 table shifted
+                const int logN = logR + logS;
+                const size_t cnt = (size_t)1 << logN;
+                BBG_HIP(hipMalloc(&d.tw_inter[inv][q], cnt * sizeof(Fr)));
+                d.bytes += cnt * sizeof(Fr);
+                // w_{N_q}^(2^b) = w_n^(2^(b + log2n - logN))
+                hipLaunchKernelGGL(k_twiddle_2d, dim3(grid_for(cnt, 256)), dim3(256), 0, st, (Fr*)d.tw_inter[inv][q],
+                                   pow2 + (log2n - logN), logR, logS, (const Fr*)nullptr);
+            }
+        }
+    }
+    // coset tables: g^j and n^-1 * g^-j
+    BBG_HIP(hipMalloc(&d.coset_fwd, n * sizeof(Fr)));
+    BBG_HIP(hipMalloc(&d.coset_inv, n * sizeof(Fr)));
+    d.bytes += 2 * n * sizeof(Fr);
+    hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen, (const Fr*)nullptr);
+    hipLaunchKernelGGL(k_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d.coset_fwd,
+                       dc->pow2_tmp, (const Fr*)nullptr, n);
+    hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen_inv, (const Fr*)nullptr);
+    hipLaunchKernelGGL(k_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d.coset_inv,
+                       dc->pow2_tmp, &dc->n_inv, n);
+    BBG_HIP(hipGetLastError());
+    BBG_HIP(hipStreamSynchronize(st));
+    auto ins = ctx->domains.emplace(log2n, d);
+    *out = &ins.first->second;
+    return BBG_OK;
+}
+
+static int launch_pass(const NttDomain& d, int q, int inverse, const Fr* in, Fr* out, const Fr* post, hipStream_t st)
+{
+    PassParams p;
+    p.in = in;
+    p.out = out;
+    p.logR = d.logR[q];
+    p.logW = d.logW[q];
+    p.log2n = (int)d.log2n;
+    p.tw_radix = (const Fr*)d.tw_radix[inverse][q];
+    p.post = post;
+    p.row_pass = (q == d.passes - 1);
+    int logS = (int)d.log2n;
+    for (int k = 0; k <= q; k++) logS -= d.logR[k];
+    p.logS = logS;
+    p.tw_inter = p.row_pass ? nullptr : (const Fr*)d.tw_inter[inverse][q];
+    p.logR1 = d.passes > 1 ? d.logR[0] : 0;
+    p.nmid = d.passes >= 2 ? d.passes - 2 : 0;
+    p.logMid[0] = d.passes >= 3 ? d.logR[1] : 0;
+    p.logMid[1] = d.passes >= 4 ? d.logR[2] : 0;
+    const int R = 1 << p.logR, W = 1 << p.logW;
+    const size_t lds_bytes = ((size_t)2 * W * (R + 1) + R) * 16 + 64;
+    const size_t tiles = ((size_t)1 << d.log2n) >> (p.logR + p.logW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BBG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int threads = (R * W) / 2;
+    if (threads > 1024) threads = 1024;
+    if (threads < 64) threads = 64;
+    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, p);
+    return BBG_OK;
+}
+
+// core transform: in place on `a` from the caller's view; `post` (optional) multiplies natural-index outputs.
+static int ntt_core(bbg_ctx* ctx, NttDomain& d, Fr* a, int inverse, const Fr* post, hipStream_t st)
+{
+    const size_t n = (size_t)1 << d.log2n;
+    if (d.log2n == 0) {
+        if (post) hipLaunchKernelGGL(k_scale_table, dim3(1), dim3(64), 0, st, a, post, (size_t)1);
+        return BBG_OK;
+    }
+    if (d.passes == 1) return launch_pass(d, 0, inverse, a, a, post, st);
+    int rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, n * sizeof(Fr));
+    if (rc) return rc;
+    Fr* scratch = (Fr*)ctx->ntt_scratch;
+    // pass 0: a -> scratch (same positions); middle passes in place on scratch; last pass scratch -> a (transposing)
+    launch_pass(d, 0, inverse, a, scratch, nullptr, st);
+    for (int q = 1; q < d.passes - 1; q++) launch_pass(d, q, inverse, scratch, scratch, nullptr, st);
+    launch_pass(d, d.passes - 1, inverse, scratch, a, post, st);
+    return BBG_OK;
+}
+
+int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
+            hipStream_t st)
+{
+    if (!d_coeffs) { set_error("bbg_ntt: null coeffs"); return BBG_E_INVALID; }
+    if (log2n > 28) { set_error("bbg_ntt: log2n > 28 exceeds the 2-adicity of BN254 Fr (fr.hpp:27-30)"); return BBG_E_INVALID; }
+    if (op < 0 || op > 7) { set_error("bbg_ntt: unknown op"); return BBG_E_INVALID; }
+    if (op >= 4 && !constant) { set_error("bbg_ntt: op needs a constant"); return BBG_E_INVALID; }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    NttDomain& d = *dp;
+    DomainConsts* dc = (DomainConsts*)d.consts;
+    const size_t n = (size_t)1 << log2n;
+    if (generator_size == 0 || generator_size > n) generator_size = n;
+    Fr* a = (Fr*)d_coeffs;
+    Fr* cst = nullptr;
+    if (constant) {
+        cst = &dc->constant;
+        BBG_HIP(hipMemcpyAsync(cst, constant, 32, hipMemcpyHostToDevice, st));
+    }
+    switch (op) {
+    case BBG_FFT:
+        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        break;
+    case BBG_IFFT:
+        rc = ntt_core(ctx, d, a, 1, nullptr, st);
+        if (!rc) hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, &dc->n_inv, n);
+        break;
+    case BBG_COSET_FFT:
+        hipLaunchKernelGGL(k_scale_table, dim3(grid_for(generator_size, 256)), dim3(256), 0, st, a, (const Fr*)d.coset_fwd,
+                           generator_size);
+        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        break;
+    case BBG_COSET_IFFT:
+        rc = ntt_core(ctx, d, a, 1, (const Fr*)d.coset_inv, st);
+        break;
+    case BBG_FFT_WITH_CONSTANT:
+        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        if (!rc) hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, cst, n);
+        break;
+    case BBG_COSET_FFT_WITH_CONSTANT:
+        // a[j] *= constant * g^j, j < generator_size
+        hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen, (const Fr*)nullptr);
+        hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((generator_size + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, a,
+                           dc->pow2_tmp, cst, generator_size);
+        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        break;
+    case BBG_COSET_FFT_WITH_GENERATOR_SHIFT:
+        // generator = g * constant
+        hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen, (const Fr*)cst);
+        hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((generator_size + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, a,
+                           dc->pow2_tmp, (const Fr*)nullptr, generator_size);
+        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        break;
+    case BBG_IFFT_WITH_CONSTANT:
+        rc = ntt_core(ctx, d, a, 1, nullptr, st);
+        if (!rc) {
+            hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, &dc->n_inv, n);
+            hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, cst, n);
+        }
+        break;
+    }
+    if (rc) return rc;
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t st)
+{
+    int logext = 0;
+    while (((size_t)1 << logext) < ext) logext++;
+    if (((size_t)1 << logext) != ext || ext == 0 || log2n + logext > 28) {
+        set_error("bbg_coset_fft_split: ext must be a power of two with n*ext <= 2^28");
+        return BBG_E_INVALID;
+    }
+    NttDomain *dsmall = nullptr, *dlarge = nullptr;
+    int rc = build_domain(ctx, log2n, &dsmall);
+    if (rc) return rc;
+    rc = build_domain(ctx, log2n + logext, &dlarge);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log2n;
+    Fr* a = (Fr*)d_coeffs;
+    DomainConsts* dcs = (DomainConsts*)dsmall->consts;
+    DomainConsts* dcl = (DomainConsts*)dlarge->consts;
+    // replicate the n coefficients into ext slots, scale slot k by (g * w_{ext n}^k)^j, transform each, interleave
+    hipLaunchKernelGGL(k_replicate, dim3(grid_for(n, 256)), dim3(256), 0, st, a, (int)log2n, (int)ext);
+    // generator of slot k: g * root_large^k ; build incrementally in pow2_tmp[30] of the small domain
+    Fr* gk = &dcs->gk;
+    BBG_HIP(hipMemcpyAsync(gk, &dcs->gen, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    for (size_t k = 0; k < ext; k++) {
+        hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dcs->pow2_tmp, (const Fr*)gk, (const Fr*)nullptr);
+        hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, a + k * n,
+                           dcs->pow2_tmp, (const Fr*)nullptr, n);
+        rc = ntt_core(ctx, *dsmall, a + k * n, 0, nullptr, st);
+        if (rc) return rc;
+        // gk *= root_large  (k_pow2_table with two bases writes pow2[0] = gk*root; copy back)
+        hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dcs->pow2_tmp, (const Fr*)gk, (const Fr*)&dcl->root);
+        BBG_HIP(hipMemcpyAsync(gk, &dcs->pow2_tmp[0], sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    }
+    // interleave through the scratch buffer (ntt_core is done with it by now on this stream)
+    rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, n * ext * sizeof(Fr));
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(ctx->ntt_scratch, a, n * ext * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_interleave, dim3(grid_for(n * ext, 256)), dim3(256), 0, st, (const Fr*)ctx->ntt_scratch, a, (int)log2n,
+                       logext);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+int ntt_prepare(bbg_ctx* ctx, unsigned log2n)
+{
+    if (log2n > 28) { set_error("bbg_ntt_prepare: log2n > 28"); return BBG_E_INVALID; }
+    NttDomain* d = nullptr;
+    return build_domain(ctx, log2n, &d);
+}
+
+// ---- field self-test kernels (bbg_field_op)
+template <class P> __global__ void k_field_op(int op, const Fe<P>* a, const Fe<P>* b, Fe<P>* out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<P> x = fe_load<P>(a + i), y = b ? fe_load<P>(b + i) : Fe<P>::zero(), z;
+    // inputs may be any 256-bit value: bring into [0,2p) the way the reference assumes its inputs are
+    x = fe_reduce_once(fe_reduce_once(fe_reduce_once(x)));
+    y = fe_reduce_once(fe_reduce_once(fe_reduce_once(y)));
+    switch (op) {
+    case 0: z = fe_mul(x, y); break;
+    case 1: z = fe_add(x, y); break;
+    case 2: z = fe_sub(x, y); break;
+    case 3: z = fe_mul_cios(x, y); break;
+    case 4: z = fe_from_mont(x); break;
+    case 5: z = fe_to_mont(x); break;
+    default: z = x; break;
+    }
+    fe_store<P>(out + i, fe_reduce_once(z));
+}
+int field_op_device(int which, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st)
+{
+    if (n == 0) return BBG_OK;
+    if (which == 0)
+        hipLaunchKernelGGL(k_field_op<FrP>, dim3(grid_for(n, 256)), dim3(256), 0, st, op, (const Fr*)a, (const Fr*)b, (Fr*)out, n);
+    else
+        hipLaunchKernelGGL(k_field_op<FqP>, dim3(grid_for(n, 256)), dim3(256), 0, st, op, (const Fq*)a, (const Fq*)b, (Fq*)out, n);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+} // namespace bbg

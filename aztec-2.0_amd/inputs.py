@@ -1,0 +1,34 @@
+"""Deterministic synthetic inputs: the reference's RNG is unseeded
+(numeric/random/engine.cpp:122-149), so tests and bench feed BOTH the oracle and the GPU from this generator."""
+import numpy as np
+
+_MASK60 = np.uint64(0x0FFFFFFFFFFFFFFF)
+
+
+def splitmix64_limbs(seed, count):
+    """`count` uint64 words of the splitmix64 stream started at `seed` (vectorised: word i uses state seed+(i+1)*gamma)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def synthetic_scalars(seed, n):
+    """n x 4 limbs, top limb masked to 60 bits (value < 2^252 < r), read as Montgomery-form Fr residues."""
+    a = splitmix64_limbs(seed, 4 * n).reshape(n, 4).copy()
+    a[:, 3] &= _MASK60
+    return a
+
+
+def mixed_scalars(seed, n, to_montgomery):
+    """The distribution of pippenger_short_inputs (scalar_multiplication.test.cpp:733-753): a quarter each of
+    full-width, zero, 64-bit and <= 3-bit scalars.  `to_montgomery` converts plain integers (n,4) to Montgomery."""
+    plain = synthetic_scalars(seed, n)
+    q = np.arange(n) % 4
+    plain[q == 1] = 0
+    plain[q == 2, 1:] = 0
+    plain[q == 3, 1:] = 0
+    plain[q == 3, 0] &= np.uint64(7)
+    return to_montgomery(plain)

@@ -1,0 +1,127 @@
+/*
+ * bbg.h -- C ABI of libbbg.so: the MI355X (gfx950) implementation of barretenberg's PLONK-prover
+ * hot path -- Pippenger MSM over BN254 G1 and the radix-2 NTT family over BN254 Fr.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain pointers and sizes in the
+ * REFERENCE'S OWN MEMORY LAYOUT (paths relative to barretenberg/src/aztec/):
+ *   fr / fq           32 B, 4 x u64 little-endian limbs, Montgomery form R = 2^256, any representative
+ *                     in [0, 2p) accepted                        (ecc/fields/field.hpp:24,86)
+ *   g1::affine_element 64 B  x || y                               (ecc/groups/affine_element.hpp:70-71)
+ *   g1::element        96 B  x || y || z Jacobian, infinity = bit 63 of x.data[3]
+ *                                                                 (ecc/groups/element.hpp:88-90, element_impl.hpp:497-516)
+ * so a barretenberg build binds them with no marshalling (see INTEGRATION.md for the C++ shim that
+ * re-exports scalar_multiplication::pippenger*() and polynomial_arithmetic::fft*() on top of this).
+ *
+ * All functions return 0 on success and a negative BBG_E* code on failure; bbg_last_error() gives a
+ * thread-local message.  The reference has no status codes (throw_or_abort, common/throw_or_abort.hpp:5-13);
+ * the C++ shim turns a non-zero return into std::runtime_error.
+ *
+ * There is no CPU fallback anywhere behind this ABI: without a HIP device bbg_init() fails.
+ */
+#ifndef BBG_H
+#define BBG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBG_OK 0
+#define BBG_E_INVALID (-1)  /* bad argument (null pointer, size out of range, n not a power of two ...) */
+#define BBG_E_HIP (-2)      /* a HIP runtime call failed; see bbg_last_error() */
+#define BBG_E_NODEVICE (-3) /* no gfx950 device visible */
+#define BBG_E_NOMEM (-4)
+
+typedef struct bbg_ctx bbg_ctx; /* one per GPU / per process rank */
+typedef struct bbg_srs bbg_srs; /* device-resident SRS (the Pippenger point table) */
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+int bbg_device_count(void);
+/* Binds `device` (hipSetDevice), creates the context and its stream. */
+int bbg_init(int device, bbg_ctx** out);
+void bbg_destroy(bbg_ctx* ctx);
+const char* bbg_last_error(void);
+/* Blocks until everything queued on the context's stream has finished. */
+int bbg_sync(bbg_ctx* ctx);
+/* Use a caller-owned HIP stream (hipStream_t passed as void*; e.g. torch.cuda.current_stream().cuda_stream). */
+int bbg_set_stream(bbg_ctx* ctx, void* hip_stream);
+
+/* ---- SRS: replaces scalar_multiplication::Pippenger (ecc/curves/bn254/scalar_multiplication/pippenger.hpp:35-52,
+ *      pippenger.cpp:7-37) and the C binding new_pippenger/delete_pippenger (.../c_bind.cpp:17-29). --------------
+ * points: n affine points in Montgomery form.  stride_bytes = 64 for a plain array P_0..P_{n-1} (what
+ * io::read_transcript_g1 yields, srs/io.cpp:134-162) or 128 for the reference's interleaved endomorphism table
+ * [P_i, (beta*x_i, -y_i)] (generate_pippenger_point_table, scalar_multiplication.cpp:104-112), whose odd entries
+ * are ignored: the (beta*x, -y) twin is one Fq multiplication on chip.  The table is uploaded to HBM once. */
+int bbg_srs_register(bbg_ctx* ctx, const uint64_t* points, size_t n, size_t stride_bytes, bbg_srs** out);
+/* Same, from a device buffer of n plain 64-byte points (copied). */
+int bbg_srs_register_device(bbg_ctx* ctx, const void* d_points, size_t n, bbg_srs** out);
+/* Synthetic SRS P_i = (a + i*s)*G generated on the GPU (the Ignition transcript is absent from the
+ * reference snapshot).  a, s: plain 64-bit scalars, s != 0. */
+int bbg_srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, bbg_srs** out);
+/* Reads an Ignition-format transcript file (manifest + big-endian points; srs/io.cpp:11-162): result is
+ * monomials[0] = G followed by the file's points, num_points in total -- exactly read_transcript_g1. */
+int bbg_srs_load_transcript(bbg_ctx* ctx, const char* path, size_t num_points, bbg_srs** out);
+size_t bbg_srs_num_points(const bbg_srs* srs);
+/* Copies points [from, from+count) back to the host (64-byte Montgomery affine each). */
+int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points);
+void bbg_srs_free(bbg_srs* srs);
+
+/* ---- MSM: replaces scalar_multiplication::pippenger / pippenger_unsafe
+ *      (scalar_multiplication.cpp:853-929) and Pippenger::pippenger_unsafe(scalars, from, range) (pippenger.cpp:27-31),
+ *      C binding pippenger_unsafe (c_bind.cpp:31-37). -------------------------------------------------------------
+ * result = sum_{i<n} scalars[i] * P_{from+i}.  scalars: n x 4 limbs, Montgomery Fr.  out_jacobian: 12 limbs
+ * (g1::element).  Exceptional cases (equal / opposite points, zero scalars, n = 0 -> infinity) are always handled,
+ * i.e. the behaviour of handle_edge_cases = true; the "unsafe" entry of the shim maps here too. */
+int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, size_t n, uint64_t out_jacobian[12]);
+/* Device-resident variant: d_scalars and d_out_jacobian (96 B) are device pointers; asynchronous on the context stream. */
+int bbg_msm_device(bbg_ctx* ctx, bbg_srs* srs, const void* d_scalars, size_t from, size_t n, void* d_out_jacobian);
+/* g1_sum (c_bind.cpp:39-46): sum of n Jacobian points (host arrays, 96 B each). */
+int bbg_g1_sum(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t out_jacobian[12]);
+/* g1::affine_element(result) (element_impl.hpp:51-68) for n points; output canonical Montgomery affine (64 B each). */
+int bbg_g1_normalize(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t* out_affine);
+
+/* ---- NTT family: replaces polynomial_arithmetic::fft/ifft/coset_fft/coset_ifft/... on fr* coeffs
+ *      (polynomials/polynomial_arithmetic.cpp:374-484) and the C bindings coset_fft_with_generator_shift / ifft
+ *      (plonk/proof_system/prover/c_bind.cpp:59-76). ----------------------------------------------------------- */
+enum {
+    BBG_FFT = 0,                             /* fft                            :374 */
+    BBG_IFFT = 1,                            /* ifft                           :379 */
+    BBG_COSET_FFT = 2,                       /* coset_fft(coeffs, domain)      :395 */
+    BBG_COSET_IFFT = 3,                      /* coset_ifft                     :480 */
+    BBG_FFT_WITH_CONSTANT = 4,               /* fft_with_constant              :387 */
+    BBG_COSET_FFT_WITH_CONSTANT = 5,         /* coset_fft_with_constant        :458 */
+    BBG_COSET_FFT_WITH_GENERATOR_SHIFT = 6,  /* coset_fft_with_generator_shift :465 */
+    BBG_IFFT_WITH_CONSTANT = 7               /* ifft_with_constant             :471 */
+};
+/* In place on coeffs[2^log2n] (Montgomery Fr, natural order in and out).  generator_size = evaluation_domain::
+ * generator_size (0 = whole domain): coset_fft scales only the first generator_size coefficients by g^j
+ * (polynomial_arithmetic.cpp:397, proving_key.cpp:21-22).  constant: Montgomery Fr for ops 4-7, else NULL.
+ * The per-size twiddle tables (evaluation_domain::compute_lookup_table) are built on first use and cached. */
+int bbg_ntt(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant);
+int bbg_ntt_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant);
+/* Pre-builds the tables for a domain size (outside any timed region, like compute_lookup_table()). */
+int bbg_ntt_prepare(bbg_ctx* ctx, unsigned log2n);
+/* coset_fft(coeffs, small_domain, large_domain, ext) (:401-456): coeffs holds 2^log2n coefficients in a buffer of
+ * ext * 2^log2n elements; result interleaves ext size-n coset FFTs at index ext*i + k. */
+int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t ext);
+int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext);
+
+/* ---- device memory helpers for hosts that do not link HIP (bbmalloc/bbfree analogue, c_bind.cpp:11-15) ---- */
+int bbg_dev_alloc(bbg_ctx* ctx, size_t bytes, void** d_ptr);
+int bbg_dev_free(bbg_ctx* ctx, void* d_ptr);
+int bbg_dev_upload(bbg_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---- tuning / introspection ---- */
+/* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 6..11). */
+int bbg_set_option(bbg_ctx* ctx, const char* key, long value);
+/* Field-level self test entry used by tests: out[i] = a[i] (op) b[i] computed by the device field code.
+ * which: 0 Fr, 1 Fq.  op: 0 mul, 1 add, 2 sub, 3 mul via the CIOS cross-check path, 4 from_montgomery, 5 to_montgomery. */
+int bbg_field_op(bbg_ctx* ctx, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBG_H */

@@ -1,0 +1,401 @@
+"""ctypes access to the CHECKERS -- test infrastructure only.
+
+  Oracle : oracle/libbn254_oracle.so, this repo's plain-C restatement (bn254_oracle.c).
+  Ref    : oracle/_ref/libbbref.so, the real barretenberg hot path compiled from /root/reference
+           (ref_driver.cpp + the reference's own TUs); present only where it was built / shipped prebuilt.
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libbn254_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libbbref.so")
+
+vp, sz, cint, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
+
+
+def build(with_ref=True):
+    subprocess.run(["make", "-C", _HERE, "libbn254_oracle.so"], check=True)
+    if with_ref:
+        subprocess.run(["make", "-C", _HERE, "ref"], check=True)
+
+
+def _arr(a, last):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, last)
+    assert a.shape[-1] == last, (a.shape, last)
+    return a
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build(with_ref=False)
+        L = self.lib = ctypes.CDLL(ORACLE_SO)
+        for name, args in {
+            "oracle_fe_mul": [cint, vp, vp, vp, sz], "oracle_fe_add": [cint, vp, vp, vp, sz],
+            "oracle_fe_sub": [cint, vp, vp, vp, sz], "oracle_fe_inv": [cint, vp, vp, sz],
+            "oracle_fe_to_mont": [cint, vp, vp, sz], "oracle_fe_from_mont": [cint, vp, vp, sz],
+            "oracle_fe_canon": [cint, vp, vp, sz], "oracle_fr_root_of_unity": [cu, vp],
+            "oracle_endo_split": [vp, vp, sz], "oracle_g1_generator": [vp], "oracle_g1_mul": [vp, vp, vp],
+            "oracle_g1_add": [vp, vp, vp], "oracle_g1_jac_to_affine": [vp, vp], "oracle_g1_sum": [vp, sz, vp],
+            "oracle_g1_to_buffer": [vp, vp], "oracle_srs_linear": [ctypes.c_uint64, ctypes.c_uint64, sz, vp],
+            "oracle_srs_powers": [vp, sz, vp], "oracle_srs_hashed": [ctypes.c_uint64, sz, vp], "oracle_point_table": [vp, sz, vp],
+            "oracle_wnaf_schedule": [vp, sz, sz, vp, vp, vp], "oracle_pippenger": [vp, vp, sz, vp],
+            "oracle_msm_naive": [vp, vp, sz, vp], "oracle_poly_eval": [vp, sz, vp, vp],
+        }.items():
+            getattr(L, name).argtypes = args
+            getattr(L, name).restype = None
+        L.oracle_g1_on_curve.argtypes = [vp]; L.oracle_g1_on_curve.restype = cint
+        L.oracle_optimal_bucket_width.argtypes = [sz]; L.oracle_optimal_bucket_width.restype = sz
+        L.oracle_ntt.argtypes = [vp, cu, cint, sz, vp]; L.oracle_ntt.restype = cint
+        L.oracle_coset_fft_split.argtypes = [vp, cu, sz]; L.oracle_coset_fft_split.restype = cint
+        L.oracle_num_threads.argtypes = []; L.oracle_num_threads.restype = cint
+
+    # ---- fields (which: 0 Fr, 1 Fq)
+    def _bin(self, fn, which, a, b):
+        a, b = _arr(a, 4), _arr(b, 4)
+        r = np.empty_like(a)
+        fn(which, a.ctypes.data, b.ctypes.data, r.ctypes.data, a.shape[0])
+        return r
+
+    def _un(self, fn, which, a):
+        a = _arr(a, 4)
+        r = np.empty_like(a)
+        fn(which, a.ctypes.data, r.ctypes.data, a.shape[0])
+        return r
+
+    def fe_mul(self, which, a, b): return self._bin(self.lib.oracle_fe_mul, which, a, b)
+    def fe_add(self, which, a, b): return self._bin(self.lib.oracle_fe_add, which, a, b)
+    def fe_sub(self, which, a, b): return self._bin(self.lib.oracle_fe_sub, which, a, b)
+    def fe_inv(self, which, a): return self._un(self.lib.oracle_fe_inv, which, a)
+    def to_mont(self, which, a): return self._un(self.lib.oracle_fe_to_mont, which, a)
+    def from_mont(self, which, a): return self._un(self.lib.oracle_fe_from_mont, which, a)
+    def canon(self, which, a): return self._un(self.lib.oracle_fe_canon, which, a)
+
+    def root_of_unity(self, log2n):
+        r = np.empty(4, dtype=np.uint64)
+        self.lib.oracle_fr_root_of_unity(log2n, r.ctypes.data)
+        return r
+
+    def endo_split(self, scalars):
+        s = _arr(scalars, 4)
+        r = np.empty_like(s)
+        self.lib.oracle_endo_split(s.ctypes.data, r.ctypes.data, s.shape[0])
+        return r
+
+    # ---- group
+    def g1_generator(self):
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_g1_generator(r.ctypes.data)
+        return r
+
+    def g1_on_curve(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        return bool(self.lib.oracle_g1_on_curve(p.ctypes.data))
+
+    def g1_mul(self, p, k):
+        p, k = np.ascontiguousarray(p, dtype=np.uint64), np.ascontiguousarray(k, dtype=np.uint64)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_g1_mul(p.ctypes.data, k.ctypes.data, r.ctypes.data)
+        return r
+
+    def g1_add(self, p, q):
+        p, q = np.ascontiguousarray(p, dtype=np.uint64), np.ascontiguousarray(q, dtype=np.uint64)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_g1_add(p.ctypes.data, q.ctypes.data, r.ctypes.data)
+        return r
+
+    def jac_to_affine(self, jac):
+        j = np.ascontiguousarray(jac, dtype=np.uint64)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_g1_jac_to_affine(j.ctypes.data, r.ctypes.data)
+        return r
+
+    def g1_sum(self, jacs):
+        j = _arr(jacs, 12)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_g1_sum(j.ctypes.data, j.shape[0], r.ctypes.data)
+        return r
+
+    def g1_to_buffer(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        buf = np.empty(64, dtype=np.uint8)
+        self.lib.oracle_g1_to_buffer(p.ctypes.data, buf.ctypes.data)
+        return bytes(buf)
+
+    def srs_linear(self, a, s, n):
+        r = np.empty((n, 8), dtype=np.uint64)
+        self.lib.oracle_srs_linear(a, s, n, r.ctypes.data)
+        return r
+
+    def srs_hashed(self, seed, n):
+        r = np.empty((n, 8), dtype=np.uint64)
+        self.lib.oracle_srs_hashed(seed, n, r.ctypes.data)
+        return r
+
+    def srs_powers(self, x_mont, n):
+        x = np.ascontiguousarray(x_mont, dtype=np.uint64)
+        r = np.empty((n, 8), dtype=np.uint64)
+        self.lib.oracle_srs_powers(x.ctypes.data, n, r.ctypes.data)
+        return r
+
+    def point_table(self, points):
+        p = _arr(points, 8)
+        r = np.empty((2 * p.shape[0], 8), dtype=np.uint64)
+        self.lib.oracle_point_table(p.ctypes.data, p.shape[0], r.ctypes.data)
+        return r
+
+    # ---- MSM
+    def optimal_bucket_width(self, n): return int(self.lib.oracle_optimal_bucket_width(n))
+
+    def wnaf_schedule(self, scalars, wnaf_bits):
+        s = _arr(scalars, 4)
+        n = s.shape[0]
+        rounds = (127 + wnaf_bits - 1) // wnaf_bits
+        sched = np.empty((rounds, 2 * n), dtype=np.uint64)
+        skew = np.empty(2 * n, dtype=np.uint8)
+        counts = np.zeros(256, dtype=np.uint64)
+        self.lib.oracle_wnaf_schedule(s.ctypes.data, n, wnaf_bits, sched.ctypes.data, skew.ctypes.data, counts.ctypes.data)
+        return sched, skew, counts[:rounds]
+
+    def pippenger(self, scalars, points):
+        s, p = _arr(scalars, 4), _arr(points, 8)
+        assert s.shape[0] == p.shape[0]
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_pippenger(s.ctypes.data, p.ctypes.data, s.shape[0], r.ctypes.data)
+        return r
+
+    def msm_naive(self, scalars, points):
+        s, p = _arr(scalars, 4), _arr(points, 8)
+        assert s.shape[0] == p.shape[0]
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.oracle_msm_naive(s.ctypes.data, p.ctypes.data, s.shape[0], r.ctypes.data)
+        return r
+
+    # ---- NTT
+    def ntt(self, coeffs, op=0, generator_size=0, constant=None):
+        a = _arr(coeffs, 4).copy()
+        n = a.shape[0]
+        log2n = n.bit_length() - 1
+        assert (1 << log2n) == n
+        c = None if constant is None else np.ascontiguousarray(constant, dtype=np.uint64)
+        rc = self.lib.oracle_ntt(a.ctypes.data, log2n, op, generator_size, None if c is None else c.ctypes.data)
+        assert rc == 0, rc
+        return a
+
+    def coset_fft_split(self, coeffs, ext):
+        a = _arr(coeffs, 4)
+        n = a.shape[0]
+        buf = np.zeros((n * ext, 4), dtype=np.uint64)
+        buf[:n] = a
+        rc = self.lib.oracle_coset_fft_split(buf.ctypes.data, n.bit_length() - 1, ext)
+        assert rc == 0, rc
+        return buf
+
+    def poly_eval(self, coeffs, z):
+        a, z = _arr(coeffs, 4), np.ascontiguousarray(z, dtype=np.uint64)
+        r = np.empty(4, dtype=np.uint64)
+        self.lib.oracle_poly_eval(a.ctypes.data, a.shape[0], z.ctypes.data, r.ctypes.data)
+        return r
+
+    def num_threads(self): return int(self.lib.oracle_num_threads())
+
+
+def ref_available():
+    if not os.path.exists(REF_SO):
+        return False
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return all(f in flags for f in (" adx", " bmi2", " avx2"))
+
+
+class Ref:
+    """The real reference (barretenberg) hot path; see oracle/ref_driver.cpp."""
+
+    def __init__(self):
+        if not ref_available():
+            raise RuntimeError("oracle/_ref/libbbref.so not available on this machine")
+        L = self.lib = ctypes.CDLL(REF_SO)
+        L.ref_num_threads.restype = cint
+        L.ref_fe_op.argtypes = [cint, cint, vp, vp, vp, sz]
+        L.ref_fr_root_of_unity.argtypes = [cu, vp]
+        L.ref_fr_coset_generator.argtypes = [vp]
+        L.ref_endo_split.argtypes = [vp, vp, sz]
+        L.ref_g1_generator.argtypes = [vp]
+        L.ref_g1_on_curve.argtypes = [vp]; L.ref_g1_on_curve.restype = cint
+        L.ref_g1_mul.argtypes = [vp, vp, vp]
+        L.ref_g1_add.argtypes = [vp, vp, vp]
+        L.ref_g1_dbl.argtypes = [vp, vp]
+        L.ref_g1_to_buffer.argtypes = [vp, vp]
+        L.ref_point_table.argtypes = [vp, sz, vp]
+        L.ref_wnaf_schedule.argtypes = [vp, sz, vp, vp, vp]; L.ref_wnaf_schedule.restype = cint
+        L.ref_msm_new.argtypes = [vp, sz]; L.ref_msm_new.restype = vp
+        L.ref_msm_free.argtypes = [vp]
+        L.ref_msm_run.argtypes = [vp, vp, sz, sz, cint, vp]; L.ref_msm_run.restype = ctypes.c_double
+        L.ref_msm_run_jac.argtypes = [vp, vp, sz, sz, vp]
+        L.ref_msm_naive.argtypes = [vp, vp, sz, vp]
+        L.ref_g1_sum.argtypes = [vp, sz, vp]
+        L.ref_domain_new.argtypes = [cu, sz]; L.ref_domain_new.restype = vp
+        L.ref_domain_free.argtypes = [vp]
+        L.ref_ntt_run.argtypes = [vp, vp, cint, vp]; L.ref_ntt_run.restype = ctypes.c_double
+        L.ref_coset_fft_split.argtypes = [vp, cu, sz]
+        L.ref_poly_eval.argtypes = [vp, sz, vp, vp]
+
+    def num_threads(self): return int(self.lib.ref_num_threads())
+
+    def fe_op(self, which, op, a, b=None):
+        a = _arr(a, 4)
+        r = np.empty_like(a)
+        bp = None
+        if b is not None:
+            b = _arr(b, 4)
+            bp = b.ctypes.data
+        self.lib.ref_fe_op(which, op, a.ctypes.data, bp, r.ctypes.data, a.shape[0])
+        return r
+
+    def root_of_unity(self, log2n):
+        r = np.empty(4, dtype=np.uint64)
+        self.lib.ref_fr_root_of_unity(log2n, r.ctypes.data)
+        return r
+
+    def coset_generator(self):
+        r = np.empty(4, dtype=np.uint64)
+        self.lib.ref_fr_coset_generator(r.ctypes.data)
+        return r
+
+    def endo_split(self, scalars):
+        s = _arr(scalars, 4)
+        r = np.empty_like(s)
+        self.lib.ref_endo_split(s.ctypes.data, r.ctypes.data, s.shape[0])
+        return r
+
+    def g1_generator(self):
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.ref_g1_generator(r.ctypes.data)
+        return r
+
+    def g1_on_curve(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        return bool(self.lib.ref_g1_on_curve(p.ctypes.data))
+
+    def g1_mul(self, p, k):
+        p, k = np.ascontiguousarray(p, dtype=np.uint64), np.ascontiguousarray(k, dtype=np.uint64)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.ref_g1_mul(p.ctypes.data, k.ctypes.data, r.ctypes.data)
+        return r
+
+    def g1_add(self, p, q):
+        p, q = np.ascontiguousarray(p, dtype=np.uint64), np.ascontiguousarray(q, dtype=np.uint64)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.ref_g1_add(p.ctypes.data, q.ctypes.data, r.ctypes.data)
+        return r
+
+    def g1_dbl(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.ref_g1_dbl(p.ctypes.data, r.ctypes.data)
+        return r
+
+    def g1_to_buffer(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64)
+        buf = np.empty(64, dtype=np.uint8)
+        self.lib.ref_g1_to_buffer(p.ctypes.data, buf.ctypes.data)
+        return bytes(buf)
+
+    def point_table(self, points):
+        p = _arr(points, 8)
+        r = np.empty((2 * p.shape[0], 8), dtype=np.uint64)
+        self.lib.ref_point_table(p.ctypes.data, p.shape[0], r.ctypes.data)
+        return r
+
+    def wnaf_schedule(self, scalars, wnaf_bits):
+        """compute_wnaf_states; `wnaf_bits` (= get_optimal_bucket_width(n) + 1) only sizes the output buffer."""
+        s = _arr(scalars, 4)
+        n = s.shape[0]
+        rounds = (127 + wnaf_bits - 1) // wnaf_bits
+        sched = np.empty(rounds * 2 * n, dtype=np.uint64)
+        skew = np.empty(2 * n, dtype=np.uint8)
+        counts = np.zeros(256, dtype=np.uint64)
+        wb = self.lib.ref_wnaf_schedule(s.ctypes.data, n, sched.ctypes.data, skew.ctypes.data, counts.ctypes.data)
+        assert wb == wnaf_bits, (wb, wnaf_bits)
+        return sched.reshape(rounds, 2 * n), skew, counts[:rounds]
+
+    def msm_naive(self, scalars, points):
+        s, p = _arr(scalars, 4), _arr(points, 8)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.ref_msm_naive(s.ctypes.data, p.ctypes.data, s.shape[0], r.ctypes.data)
+        return r
+
+    def g1_sum(self, jacs):
+        j = _arr(jacs, 12)
+        r = np.empty(8, dtype=np.uint64)
+        self.lib.ref_g1_sum(j.ctypes.data, j.shape[0], r.ctypes.data)
+        return r
+
+    class Msm:
+        def __init__(self, ref, points):
+            self.ref = ref
+            p = _arr(points, 8)
+            self.n = p.shape[0]
+            self.h = ref.lib.ref_msm_new(p.ctypes.data, self.n)
+
+        def run(self, scalars, start=0, unsafe=True):
+            s = _arr(scalars, 4)
+            r = np.empty(8, dtype=np.uint64)
+            t = self.ref.lib.ref_msm_run(self.h, s.ctypes.data, start, s.shape[0], 1 if unsafe else 0, r.ctypes.data)
+            return r, t
+
+        def run_jac(self, scalars, start=0):
+            s = _arr(scalars, 4)
+            r = np.empty(12, dtype=np.uint64)
+            self.ref.lib.ref_msm_run_jac(self.h, s.ctypes.data, start, s.shape[0], r.ctypes.data)
+            return r
+
+        def free(self):
+            if self.h:
+                self.ref.lib.ref_msm_free(self.h)
+                self.h = None
+
+    def msm(self, points): return Ref.Msm(self, points)
+
+    class Domain:
+        def __init__(self, ref, log2n, generator_size=0):
+            self.ref, self.log2n = ref, log2n
+            self.h = ref.lib.ref_domain_new(log2n, generator_size)
+
+        def run(self, coeffs, op=0, constant=None):
+            a = _arr(coeffs, 4).copy()
+            assert a.shape[0] == 1 << self.log2n
+            c = None if constant is None else np.ascontiguousarray(constant, dtype=np.uint64)
+            t = self.ref.lib.ref_ntt_run(self.h, a.ctypes.data, op, None if c is None else c.ctypes.data)
+            return a, t
+
+        def free(self):
+            if self.h:
+                self.ref.lib.ref_domain_free(self.h)
+                self.h = None
+
+    def domain(self, log2n, generator_size=0): return Ref.Domain(self, log2n, generator_size)
+
+    def coset_fft_split(self, coeffs, ext):
+        a = _arr(coeffs, 4)
+        n = a.shape[0]
+        buf = np.zeros((n * ext, 4), dtype=np.uint64)
+        buf[:n] = a
+        self.lib.ref_coset_fft_split(buf.ctypes.data, n.bit_length() - 1, ext)
+        return buf
+
+    def poly_eval(self, coeffs, z):
+        a, z = _arr(coeffs, 4), np.ascontiguousarray(z, dtype=np.uint64)
+        r = np.empty(4, dtype=np.uint64)
+        self.lib.ref_poly_eval(a.ctypes.data, a.shape[0], z.ctypes.data, r.ctypes.data)
+        return r
