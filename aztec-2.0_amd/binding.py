@@ -37,6 +37,15 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise BbgError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 (soname libamdhip64.so.7, the
+    # same soname libbbg.so needs).  If torch is imported AFTER libbbg pulled in /opt/rocm's copy, torch loads a
+    # second runtime by file name and finds "No HIP GPUs".  Importing torch first makes the loader resolve
+    # libbbg's NEEDED entry to the copy torch already mapped, so both share devices, streams and allocations.
+    if os.environ.get("BBG_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, sz, u64p, cint = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int
     protos = {
@@ -49,6 +58,7 @@ def load_library():
         "bbg_srs_register": (cint, [vp, vp, sz, sz, ctypes.POINTER(vp)]),
         "bbg_srs_register_device": (cint, [vp, vp, sz, ctypes.POINTER(vp)]),
         "bbg_srs_synth_linear": (cint, [vp, ctypes.c_uint64, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_synth_hashed": (cint, [vp, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
         "bbg_srs_load_transcript": (cint, [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp)]),
         "bbg_srs_num_points": (sz, [vp]),
         "bbg_srs_read": (cint, [vp, sz, sz, vp]),
@@ -56,6 +66,7 @@ def load_library():
         "bbg_msm": (cint, [vp, vp, vp, sz, sz, vp]),
         "bbg_msm_device": (cint, [vp, vp, vp, sz, sz, vp]),
         "bbg_g1_sum": (cint, [vp, vp, sz, vp]),
+        "bbg_g1_sum_device": (cint, [vp, vp, sz, vp]),
         "bbg_g1_normalize": (cint, [vp, vp, sz, vp]),
         "bbg_ntt": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
         "bbg_ntt_device": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
@@ -68,6 +79,8 @@ def load_library():
         "bbg_dev_download": (cint, [vp, vp, vp, sz]),
         "bbg_set_option": (cint, [vp, ctypes.c_char_p, ctypes.c_long]),
         "bbg_field_op": (cint, [vp, cint, cint, vp, vp, vp, sz]),
+        "bbg_profile_enable": (cint, [vp, cint]),
+        "bbg_profile_get": (cint, [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here == a symbol declared in bbg.h is not exported
@@ -79,10 +92,10 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_set_stream", "bbg_srs_register",
-    "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
-    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
+    "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
+    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_dev_alloc", "bbg_dev_free",
-    "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op",
+    "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
 ]
 
 
@@ -165,6 +178,11 @@ class Bbg:
         self._ck(self.lib.bbg_srs_synth_linear(self.ctx, a, s, n, ctypes.byref(h)))
         return Srs(self, h)
 
+    def srs_synth_hashed(self, seed, n):
+        h = ctypes.c_void_p()
+        self._ck(self.lib.bbg_srs_synth_hashed(self.ctx, seed, n, ctypes.byref(h)))
+        return Srs(self, h)
+
     def srs_load_transcript(self, directory, num_points):
         h = ctypes.c_void_p()
         self._ck(self.lib.bbg_srs_load_transcript(self.ctx, str(directory).encode(), num_points, ctypes.byref(h)))
@@ -185,6 +203,9 @@ class Bbg:
         out = np.zeros(12, dtype=np.uint64)
         self._ck(self.lib.bbg_g1_sum(self.ctx, j.ctypes.data, j.shape[0], out.ctypes.data))
         return out
+
+    def g1_sum_device(self, d_jacobians, n, d_out):
+        self._ck(self.lib.bbg_g1_sum_device(self.ctx, ctypes.c_void_p(d_jacobians), n, ctypes.c_void_p(d_out)))
 
     def g1_normalize(self, jacobians):
         j = _u64(jacobians, 12)
@@ -237,6 +258,15 @@ class Bbg:
         out = np.empty(shape, dtype=dtype)
         self._ck(self.lib.bbg_dev_download(self.ctx, out.ctypes.data, ctypes.c_void_p(ptr), out.nbytes))
         return out
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.bbg_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_get(self, name):
+        """(total_ms, launches) of the named kernel since profile_enable(True)."""
+        ms, cnt = ctypes.c_double(0), ctypes.c_size_t(0)
+        self._ck(self.lib.bbg_profile_get(self.ctx, name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
 
     def field_op(self, which, op, a, b=None):
         a = _u64(a, 4)

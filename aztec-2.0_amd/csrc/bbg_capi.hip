@@ -113,6 +113,10 @@ void bbg_destroy(bbg_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& kv : ctx->domains) ntt_free_domain(kv.second);
+    for (auto& kv : ctx->prof) {
+        for (auto e : kv.second.start) (void)hipEventDestroy(e);
+        for (auto e : kv.second.stop) (void)hipEventDestroy(e);
+    }
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
@@ -156,6 +160,39 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     BBG_HIP(hipDeviceSynchronize());
     for (auto& kv : ctx->domains) ntt_free_domain(kv.second);
     ctx->domains.clear();
+    return BBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel timing
+int bbg_profile_enable(bbg_ctx* ctx, int on)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->prof) {
+        for (auto e : kv.second.start) (void)hipEventDestroy(e);
+        for (auto e : kv.second.stop) (void)hipEventDestroy(e);
+    }
+    ctx->prof.clear();
+    ctx->prof_on = on != 0;
+    return BBG_OK;
+}
+int bbg_profile_get(bbg_ctx* ctx, const char* name, double* total_ms, size_t* launches)
+{
+    CHECK_CTX(ctx);
+    if (!name || !total_ms || !launches) { set_error("bbg_profile_get: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    *total_ms = 0;
+    *launches = 0;
+    auto it = ctx->prof.find(name);
+    if (it == ctx->prof.end()) return BBG_OK;
+    for (size_t i = 0; i < it->second.start.size(); i++) {
+        float ms = 0;
+        BBG_HIP(hipEventElapsedTime(&ms, it->second.start[i], it->second.stop[i]));
+        *total_ms += ms;
+    }
+    *launches = it->second.start.size();
     return BBG_OK;
 }
 
@@ -228,6 +265,19 @@ int bbg_srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, bbg_srs
     void* d_plain = nullptr;
     BBG_HIP(hipMalloc(&d_plain, n ? n * 64 : 64));
     int rc = srs_synth_linear(ctx, a, s, n, d_plain, ctx->stream);
+    if (rc == BBG_OK) rc = make_srs(ctx, d_plain, n, out);
+    (void)hipFree(d_plain);
+    return rc;
+}
+
+int bbg_srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, bbg_srs** out)
+{
+    CHECK_CTX(ctx);
+    if (!out) { set_error("bbg_srs_synth_hashed: null out"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void* d_plain = nullptr;
+    BBG_HIP(hipMalloc(&d_plain, n ? n * 64 : 64));
+    int rc = srs_synth_hashed(ctx, seed, n, d_plain, ctx->stream);
     if (rc == BBG_OK) rc = make_srs(ctx, d_plain, n, out);
     (void)hipFree(d_plain);
     return rc;
@@ -341,6 +391,14 @@ int bbg_g1_sum(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t out_j
     BBG_HIP(hipMemcpyAsync(out_jacobian, st, 96, hipMemcpyDeviceToHost, ctx->stream));
     BBG_HIP(hipStreamSynchronize(ctx->stream));
     return BBG_OK;
+}
+
+int bbg_g1_sum_device(bbg_ctx* ctx, const void* d_jacobians, size_t n, void* d_out_jacobian)
+{
+    CHECK_CTX(ctx);
+    if ((!d_jacobians && n) || !d_out_jacobian) { set_error("bbg_g1_sum_device: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return g1_sum_device(ctx, d_jacobians, n, d_out_jacobian, ctx->stream);
 }
 
 int bbg_g1_normalize(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t* out_affine)

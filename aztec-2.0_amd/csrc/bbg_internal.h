@@ -53,7 +53,17 @@ struct MsmScratch {
 
 } // namespace bbg
 
+namespace bbg {
+// Optional per-kernel timing with HIP events on the launch stream (bbg_profile_*): bench.py reads the average
+// duration of the dominant kernels live from here, so the roofline numbers do not depend on an external profiler.
+struct ProfEntry {
+    std::vector<hipEvent_t> start, stop;
+};
+} // namespace bbg
+
 struct bbg_ctx {
+    bool prof_on = false;
+    std::map<std::string, bbg::ProfEntry> prof;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -74,6 +84,26 @@ struct bbg_srs {
 };
 
 namespace bbg {
+struct ProfScope {
+    bbg_ctx* ctx;
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    ProfScope(bbg_ctx* c, const char* name, hipStream_t s) : ctx(c), st(s)
+    {
+        if (!c || !c->prof_on) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        ProfEntry& e = c->prof[name];
+        e.start.push_back(a);
+        e.stop.push_back(b);
+        (void)hipEventRecord(a, s);
+        stop = b;
+    }
+    ~ProfScope()
+    {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
 int ensure_buffer(void** buf, size_t* have, size_t need);
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
             hipStream_t stream);
@@ -84,5 +114,6 @@ int field_op_device(int which, int op, const void* a, const void* b, void* out, 
 int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
             hipStream_t stream);
 int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
+int srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, void* d_points, hipStream_t stream);
 int g1_sum_device(bbg_ctx* ctx, const void* d_jacs, size_t n, void* d_out, hipStream_t stream);
 } // namespace bbg

@@ -83,15 +83,16 @@ __global__ void __launch_bounds__(128) k_precompute_tables(const Affine* __restr
 // P_i = (a + i*s) * G : thread t owns CH consecutive points; start by double-and-add, then madd steps, normalise
 // with one inversion per thread.
 constexpr int SYNTH_CH = 16;
-__device__ Xyzz g1_mul_u64(const Affine& g, uint64_t k)
+__device__ Xyzz g1_mul_u128(const Affine& g, unsigned __int128 k)
 {
     Xyzz acc = xyzz_inf();
-    for (int i = 63; i >= 0; i--) {
+    for (int i = 127; i >= 0; i--) {
         acc = xyzz_dbl(acc);
-        if ((k >> i) & 1) acc = xyzz_madd(acc, g);
+        if ((uint64_t)(k >> i) & 1) acc = xyzz_madd(acc, g);
     }
     return acc;
 }
+__device__ Xyzz g1_mul_u64(const Affine& g, uint64_t k) { return g1_mul_u128(g, (unsigned __int128)k); }
 __global__ void __launch_bounds__(128) k_srs_synth(Affine* out, size_t n, uint64_t a, uint64_t s)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(128) k_srs_synth(Affine* out, size_t n, uint64
     two.v[0] = 2;
     G.y = fe_reduce_once(fe_to_mont(two));
     Affine S = xyzz_to_affine(g1_mul_u64(G, s));
-    Xyzz q = g1_mul_u64(G, a + (uint64_t)i0 * s);
+    Xyzz q = g1_mul_u128(G, (unsigned __int128)a + (unsigned __int128)i0 * s); // no 64-bit wrap: P_i = (a + i*s) G over the integers
     Xyzz pts[SYNTH_CH];
     Fq prod[SYNTH_CH];
     Fq acc = Fq::one();
@@ -113,6 +114,48 @@ __global__ void __launch_bounds__(128) k_srs_synth(Affine* out, size_t n, uint64
         prod[e] = acc;
         acc = fe_mul(acc, fe_mul(q.zz, q.zzz));
         q = xyzz_madd(q, S);
+        cnt++;
+    }
+    Fq inv = fq_invert(acc);
+    for (int e = cnt - 1; e >= 0; e--) {
+        Fq iz = fe_mul(inv, prod[e]);
+        inv = fe_mul(inv, fe_mul(pts[e].zz, pts[e].zzz));
+        Affine o;
+        o.x = fe_reduce_once(fe_mul(pts[e].x, fe_mul(iz, pts[e].zzz)));
+        o.y = fe_reduce_once(fe_mul(pts[e].y, fe_mul(iz, pts[e].zz)));
+        aff_store(out + i0 + e, o);
+    }
+}
+
+// P_i = k_i * G with k_i = mix64(seed + i) | 1: a synthetic SRS without small linear relations (the A + i*S
+// family has P_0 + P_3 = P_1 + P_2, which the reference's pippenger_unsafe cannot digest -- see oracle_srs_hashed).
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+constexpr int HASH_CH = 4;
+__global__ void __launch_bounds__(128) k_srs_hashed(Affine* out, size_t n, uint64_t seed)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i0 = t * HASH_CH;
+    if (i0 >= n) return;
+    Affine G;
+    G.x = Fq::one();
+    Fq two = Fq::zero();
+    two.v[0] = 2;
+    G.y = fe_reduce_once(fe_to_mont(two));
+    Xyzz pts[HASH_CH];
+    Fq prod[HASH_CH];
+    Fq acc = Fq::one();
+    int cnt = 0;
+    for (int e = 0; e < HASH_CH && i0 + e < n; e++) {
+        Xyzz q = g1_mul_u64(G, mix64(seed + (uint64_t)(i0 + e)) | 1ULL);
+        pts[e] = q;
+        prod[e] = acc;
+        acc = fe_mul(acc, fe_mul(q.zz, q.zzz));
         cnt++;
     }
     Fq inv = fq_invert(acc);
@@ -381,6 +424,15 @@ int srs_synth_linear(bbg_ctx*, uint64_t a, uint64_t s, size_t n, void* d_points,
     return BBG_OK;
 }
 
+int srs_synth_hashed(bbg_ctx*, uint64_t seed, size_t n, void* d_points, hipStream_t st)
+{
+    if (n == 0) return BBG_OK;
+    hipLaunchKernelGGL(k_srs_hashed, dim3(grid_for((n + HASH_CH - 1) / HASH_CH, 128)), dim3(128), 0, st, (Affine*)d_points, n,
+                       seed);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
 int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st)
 {
     if (from > srs.n || n > srs.n - from) {
@@ -414,19 +466,34 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     Xyzz* rows = (Xyzz*)(base + L.off_rows);
     Xyzz* cols = (Xyzz*)(base + L.off_cols);
 
-    hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
+    {
+        ProfScope ps(ctx, "msm_recode", st);
+        hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
+    }
     rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
-    size_t tmp = L.sort_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C, st);
-    if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
+    {
+        ProfScope ps(ctx, "msm_sort", st);
+        size_t tmp = L.sort_bytes;
+        hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C, st);
+        if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
+    }
     const uint32_t* skeys = dk.current();
     const uint32_t* svals = dv.current();
-    hipLaunchKernelGGL(k_offsets, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for((size_t)MSM_BUCKETS * MSM_T, 256)), dim3(256), 0, st, svals, offsets,
-                       (const Affine*)srs.points, srs.n, partials);
-    hipLaunchKernelGGL(k_bucket_sum, dim3(grid_for(MSM_BUCKETS, 256)), dim3(256), 0, st, partials, buckets);
-    hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, st, buckets, rows, cols);
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(512), 0, st, rows, cols, (Jacobian*)d_out_jac);
+    {
+        ProfScope ps(ctx, "msm_offsets", st);
+        hipLaunchKernelGGL(k_offsets, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
+    }
+    {
+        ProfScope ps(ctx, "msm_accumulate", st);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for((size_t)MSM_BUCKETS * MSM_T, 256)), dim3(256), 0, st, svals, offsets,
+                           (const Affine*)srs.points, srs.n, partials);
+    }
+    {
+        ProfScope ps(ctx, "msm_reduce", st);
+        hipLaunchKernelGGL(k_bucket_sum, dim3(grid_for(MSM_BUCKETS, 256)), dim3(256), 0, st, partials, buckets);
+        hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, st, buckets, rows, cols);
+        hipLaunchKernelGGL(k_final, dim3(1), dim3(512), 0, st, rows, cols, (Jacobian*)d_out_jac);
+    }
     BBG_HIP(hipGetLastError());
     return BBG_OK;
 }

@@ -440,7 +440,7 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
     return BBG_OK;
 }
 
-static int launch_pass(const NttDomain& d, int q, int inverse, const Fr* in, Fr* out, const Fr* post, hipStream_t st)
+static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, const Fr* in, Fr* out, const Fr* post, hipStream_t st)
 {
     PassParams p;
     p.in = in;
@@ -470,6 +470,7 @@ static int launch_pass(const NttDomain& d, int q, int inverse, const Fr* in, Fr*
     int threads = (R * W) / 2;
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
+    ProfScope ps(ctx, "ntt_pass", st);
     hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, p);
     return BBG_OK;
 }
@@ -482,14 +483,14 @@ static int ntt_core(bbg_ctx* ctx, NttDomain& d, Fr* a, int inverse, const Fr* po
         if (post) hipLaunchKernelGGL(k_scale_table, dim3(1), dim3(64), 0, st, a, post, (size_t)1);
         return BBG_OK;
     }
-    if (d.passes == 1) return launch_pass(d, 0, inverse, a, a, post, st);
+    if (d.passes == 1) return launch_pass(ctx, d, 0, inverse, a, a, post, st);
     int rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, n * sizeof(Fr));
     if (rc) return rc;
     Fr* scratch = (Fr*)ctx->ntt_scratch;
     // pass 0: a -> scratch (same positions); middle passes in place on scratch; last pass scratch -> a (transposing)
-    launch_pass(d, 0, inverse, a, scratch, nullptr, st);
-    for (int q = 1; q < d.passes - 1; q++) launch_pass(d, q, inverse, scratch, scratch, nullptr, st);
-    launch_pass(d, d.passes - 1, inverse, scratch, a, post, st);
+    launch_pass(ctx, d, 0, inverse, a, scratch, nullptr, st);
+    for (int q = 1; q < d.passes - 1; q++) launch_pass(ctx, d, q, inverse, scratch, scratch, nullptr, st);
+    launch_pass(ctx, d, d.passes - 1, inverse, scratch, a, post, st);
     return BBG_OK;
 }
 
@@ -616,8 +617,10 @@ template <class P> __global__ void k_field_op(int op, const Fe<P>* a, const Fe<P
     if (i >= n) return;
     Fe<P> x = fe_load<P>(a + i), y = b ? fe_load<P>(b + i) : Fe<P>::zero(), z;
     // inputs may be any 256-bit value: bring into [0,2p) the way the reference assumes its inputs are
-    x = fe_reduce_once(fe_reduce_once(fe_reduce_once(x)));
-    y = fe_reduce_once(fe_reduce_once(fe_reduce_once(y)));
+    for (int k = 0; k < 5; k++) { // 2^256 < 6p
+        x = fe_reduce_once(x);
+        y = fe_reduce_once(y);
+    }
     switch (op) {
     case 0: z = fe_mul(x, y); break;
     case 1: z = fe_add(x, y); break;

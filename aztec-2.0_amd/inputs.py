@@ -5,19 +5,21 @@ import numpy as np
 _MASK60 = np.uint64(0x0FFFFFFFFFFFFFFF)
 
 
-def splitmix64_limbs(seed, count):
-    """`count` uint64 words of the splitmix64 stream started at `seed` (vectorised: word i uses state seed+(i+1)*gamma)."""
+def splitmix64_limbs(seed, count, offset=0):
+    """Words [offset, offset+count) of the splitmix64 stream started at `seed` (index-based: word i uses state
+    seed + (i+1)*gamma, so any slice can be generated on its own -- ranks generate only their shard)."""
     with np.errstate(over="ignore"):
-        idx = np.arange(1, count + 1, dtype=np.uint64)
+        idx = np.arange(1 + offset, count + offset + 1, dtype=np.uint64)
         z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
 
 
-def synthetic_scalars(seed, n):
-    """n x 4 limbs, top limb masked to 60 bits (value < 2^252 < r), read as Montgomery-form Fr residues."""
-    a = splitmix64_limbs(seed, 4 * n).reshape(n, 4).copy()
+def synthetic_scalars(seed, n, start=0):
+    """Elements [start, start+n) of the stream: n x 4 limbs, top limb masked to 60 bits (value < 2^252 < r), read as
+    Montgomery-form Fr residues."""
+    a = splitmix64_limbs(seed, 4 * n, 4 * start).reshape(n, 4).copy()
     a[:, 3] &= _MASK60
     return a
 

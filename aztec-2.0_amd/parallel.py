@@ -1,0 +1,55 @@
+"""Multi-GPU decomposition of the hot path: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI
+on the GPU box, "gloo" in the CPU tests).
+
+MSM shards by POINT RANGE -- the reference's own precedent is Pippenger::pippenger_unsafe(scalars, from, range) +
+g1_sum (ecc/curves/bn254/scalar_multiplication/pippenger.cpp:27-31, c_bind.cpp:31-46): rank g owns SRS points and
+scalars [g*n/G, (g+1)*n/G), runs the whole bucket MSM locally, and the G 96-byte Jacobian partials are all-gathered
+and added.  RCCL has no elliptic-curve reduction operator, so "reduce" = all_gather + local g1_sum; the exchange is
+G*96 bytes, i.e. latency only.  The NTT side of the prover needs no exchange at all: a 4n coset FFT of n non-zero
+coefficients is 4 independent size-n coset FFTs (work_queue.hpp:166-199), so ranks take whole transforms.
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous point range of `rank`: (start, count); the last rank takes the remainder."""
+    base = n // world
+    start = rank * base
+    count = base if rank < world - 1 else n - start
+    return start, count
+
+
+def all_gather_partials(local_jacobian, dist, device=None):
+    """local_jacobian: 12 uint64 limbs (numpy) or a torch int64 tensor of 12.  Returns a (world, 12) uint64 numpy array
+    holding every rank's partial, identical on all ranks."""
+    import torch
+    if isinstance(local_jacobian, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(local_jacobian, dtype=np.uint64).view(np.int64).copy())
+        if device is not None:
+            t = t.to(device)
+    else:
+        t = local_jacobian
+    world = dist.get_world_size()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy().view(np.uint64)
+
+
+def msm_sharded(bbg, srs_local, d_scalars_ptr, n_local, d_out_tensor, dist):
+    """Local bucket MSM on this rank's shard, then all_gather + g1_sum.  d_out_tensor: torch int64[12] on the GPU.
+    Returns the global result as 12 uint64 limbs (identical on every rank)."""
+    bbg.msm_device(srs_local, d_scalars_ptr, n_local, d_out_tensor.data_ptr())
+    bbg.sync()
+    if dist is None or dist.get_world_size() == 1:
+        return d_out_tensor.cpu().numpy().view(np.uint64)
+    parts = all_gather_partials(d_out_tensor, dist)
+    return bbg.g1_sum(parts)
+
+
+def msm_sharded_async(bbg, srs_local, d_scalars_ptr, n_local, d_partial, d_gathered, d_result, dist):
+    """Stream-ordered variant used in the timed loop of bench.py: nothing leaves the GPU.  d_partial int64[12],
+    d_gathered int64[world*12], d_result int64[12] are torch CUDA tensors; bbg must run on torch's current stream
+    (bbg.set_stream) so that the RCCL all-gather is ordered after the MSM kernels and before the group sum."""
+    bbg.msm_device(srs_local, d_scalars_ptr, n_local, d_partial.data_ptr())
+    dist.all_gather_into_tensor(d_gathered, d_partial)
+    bbg.g1_sum_device(d_gathered.data_ptr(), dist.get_world_size(), d_result.data_ptr())

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BN254 G1 MSM + Fr NTT at n = 2^20 on N MI355X (BASELINE.json `metric`, config 3 + config 2).
+
+One STEP = one pass of the prover hot path over one batch of synthetic input, per GPU:
+    1 x Pippenger MSM of n = 2^20 scalars over the device-resident SRS  (+ for N > 1: RCCL all-gather of the N 96-byte
+    partials and the group sum -- the point-range sharding of one N*2^20-point MSM), then
+    1 x forward NTT of n = 2^20 coefficients (in place, device resident).
+Inputs are resident in HBM before the timed region (SRS registered once, like the Pippenger constructor; twiddles
+built once, like compute_lookup_table).  `value` = scalars processed by all ranks per second over the WHOLE step
+(MSM + NTT), so it under-states the MSM-only rate; the separately event-timed MSM / NTT rates are in `extra`.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  At N = 1, rank 0 also runs the CPU baseline on the host cores (the real reference
+binary oracle/_ref/libbbref.so when it runs on this CPU, else the oracle port) on a bounded sample, and checks the GPU
+results bit-exactly against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0xBB254
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MAD_PEAK_TOPS = 28.0           # measured v_mad_u64_u32 issue rate, bench_micro/mulbench.hip (profiles/r01_mulbench.txt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    import importlib
+    par = importlib.import_module("aztec_amd.parallel")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    lg = args.log2n
+    n = 1 << lg
+    bbg = pkg.Bbg(local_rank)
+    bbg.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---- setup (untimed): SRS shard resident in HBM, scalars / coefficients resident, twiddles built
+    start = rank * n  # weak scaling: every rank owns n points of a world*n-point SRS
+    srs = bbg.srs_synth_hashed(SEED + start, n)  # P_{start+i}: the hashed generator is index-based
+    scalars = pkg.synthetic_scalars(SEED + 3, n, start)
+    coeffs = pkg.synthetic_scalars(SEED + 100 + lg, n)
+    d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
+    d_coeffs = torch.from_numpy(coeffs.view(np.int64)).to(dev)
+    d_coeffs_work = d_coeffs.clone()
+    d_partial = torch.zeros(12, dtype=torch.int64, device=dev)
+    d_gathered = torch.zeros(12 * world, dtype=torch.int64, device=dev)
+    d_result = torch.zeros(12, dtype=torch.int64, device=dev)
+    bbg.ntt_prepare(lg)
+
+    def step():
+        if world > 1:
+            par.msm_sharded_async(bbg, srs, d_scalars.data_ptr(), n, d_partial, d_gathered, d_result, dist)
+        else:
+            bbg.msm_device(srs, d_scalars.data_ptr(), n, d_result.data_ptr())
+        bbg.ntt_device(d_coeffs_work.data_ptr(), lg, 0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    bbg.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = {k: bbg.profile_get(k) for k in ("msm_recode", "msm_sort", "msm_offsets", "msm_accumulate", "msm_reduce", "ntt_pass")}
+    bbg.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * n / (elapsed / args.steps) / 1e6
+
+    # ---- per-kernel numbers from the HIP events recorded inside the timed region
+    def avg(name):
+        ms, cnt = prof[name]
+        return (ms / cnt) if cnt else float("nan")
+
+    msm_ms = sum(prof[k][0] for k in ("msm_recode", "msm_sort", "msm_offsets", "msm_accumulate", "msm_reduce")) / args.steps
+    ntt_ms = prof["ntt_pass"][0] / args.steps
+    acc_ms = avg("msm_accumulate")
+    alg_bytes_msm = 96.0 * n                      # 32-B scalar + 64-B base per term, one launch covers all n terms
+    achieved = alg_bytes_msm / (acc_ms * 1e-3) / 1e9
+    roofline = {"kernel": "k_accumulate (MSM bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(acc_ms, 4),
+                "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
+    pass_ms = avg("ntt_pass")
+    ntt_alg = 64.0 * n
+    ntt_passes = prof["ntt_pass"][1] / max(1, args.steps)
+    extra = {
+        "msm_ms": round(msm_ms, 4), "msm_mscalar_per_s_per_gpu": round(n / msm_ms / 1e3, 2),
+        "ntt_ms": round(ntt_ms, 4), "ntt_gfield_ops_per_s_per_gpu": round(1.5 * n * lg / ntt_ms / 1e6, 2),
+        "msm_phase_ms": {k: round(prof[k][0] / args.steps, 4) for k in prof if k.startswith("msm_")},
+        "roofline_ntt": {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": round(ntt_alg / (pass_ms * 1e-3) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ntt_alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic": None, "avg_launch_ms": round(pass_ms, 4), "launches_per_ntt": ntt_passes,
+                         "whole_ntt_frac": round(ntt_alg / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        "alu": {"unit": "T v_mad_u64_u32/s", "peak_measured": MAD_PEAK_TOPS,
+                # 16 windows x n mixed additions x 10 Fq mul x 136 mads ; n/2*(lg - passes) + n*(passes-1) Fr mul x 136
+                "msm_accumulate": round(16.0 * n * 10 * 136 / (acc_ms * 1e-3) / 1e12, 2),
+                "ntt": round((n / 2 * (lg - ntt_passes) + n * (ntt_passes - 1)) * 136 / (ntt_ms * 1e-3) / 1e12, 2)},
+    }
+
+    out = {
+        "metric": "BN254 G1 MSM Mscalar-mults/s (+ Fr NTT Gfield-ops/s in extra) at n=2^%d" % lg,
+        "value": round(value, 3), "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
+        "config": {"workload": "per GPU and step: 1 Pippenger MSM (n=2^%d scalars, hashed synthetic SRS resident in HBM) + 1 forward "
+                               "NTT (n=2^%d); N>1 = one N*2^%d-point MSM sharded by point range, RCCL all-gather of 96-B partials" % (lg, lg, lg),
+                   "log2n": lg, "sharding": "point-range" if world > 1 else "none"},
+        "roofline": roofline, "extra": extra,
+    }
+
+    # ---- CPU baseline + bit-exact check against it (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, value)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    srs.free()
+    bbg.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, gpu_value):
+    """Times the CPU path on the host cores on a bounded sample of the same workload and checks parity."""
+    from oracle.oracle import Oracle, Ref, ref_available
+    n = 1 << lg
+    oracle = Oracle()
+    gpu_msm = oracle.jac_to_affine(d_result.cpu().numpy().view(np.uint64))
+    work = d_coeffs.clone()
+    bbg.ntt_device(work.data_ptr(), lg, 0)
+    bbg.sync()
+    gpu_ntt = oracle.canon(0, work.cpu().numpy().view(np.uint64))
+    points = srs.read()
+    if ref_available():
+        ref = Ref()
+        ctx = ref.msm(points)
+        best = 1e9
+        for _ in range(2):
+            res, t = ctx.run(scalars, 0, True)
+            best = min(best, t)
+        ctx.free()
+        dom = ref.domain(lg, 0)
+        best_ntt = 1e9
+        for _ in range(3):
+            ntt_out, t = dom.run(coeffs, 0)
+            best_ntt = min(best_ntt, t)
+        dom.free()
+        parity = bool(np.array_equal(res, gpu_msm) and np.array_equal(ntt_out, gpu_ntt))
+        val = n / best / 1e6
+        return {"value": round(val, 3), "unit": "Mscalar-mults/s", "cores": ref.num_threads(), "kind": "reference",
+                "sample": "reference binary (oracle/_ref): pippenger_unsafe n=2^%d best of 2 (%.1f ms) + fft n=2^%d best of 3 "
+                          "(%.1f ms), same SRS/scalars/coefficients as the GPU run" % (lg, best * 1e3, lg, best_ntt * 1e3),
+                "ntt_gfield_ops_per_s": round(1.5 * n * lg / best_ntt / 1e9, 3), "msm_ms": round(best * 1e3, 2),
+                "ntt_ms": round(best_ntt * 1e3, 2), "gpu_bit_exact_vs_cpu": parity, "gpu_over_cpu": round(gpu_value / val, 1)}
+    # port: the oracle is a scalar restatement; sample 2^16 terms of the same inputs
+    m = min(n, 1 << 16)
+    t0 = time.perf_counter()
+    res = oracle.pippenger(scalars[:m], points[:m])
+    t_msm = time.perf_counter() - t0
+    part = oracle.jac_to_affine(bbg.msm(srs, scalars[:m]))
+    t0 = time.perf_counter()
+    ntt_out = oracle.ntt(coeffs, 0)
+    t_ntt = time.perf_counter() - t0
+    parity = bool(np.array_equal(res, part) and np.array_equal(ntt_out, gpu_ntt))
+    val = m / t_msm / 1e6
+    return {"value": round(val, 3), "unit": "Mscalar-mults/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "oracle port: bucket MSM on the first 2^16 terms (%.1f ms) + full fft n=2^%d (%.1f ms)" % (t_msm * 1e3, lg, t_ntt * 1e3),
+            "ntt_gfield_ops_per_s": round(1.5 * n * lg / t_ntt / 1e9, 3), "gpu_bit_exact_vs_cpu": parity,
+            "gpu_over_cpu": round(gpu_value / val, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,9 @@ int bbg_srs_register_device(bbg_ctx* ctx, const void* d_points, size_t n, bbg_sr
 /* Synthetic SRS P_i = (a + i*s)*G generated on the GPU (the Ignition transcript is absent from the
  * reference snapshot).  a, s: plain 64-bit scalars, s != 0. */
 int bbg_srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, bbg_srs** out);
+/* Synthetic SRS P_i = k_i*G, k_i = mix64(seed + i) | 1 (splitmix64 finaliser): no small linear relations between
+ * the bases, which pippenger_unsafe requires of its inputs (scalar_multiplication.cpp:908-921). */
+int bbg_srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, bbg_srs** out);
 /* Reads an Ignition-format transcript file (manifest + big-endian points; srs/io.cpp:11-162): result is
  * monomials[0] = G followed by the file's points, num_points in total -- exactly read_transcript_g1. */
 int bbg_srs_load_transcript(bbg_ctx* ctx, const char* path, size_t num_points, bbg_srs** out);
@@ -79,6 +82,8 @@ int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, si
 int bbg_msm_device(bbg_ctx* ctx, bbg_srs* srs, const void* d_scalars, size_t from, size_t n, void* d_out_jacobian);
 /* g1_sum (c_bind.cpp:39-46): sum of n Jacobian points (host arrays, 96 B each). */
 int bbg_g1_sum(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t out_jacobian[12]);
+/* Same on device buffers, asynchronous on the context stream (the multi-GPU combine after an all-gather of partials). */
+int bbg_g1_sum_device(bbg_ctx* ctx, const void* d_jacobians, size_t n, void* d_out_jacobian);
 /* g1::affine_element(result) (element_impl.hpp:51-68) for n points; output canonical Montgomery affine (64 B each). */
 int bbg_g1_normalize(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t* out_affine);
 
@@ -117,6 +122,10 @@ int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 6..11). */
 int bbg_set_option(bbg_ctx* ctx, const char* key, long value);
+/* Per-kernel timing with HIP events recorded on the launch stream.  Names: "msm_recode", "msm_sort", "msm_offsets",
+ * "msm_accumulate", "msm_reduce", "ntt_pass".  enable(…, 1) clears previous samples. */
+int bbg_profile_enable(bbg_ctx* ctx, int on);
+int bbg_profile_get(bbg_ctx* ctx, const char* name, double* total_ms, size_t* launches);
 /* Field-level self test entry used by tests: out[i] = a[i] (op) b[i] computed by the device field code.
  * which: 0 Fr, 1 Fq.  op: 0 mul, 1 add, 2 sub, 3 mul via the CIOS cross-check path, 4 from_montgomery, 5 to_montgomery. */
 int bbg_field_op(bbg_ctx* ctx, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

@@ -1,0 +1,120 @@
+"""Developer probe (not a test, not the bench): shakes the HIP path against the oracle on a GPU box and prints
+timings.  Usage: python scripts/gpu_probe.py [stage ...]  with stages: field ntt msm time"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+pkg = ge.load_package()
+from oracle.oracle import Oracle  # noqa: E402
+
+stages = sys.argv[1:] or ["field", "ntt", "msm", "time"]
+O = Oracle()
+B = pkg.Bbg(0)
+inp = pkg.inputs
+
+
+def check(name, a, b):
+    ok = np.array_equal(a, b)
+    print(f"{'ok  ' if ok else 'FAIL'} {name}", flush=True)
+    if not ok:
+        bad = np.argwhere(np.any(np.asarray(a).reshape(-1, a.shape[-1]) != np.asarray(b).reshape(-1, b.shape[-1]), axis=1))
+        print("   first mismatches at rows", bad[:8].ravel(), "of", len(a))
+    return ok
+
+
+if "field" in stages:
+    a = inp.synthetic_scalars(1, 4096)
+    b = inp.synthetic_scalars(2, 4096)
+    a[0] = 0xFFFFFFFFFFFFFFFF
+    b[1] = 0
+    for which in (0, 1):
+        check(f"field{which} mul", B.field_op(which, 0, a, b), O.fe_mul(which, a, b))
+        check(f"field{which} mul cios", B.field_op(which, 3, a, b), O.fe_mul(which, a, b))
+        check(f"field{which} add", B.field_op(which, 1, a, b), O.fe_add(which, a, b))
+        check(f"field{which} sub", B.field_op(which, 2, a, b), O.fe_sub(which, a, b))
+        check(f"field{which} from_mont", B.field_op(which, 4, a), O.from_mont(which, a))
+        check(f"field{which} to_mont", B.field_op(which, 5, a), O.to_mont(which, a))
+
+if "ntt" in stages:
+    k = inp.synthetic_scalars(77, 1)[0]
+    for lg in (0, 1, 2, 3, 5, 8, 11, 12, 13, 14, 16):
+        c = inp.synthetic_scalars(100 + lg, 1 << lg)
+        for op in range(8):
+            kk = k if op >= 4 else None
+            got = O.canon(0, B.ntt(c, op, 0, kk))
+            check(f"ntt lg={lg} op={op}", got, O.ntt(c, op, 0, kk))
+        if lg >= 2:
+            gs = (1 << lg) // 4
+            for op in (2, 5, 6):
+                kk = k if op >= 4 else None
+                check(f"ntt lg={lg} op={op} gs={gs}", O.canon(0, B.ntt(c, op, gs, kk)), O.ntt(c, op, gs, kk))
+    c = inp.synthetic_scalars(5, 256)
+    for ext in (2, 4, 8):
+        check(f"coset split ext={ext}", O.canon(0, B.coset_fft_split(c, ext)), O.coset_fft_split(c, ext))
+
+if "msm" in stages:
+    n = 1 << 12
+    pts_l = O.srs_linear(0x123456789ABCDEF, 0xFEDCBA987654321, n)
+    srs_l = B.srs_synth_linear(0x123456789ABCDEF, 0xFEDCBA987654321, n)
+    check("srs synth linear", srs_l.read(), pts_l)
+    pts_h = O.srs_hashed(0xBB254, n)
+    srs_h = B.srs_synth_hashed(0xBB254, n)
+    check("srs synth hashed", srs_h.read(), pts_h)
+    srs_r = B.srs_register(pts_h)
+    check("srs register", srs_r.read(), pts_h)
+    sc = inp.synthetic_scalars(3, n)
+    for nn in (0, 1, 2, 17, 100, 1000, n):
+        got = O.jac_to_affine(B.msm(srs_h, sc[:nn]))
+        check(f"msm n={nn}", got, O.pippenger(sc[:nn], pts_h[:nn]))
+    got = O.jac_to_affine(B.msm(srs_l, sc[:1000], start=100))
+    check("msm linear from=100", got, O.pippenger(sc[:1000], pts_l[100:1100]))
+    mixed = inp.mixed_scalars(9, n, lambda p: O.to_mont(0, p))
+    check("msm mixed", O.jac_to_affine(B.msm(srs_h, mixed)), O.pippenger(mixed, pts_h))
+    same = np.tile(sc[:1], (n, 1))
+    check("msm all-equal scalars", O.jac_to_affine(B.msm(srs_h, same)), O.pippenger(same, pts_h))
+
+if "time" in stages:
+    import torch
+    for lg in (16, 18, 20, 22, 24):
+        n = 1 << lg
+        c = inp.synthetic_scalars(lg, n)
+        t = torch.from_numpy(c.view(np.int64)).cuda()
+        B.ntt_prepare(lg)
+        B.ntt_device(t.data_ptr(), lg, 0)
+        B.sync()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            B.ntt_device(t.data_ptr(), lg, 0)
+        B.sync()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"ntt 2^{lg}: {dt*1e3:.3f} ms  {1.5*n*lg/dt/1e9:.2f} Gfield-op/s  {64*n/dt/1e9:.1f} GB/s(alg)", flush=True)
+    for lg in (16, 20):
+        n = 1 << lg
+        t0 = time.perf_counter()
+        srs = B.srs_synth_hashed(0xBB254, n)
+        print(f"srs synth+tables 2^{lg}: {time.perf_counter()-t0:.3f} s")
+        sc = inp.synthetic_scalars(1234, n)
+        ts = torch.from_numpy(sc.view(np.int64)).cuda()
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+        B.sync()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+        B.sync()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"msm 2^{lg}: {dt*1e3:.3f} ms  {n/dt/1e6:.2f} Mscalar-mul/s", flush=True)
+        if lg == 16:
+            pts = srs.read()
+            got = O.jac_to_affine(out.cpu().numpy().view(np.uint64))
+            check("msm 2^16 vs oracle", got, O.pippenger(sc, pts))
+        srs.free()
+print("probe done")

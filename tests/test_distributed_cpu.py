@@ -1,0 +1,85 @@
+"""world_size-2 gloo test of the multi-GPU decomposition (aztec-2.0_amd/parallel.py) on CPU: the point-range sharding,
+the all_gather of 96-byte partials and the final group sum reproduce the single-process MSM.  The per-rank "device
+MSM" is emulated with the oracle (this is a CPU test of the host logic; the GPU kernels are covered by -m gpu)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["BBG_ROOT"])
+import torch.distributed as dist
+import __graft_entry__ as ge
+from oracle.oracle import Oracle
+pkg = ge.load_package()
+import importlib
+par = importlib.import_module("aztec_amd.parallel")
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+O = Oracle()
+n = 1000
+pts = O.srs_hashed(0xBB254, n)
+sc = pkg.synthetic_scalars(4, n)
+start, count = par.shard_range(n, rank, world)
+aff = O.pippenger(sc[start:start + count], pts[start:start + count])
+one = O.to_mont(1, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+jac = np.concatenate([aff, one]) if (int(aff[3]) >> 63) == 0 else np.concatenate([aff, np.zeros(4, dtype=np.uint64)])
+parts = par.all_gather_partials(jac, dist)
+assert parts.shape == (world, 12)
+total = O.g1_sum(parts)
+whole = O.pippenger(sc, pts)
+assert np.array_equal(total, whole), "sharded MSM != whole MSM"
+covered = sum(par.shard_range(n, r, world)[1] for r in range(world))
+assert covered == n
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_msm_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BBG_ROOT=ROOT,
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        outs.append(out.decode())
+    for rank, p in enumerate(procs):
+        assert p.returncode == 0, outs[rank]
+        assert f"rank {rank} ok" in outs[rank]
+
+
+def test_shard_range_partitions():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.load_package()
+    import importlib
+    par = importlib.import_module("aztec_amd.parallel")
+    for n in (0, 1, 7, 1 << 20, (1 << 20) + 3):
+        for world in (1, 2, 4, 8):
+            pos = 0
+            for r in range(world):
+                s, c = par.shard_range(n, r, world)
+                assert s == pos and c >= 0
+                pos += c
+            assert pos == n

@@ -1,0 +1,319 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI (libbbg.so); results are compared
+bit-exactly, on canonical values, with the oracle on the same seeded inputs, with the golden vectors recorded from the
+compiled reference, and -- at BASELINE.json's full sizes -- through size-independent algebraic properties."""
+import numpy as np
+import pytest
+
+from conftest import limbs, sha, unhex
+
+pytestmark = pytest.mark.gpu
+
+FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
+
+
+# ---------------------------------------------------------------------------------------------- fields
+def test_native_library_loaded(pkg, bbg):
+    maps = open("/proc/self/maps").read()
+    assert "libbbg.so" in maps, "the HIP extension is not the code that ran"
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_field_ops(pkg, oracle, bbg, which):
+    a = pkg.synthetic_scalars(11, 20000)
+    b = pkg.synthetic_scalars(12, 20000)
+    a[0] = 0xFFFFFFFFFFFFFFFF  # un-reduced representatives
+    b[1] = 0
+    a[2] = oracle.canon(which, a[3:4])[0]
+    assert np.array_equal(bbg.field_op(which, 0, a, b), oracle.fe_mul(which, a, b))
+    assert np.array_equal(bbg.field_op(which, 3, a, b), oracle.fe_mul(which, a, b))  # CIOS cross-check path
+    assert np.array_equal(bbg.field_op(which, 1, a, b), oracle.fe_add(which, a, b))
+    assert np.array_equal(bbg.field_op(which, 2, a, b), oracle.fe_sub(which, a, b))
+    assert np.array_equal(bbg.field_op(which, 4, a), oracle.from_mont(which, a))
+    assert np.array_equal(bbg.field_op(which, 5, a), oracle.to_mont(which, a))
+
+
+def test_field_reference_kats(bbg, oracle, kats):
+    for name, which, op in (("fr_mul", 0, 0), ("fr_add", 0, 1), ("fr_sub", 0, 2), ("fq_mul", 1, 0), ("fq_mul_short", 1, 0),
+                            ("fq_add", 1, 1), ("fq_sub", 1, 2), ("fr_sqr", 0, 0), ("fq_sqr", 1, 0)):
+        k = kats[name]
+        a = limbs(k["a"])
+        b = limbs(k["b"]) if "b" in k else a
+        assert np.array_equal(bbg.field_op(which, op, a, b)[0], oracle.canon(which, limbs(k["expected"]))[0]), k["cite"]
+
+
+# ---------------------------------------------------------------------------------------------- NTT family
+@pytest.mark.parametrize("lg", [0, 1, 2, 3, 5, 9, 11, 12, 13, 15, 16])
+def test_ntt_all_variants_vs_oracle(pkg, oracle, bbg, golden, lg):
+    kc = unhex(golden["ntt_constant"])[0]
+    c = pkg.synthetic_scalars(0xBB254 + 100 + lg, 1 << lg)
+    for op in range(8):
+        k = kc if op >= 4 else None
+        assert np.array_equal(oracle.canon(0, bbg.ntt(c, op, 0, k)), oracle.ntt(c, op, 0, k)), (lg, op)
+    if lg >= 2:
+        gs = (1 << lg) // 4  # proving_key's generator_size = n on the 4n domain (proving_key.cpp:21-22)
+        for op in (2, 5, 6):
+            k = kc if op >= 4 else None
+            assert np.array_equal(oracle.canon(0, bbg.ntt(c, op, gs, k)), oracle.ntt(c, op, gs, k)), (lg, op, gs)
+
+
+def test_ntt_golden_from_reference(pkg, oracle, bbg, golden):
+    kc = unhex(golden["ntt_constant"])[0]
+    for rec in golden["ntt"]:
+        c = pkg.synthetic_scalars(rec["seed"], 1 << rec["log2n"])
+        out = oracle.canon(0, bbg.ntt(c, rec["op"], rec["generator_size"], kc if rec["op"] >= 4 else None))
+        assert sha(out) == rec["sha256"], rec
+    for rec in golden["coset_fft_split"]:
+        c = pkg.synthetic_scalars(rec["seed"], 1 << rec["log2n"])
+        assert sha(oracle.canon(0, bbg.coset_fft_split(c, rec["ext"]))) == rec["sha256"], rec
+
+
+@pytest.mark.parametrize("tile,maxr", [(12, 9), (12, 10), (11, 8), (10, 6), (9, 5)])
+def test_ntt_pass_plans(pkg, oracle, bbg, tile, maxr):
+    """Different pass decompositions (2, 3 and 4 passes, several tile widths) give the same transform."""
+    bbg.set_option("ntt_tile_log", tile)
+    bbg.set_option("ntt_max_logr", maxr)
+    try:
+        for lg in (12, 14, 17):
+            c = pkg.synthetic_scalars(7000 + lg, 1 << lg)
+            assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), (tile, maxr, lg)
+            assert np.array_equal(oracle.canon(0, bbg.ntt(c, COSET_IFFT)), oracle.ntt(c, 3)), (tile, maxr, lg)
+    finally:
+        bbg.set_option("ntt_tile_log", 12)
+        bbg.set_option("ntt_max_logr", 9)
+
+
+def test_fft_matches_horner(pkg, oracle, bbg):
+    """fft_with_small_degree (polynomial_arithmetic.test.cpp:45-68) on the GPU transform."""
+    n = 16
+    c = pkg.synthetic_scalars(31337, n)
+    out = oracle.canon(0, bbg.ntt(c, FFT))
+    w = oracle.root_of_unity(4)
+    z = oracle.to_mont(0, np.array([1, 0, 0, 0], dtype=np.uint64))[0]
+    for i in range(n):
+        assert np.array_equal(oracle.poly_eval(c, z), out[i])
+        z = oracle.fe_mul(0, z, w)[0]
+
+
+@pytest.mark.parametrize("lg", [18, 20, 22, 24])
+def test_ntt_full_size_properties(pkg, oracle, bbg, lg):
+    """BASELINE config 2 sizes: round trips (basic_fft / fft_coset_ifft_consistency, polynomial_arithmetic.test.cpp:70-134),
+    linearity, and the n / 2n cross-domain consistency of :136-177, all bit-exact on canonical values."""
+    import torch
+    n = 1 << lg
+    a = pkg.synthetic_scalars(900 + lg, n)
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    work = ta.clone()
+    bbg.ntt_device(work.data_ptr(), lg, FFT)
+    bbg.ntt_device(work.data_ptr(), lg, IFFT)
+    bbg.sync()
+    back = work.cpu().numpy().view(np.uint64)
+    assert np.array_equal(oracle.canon(0, back), oracle.canon(0, a)), "ifft(fft(a)) != a"
+    work = ta.clone()
+    bbg.ntt_device(work.data_ptr(), lg, COSET_FFT)
+    bbg.ntt_device(work.data_ptr(), lg, COSET_IFFT)
+    bbg.sync()
+    assert np.array_equal(oracle.canon(0, work.cpu().numpy().view(np.uint64)), oracle.canon(0, a)), "coset round trip"
+    # spot values against Horner evaluation at omega^i (ordering + root choice at full size)
+    work = ta.clone()
+    bbg.ntt_device(work.data_ptr(), lg, FFT)
+    bbg.sync()
+    out = oracle.canon(0, work.cpu().numpy().view(np.uint64))
+    if lg <= 20:
+        w = oracle.root_of_unity(lg)
+        for i in (0, 1, 5, n // 2 + 3, n - 1):
+            # omega^i by square-and-multiply on the oracle side
+            z = oracle.to_mont(0, np.array([1, 0, 0, 0], dtype=np.uint64))[0]
+            base, e = w, i
+            while e:
+                if e & 1:
+                    z = oracle.fe_mul(0, z, base)[0]
+                base = oracle.fe_mul(0, base, base)[0]
+                e >>= 1
+            assert np.array_equal(oracle.poly_eval(a, z), out[i]), i
+    # linearity: fft(a + b) = fft(a) + fft(b)
+    b = pkg.synthetic_scalars(1900 + lg, n)
+    s = oracle.fe_add(0, a, b)
+    wb = torch.from_numpy(b.view(np.int64)).cuda()
+    ws = torch.from_numpy(s.view(np.int64)).cuda()
+    bbg.ntt_device(wb.data_ptr(), lg, FFT)
+    bbg.ntt_device(ws.data_ptr(), lg, FFT)
+    bbg.sync()
+    fb = wb.cpu().numpy().view(np.uint64)
+    fs = ws.cpu().numpy().view(np.uint64)
+    assert np.array_equal(oracle.fe_add(0, out, fb), oracle.canon(0, fs)), "linearity"
+
+
+def test_ntt_golden_2_20_digest(pkg, oracle, bbg, golden):
+    recs = [r for r in golden["ntt"] if r["log2n"] == 20]
+    assert recs
+    for rec in recs:
+        c = pkg.synthetic_scalars(rec["seed"], 1 << 20)
+        assert sha(oracle.canon(0, bbg.ntt(c, rec["op"], rec["generator_size"]))) == rec["sha256"], rec
+
+
+def test_ntt_error_paths(pkg, bbg):
+    c = pkg.synthetic_scalars(1, 8)
+    with pytest.raises(pkg.BbgError):
+        bbg.ntt(c, 4)  # fft_with_constant without a constant
+    with pytest.raises(pkg.BbgError):
+        bbg.ntt(c, 99)
+    with pytest.raises(pkg.BbgError):
+        bbg.ntt_prepare(29)  # beyond the 2-adicity of Fr
+
+
+# ---------------------------------------------------------------------------------------------- SRS
+def test_srs_synth_and_register(pkg, oracle, bbg):
+    n = 3000
+    want_l = oracle.srs_linear(0x123456789ABCDEF, 0xFEDCBA987654321, n)
+    srs = bbg.srs_synth_linear(0x123456789ABCDEF, 0xFEDCBA987654321, n)
+    assert np.array_equal(srs.read(), want_l)
+    srs.free()
+    want_h = oracle.srs_hashed(0xBB254, n)
+    srs = bbg.srs_synth_hashed(0xBB254, n)
+    assert np.array_equal(srs.read(), want_h)
+    assert srs.num_points == n
+    srs.free()
+    srs = bbg.srs_register(want_h)
+    assert np.array_equal(srs.read(5, 10), want_h[5:15])
+    srs.free()
+    # the reference's interleaved endomorphism table (stride 128) is accepted as-is
+    table = oracle.point_table(want_h[:100])
+    srs = bbg.srs_register(table, stride_bytes=128)
+    assert np.array_equal(srs.read(), want_h[:100])
+    srs.free()
+
+
+def test_srs_transcript_roundtrip(pkg, oracle, bbg, tmp_path):
+    """Ignition transcript format (srs/io.cpp:11-162): write one with the documented layout, load it through the
+    product reader, expect monomials[0] = G followed by the file's points."""
+    import struct
+    n_file = 40
+    pts = oracle.srs_hashed(77, n_file)
+    plain = oracle.from_mont(1, pts.reshape(-1, 4)).reshape(n_file, 8)
+    path = tmp_path / "transcript00.dat"
+    with open(path, "wb") as f:
+        f.write(struct.pack(">7I", 0, 1, n_file, 0, n_file, 0, 0))
+        f.write(plain.astype(">u8").tobytes())  # every limb big-endian, limbs least-significant first
+        f.write(b"\0" * 64)
+    srs = bbg.srs_load_transcript(tmp_path, 33)
+    got = srs.read()
+    assert np.array_equal(got[0], oracle.g1_generator())
+    assert np.array_equal(got[1:], pts[:32])
+    srs.free()
+    with pytest.raises(pkg.BbgError, match="Is your srs large enough"):
+        bbg.srs_load_transcript(tmp_path, 100)
+
+
+# ---------------------------------------------------------------------------------------------- MSM
+@pytest.fixture(scope="module")
+def srs16(bbg):
+    s = bbg.srs_synth_hashed(0xBB254, 1 << 16)
+    yield s
+    s.free()
+
+
+def test_msm_vs_oracle_sizes(pkg, oracle, bbg, srs16):
+    pts = srs16.read(0, 5000)
+    sc = pkg.synthetic_scalars(0xBB254 + 3, 5000)
+    for n in (0, 1, 2, 3, 17, 64, 65, 100, 1000, 4097, 5000):  # undersized_inputs :619, ragged sizes
+        got = oracle.jac_to_affine(bbg.msm(srs16, sc[:n]))
+        assert np.array_equal(got, oracle.pippenger(sc[:n], pts[:n])), n
+    got = oracle.jac_to_affine(bbg.msm(srs16, sc[:1000], start=300))  # Pippenger::pippenger_unsafe(scalars, from, range)
+    assert np.array_equal(got, oracle.pippenger(sc[:1000], srs16.read(300, 1000)))
+
+
+def test_msm_golden_from_reference(pkg, oracle, bbg, golden, srs16):
+    """Results recorded from the compiled reference (pippenger_unsafe == pippenger there), incl. n = 2^16 and 2^16+1."""
+    for rec in golden["msm"]:
+        if rec["srs"] != "hashed" or rec["from"] + rec["n"] > (1 << 16):
+            continue
+        if rec.get("scalar_kind") == "mixed":
+            sc = pkg.inputs.mixed_scalars(rec["scalar_seed"], rec["n"], lambda p: oracle.to_mont(0, p))
+        else:
+            sc = pkg.synthetic_scalars(rec["scalar_seed"], rec["n"])
+        got = oracle.jac_to_affine(bbg.msm(srs16, sc, start=rec["from"]))
+        assert np.array_equal(got, unhex(rec["result"], 8)[0]), rec
+    assert sha(srs16.read()) == golden["msm_points_sha256"]["hashed_2^16"]
+
+
+def test_msm_edge_cases(pkg, oracle, bbg, golden, srs16):
+    pts = srs16.read(0, 2048)
+    # pippenger_mul_by_zero (:910-927), pippenger_zero_points (:895-908)
+    zero = np.zeros((100, 4), dtype=np.uint64)
+    assert int(bbg.msm(srs16, zero)[3]) >> 63 == 1
+    assert int(bbg.msm(srs16, zero[:0])[3]) >> 63 == 1
+    # pippenger_one (:862-893)
+    one = oracle.to_mont(0, np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs16, one)), pts[0])
+    # pippenger_short_inputs (:723-774): full / zero / 64-bit / 3-bit scalars
+    mixed = pkg.inputs.mixed_scalars(99, 2048, lambda p: oracle.to_mont(0, p))
+    assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs16, mixed)), oracle.pippenger(mixed, pts))
+    # un-reduced scalar representatives (kate_commitment_scheme.cpp:46-53 hands those in)
+    sc = pkg.synthetic_scalars(5, 64)
+    r = np.array([0x43E1F593F0000001, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029], dtype=np.uint64)
+    unred = sc.copy()
+    carry = np.zeros(64, dtype=np.uint64)
+    for j in range(4):  # unred = sc + r (still < 2^256 since sc < 2^252)
+        t = sc[:, j].astype(object) + int(r[j]) + carry.astype(object)
+        unred[:, j] = np.array([int(x) & 0xFFFFFFFFFFFFFFFF for x in t], dtype=np.uint64)
+        carry = np.array([int(x) >> 64 for x in t], dtype=np.uint64)
+    assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs16, unred)), oracle.pippenger(sc, pts[:64]))
+    # all scalars equal (every term lands in the same buckets)
+    same = np.tile(sc[:1], (2048, 1))
+    assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs16, same)), oracle.pippenger(same, pts))
+    # pippenger_edge_case_dbl (:688-721): all POINTS equal -> every bucket add is a doubling / collision
+    rec = [r_ for r_ in golden["msm"] if r_["srs"] == "all_equal_to_hashed_point_0"][0]
+    eq = bbg.srs_register(np.tile(pts[:1], (rec["n"], 1)))
+    got = oracle.jac_to_affine(bbg.msm(eq, pkg.synthetic_scalars(rec["scalar_seed"], rec["n"])))
+    assert np.array_equal(got, unhex(rec["result"], 8)[0])
+    eq.free()
+    # P and -P with the same scalar cancel to infinity
+    neg = pts[:2].copy()
+    neg[1, :4] = pts[0, :4]
+    neg[1, 4:] = oracle.fe_sub(1, np.zeros((1, 4), dtype=np.uint64), pts[0:1, 4:])[0]
+    s2 = bbg.srs_register(neg)
+    assert int(bbg.msm(s2, np.tile(sc[:1], (2, 1)))[3]) >> 63 == 1
+    s2.free()
+    # linear SRS (bases with linear relations): defined for the safe variant only in the reference
+    rec = [r_ for r_ in golden["msm"] if r_["srs"] == "linear"][0]
+    lin = bbg.srs_synth_linear(rec["a"], rec["s"], rec["n"])
+    got = oracle.jac_to_affine(bbg.msm(lin, pkg.synthetic_scalars(rec["scalar_seed"], rec["n"])))
+    assert np.array_equal(got, unhex(rec["result"], 8)[0])
+    lin.free()
+    with pytest.raises(pkg.BbgError):
+        bbg.msm(srs16, sc, start=(1 << 16) - 10)  # range exceeds the SRS
+
+
+def test_g1_sum_and_normalize(pkg, oracle, bbg, srs16):
+    sc = pkg.synthetic_scalars(21, 300)
+    parts = np.stack([bbg.msm(srs16, sc[i * 100:(i + 1) * 100], start=i * 100) for i in range(3)])
+    whole = oracle.jac_to_affine(bbg.msm(srs16, sc))
+    assert np.array_equal(oracle.jac_to_affine(bbg.g1_sum(parts)), whole)  # sharded by point range == whole (c_bind.cpp:31-46)
+    assert np.array_equal(oracle.g1_sum(parts), whole)
+    norm = bbg.g1_normalize(parts)
+    for i in range(3):
+        assert np.array_equal(norm[i], oracle.jac_to_affine(parts[i]))
+
+
+def test_msm_2_20_golden_and_properties(pkg, oracle, bbg, golden):
+    """BASELINE config 3: n = 2^20.  Bit-exact against the result recorded from the compiled reference
+    (pippenger_unsafe on the same SRS and scalars), plus MSM(-s) = -MSM(s) (oversized_inputs :573-617) and linearity."""
+    n = 1 << 20
+    srs = bbg.srs_synth_hashed(0xBB254, n)
+    assert sha(srs.read()) == golden["msm_points_sha256"]["hashed_2^20"]
+    rec = [r for r in golden["msm"] if r["n"] == n][0]
+    sc = pkg.synthetic_scalars(rec["scalar_seed"], n)
+    res = oracle.jac_to_affine(bbg.msm(srs, sc))
+    assert np.array_equal(res, unhex(rec["result"], 8)[0])
+    neg = oracle.fe_sub(0, np.zeros_like(sc), sc)
+    res_neg = oracle.jac_to_affine(bbg.msm(srs, neg))
+    assert np.array_equal(res_neg[:4], res[:4])
+    assert np.array_equal(res_neg[4:], oracle.fe_sub(1, np.zeros((1, 4), dtype=np.uint64), res[4:])[0])
+    sc2 = pkg.synthetic_scalars(4321, n)
+    r2 = oracle.jac_to_affine(bbg.msm(srs, sc2))
+    rsum = oracle.jac_to_affine(bbg.msm(srs, oracle.fe_add(0, sc, sc2)))
+    assert np.array_equal(oracle.g1_add(res, r2), rsum)
+    # point-range sharding (the multi-GPU decomposition) == whole
+    parts = np.stack([bbg.msm(srs, sc[i * (n // 4):(i + 1) * (n // 4)], start=i * (n // 4)) for i in range(4)])
+    assert np.array_equal(oracle.jac_to_affine(bbg.g1_sum(parts)), res)
+    srs.free()
