@@ -117,4 +117,23 @@ if "time" in stages:
             got = O.jac_to_affine(out.cpu().numpy().view(np.uint64))
             check("msm 2^16 vs oracle", got, O.pippenger(sc, pts))
         srs.free()
+if "tune" in stages:
+    import torch
+    for lg in (20, 22, 24):
+        n = 1 << lg
+        c = inp.synthetic_scalars(lg, n)
+        t = torch.from_numpy(c.view(np.int64)).cuda()
+        for tile, maxr in ((12, 9), (12, 10), (12, 8), (12, 7), (11, 9), (11, 7), (10, 7)):
+            B.set_option("ntt_tile_log", tile)
+            B.set_option("ntt_max_logr", maxr)
+            B.ntt_prepare(lg)
+            B.ntt_device(t.data_ptr(), lg, 0)
+            B.sync()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                B.ntt_device(t.data_ptr(), lg, 0)
+            B.sync()
+            dt = (time.perf_counter() - t0) / reps
+            print(f"ntt 2^{lg} tile={tile} maxr={maxr}: {dt*1e3:.3f} ms  {1.5*n*lg/dt/1e9:.2f} Gfield-op/s", flush=True)
 print("probe done")
