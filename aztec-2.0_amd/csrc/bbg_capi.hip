@@ -120,6 +120,13 @@ void bbg_destroy(bbg_ctx* ctx)
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
+    if (ctx->aux_stream) {
+        (void)hipStreamDestroy(ctx->aux_stream);
+        for (int k = 0; k < 2; k++) {
+            (void)hipEventDestroy(ctx->ev_acc[k]);
+            (void)hipEventDestroy(ctx->ev_done[k]);
+        }
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -128,7 +135,15 @@ int bbg_sync(bbg_ctx* ctx)
 {
     CHECK_CTX(ctx);
     BBG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) BBG_HIP(hipStreamSynchronize(ctx->aux_stream));
     return BBG_OK;
+}
+
+int bbg_join(bbg_ctx* ctx)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return msm_join(ctx, ctx->stream);
 }
 
 int bbg_set_stream(bbg_ctx* ctx, void* hip_stream)
@@ -146,6 +161,12 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     CHECK_CTX(ctx);
     if (!key) { set_error("bbg_set_option: null key"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(key, "msm_async_reduce")) {
+        BBG_HIP(hipDeviceSynchronize());
+        ctx->msm_async_reduce = value != 0;
+        return BBG_OK;
+    }
+    if (!strcmp(key, "msm_debug_idx_mask")) return msm_debug_idx_mask((uint32_t)value);
     if (!strcmp(key, "ntt_tile_log")) {
         if (value < 9 || value > 12) { set_error("ntt_tile_log must be 9..12"); return BBG_E_INVALID; }
         ctx->ntt_tile_log = (int)value;
@@ -371,6 +392,8 @@ int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, si
     char* st = (char*)ctx->staging;
     if (n) BBG_HIP(hipMemcpyAsync(st + 256, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     rc = msm_run(ctx, srs->s, st + 256, from, n, st, ctx->stream);
+    if (rc) return rc;
+    rc = msm_join(ctx, ctx->stream);
     if (rc) return rc;
     BBG_HIP(hipMemcpyAsync(out_jacobian, st, 96, hipMemcpyDeviceToHost, ctx->stream));
     BBG_HIP(hipStreamSynchronize(ctx->stream));

@@ -74,6 +74,12 @@ struct bbg_ctx {
     void* staging = nullptr; // device staging for host-pointer entry points
     size_t staging_bytes = 0;
     bbg::MsmScratch msm;
+    // MSM reduce phase may run on an auxiliary stream so that it overlaps the next MSM's sort / accumulation
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_acc[2] = { nullptr, nullptr }, ev_done[2] = { nullptr, nullptr };
+    bool ev_done_valid[2] = { false, false };
+    unsigned long msm_seq = 0;
+    bool msm_async_reduce = false;
     int ntt_tile_log = 12; // log2(elements per LDS tile)
     int ntt_max_logr = 9;
 };
@@ -114,6 +120,8 @@ int field_op_device(int which, int op, const void* a, const void* b, void* out, 
 int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
             hipStream_t stream);
 int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
+int msm_join(bbg_ctx* ctx, hipStream_t stream);
+int msm_debug_idx_mask(uint32_t mask);
 int srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, void* d_points, hipStream_t stream);
 int g1_sum_device(bbg_ctx* ctx, const void* d_jacs, size_t n, void* d_out, hipStream_t stream);
 } // namespace bbg

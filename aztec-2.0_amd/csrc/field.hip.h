@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mac_chains.hip.h"
+
 namespace bbg {
 
 // ---------------------------------------------------------------- parameters
@@ -177,7 +179,7 @@ template <class P> __device__ __forceinline__ Fe<P> fe_canon(const Fe<P>& a)
         : "+v"(acc), "+v"(c2)                                                                                        \
         : "v"(x), "v"(y)                                                                                             \
         : "vcc")
-template <class P> __device__ __forceinline__ Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b)
+template <class P> __device__ __forceinline__ Fe<P> fe_mul_v1(const Fe<P>& a, const Fe<P>& b)
 {
     uint64_t acc = 0;
     uint32_t c2 = 0;
@@ -204,6 +206,86 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul(const Fe<P>& a, const
         acc = (acc >> 32) | ((uint64_t)c2 << 32);
         c2 = 0;
     }
+    return r;
+}
+
+// ---- column helpers: N products x[i] * y[-i] chained in ONE asm statement (mac_chains.hip.h)
+template <int N> __device__ __forceinline__ void mac_col_v(uint64_t& acc, uint32_t& c2, const uint32_t* x, const uint32_t* y)
+{
+    if constexpr (N == 1) mac1_v(acc, c2, x[0], y[0]);
+    else if constexpr (N == 2) mac2_v(acc, c2, x[0], y[0], x[1], y[-1]);
+    else if constexpr (N == 3) mac3_v(acc, c2, x[0], y[0], x[1], y[-1], x[2], y[-2]);
+    else if constexpr (N == 4) mac4_v(acc, c2, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3]);
+    else if constexpr (N == 5) mac5_v(acc, c2, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4]);
+    else if constexpr (N == 6) mac6_v(acc, c2, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5]);
+    else if constexpr (N == 7) mac7_v(acc, c2, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6]);
+    else if constexpr (N == 8)
+        mac8_v(acc, c2, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6], x[7], y[-7]);
+}
+// same with the second factors = modulus limbs MOD[J], MOD[J-1], ... held in SGPRs
+template <class P, int N, int J> __device__ __forceinline__ void mac_col_mod(uint64_t& acc, uint32_t& c2, const uint32_t* x)
+{
+    if constexpr (N == 1) mac1_s(acc, c2, x[0], P::MOD[J]);
+    else if constexpr (N == 2) mac2_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1]);
+    else if constexpr (N == 3) mac3_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1], x[2], P::MOD[J - 2]);
+    else if constexpr (N == 4) mac4_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1], x[2], P::MOD[J - 2], x[3], P::MOD[J - 3]);
+    else if constexpr (N == 5)
+        mac5_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1], x[2], P::MOD[J - 2], x[3], P::MOD[J - 3], x[4], P::MOD[J - 4]);
+    else if constexpr (N == 6)
+        mac6_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1], x[2], P::MOD[J - 2], x[3], P::MOD[J - 3], x[4], P::MOD[J - 4], x[5],
+               P::MOD[J - 5]);
+    else if constexpr (N == 7)
+        mac7_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1], x[2], P::MOD[J - 2], x[3], P::MOD[J - 3], x[4], P::MOD[J - 4], x[5],
+               P::MOD[J - 5], x[6], P::MOD[J - 6]);
+    else if constexpr (N == 8)
+        mac8_s(acc, c2, x[0], P::MOD[J], x[1], P::MOD[J - 1], x[2], P::MOD[J - 2], x[3], P::MOD[J - 3], x[4], P::MOD[J - 4], x[5],
+               P::MOD[J - 5], x[6], P::MOD[J - 6], x[7], P::MOD[J - 7]);
+}
+template <class P, int K> __device__ __forceinline__ void fips_low_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b,
+                                                                         uint32_t* m)
+{
+    mac_col_v<K + 1>(acc, c2, a, b + K);
+    if constexpr (K > 0) mac_col_mod<P, K, K>(acc, c2, m);
+    m[K] = (uint32_t)acc * P::INV;
+    mac1_s(acc, c2, m[K], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+    c2 = 0;
+}
+template <class P, int K> __device__ __forceinline__ void fips_high_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b,
+                                                                          const uint32_t* m, uint32_t* r)
+{
+    if constexpr (K < 15) {
+        mac_col_v<15 - K>(acc, c2, a + (K - 7), b + 7);
+        mac_col_mod<P, 15 - K, 7>(acc, c2, m + (K - 7));
+    }
+    r[K - 8] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+    c2 = 0;
+}
+// Shipping multiplier: same FIPS schedule as fe_mul_v1, but each column is at most three asm statements and the
+// modulus limbs are SGPR operands.
+template <class P> __device__ __forceinline__ Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b)
+{
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    uint32_t m[8];
+    Fe<P> r;
+    fips_low_column<P, 0>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 1>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 2>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 3>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 4>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 5>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 6>(acc, c2, a.v, b.v, m);
+    fips_low_column<P, 7>(acc, c2, a.v, b.v, m);
+    fips_high_column<P, 8>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 9>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 10>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 11>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 12>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 13>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 14>(acc, c2, a.v, b.v, m, r.v);
+    fips_high_column<P, 15>(acc, c2, a.v, b.v, m, r.v);
     return r;
 }
 

@@ -35,7 +35,6 @@ namespace bbg {
 constexpr int MSM_WINDOWS = 16;     // 16-bit windows over a 254-bit scalar
 constexpr int MSM_C = 16;
 constexpr int MSM_BUCKETS = 1 << 15; // |digit| in [1, 2^15]
-constexpr int MSM_T = 8;             // lanes per bucket in the accumulation kernel
 constexpr int MSM_IDX_BITS = 26;     // point index bits in an entry value (n <= 2^26 per call)
 
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
@@ -218,45 +217,132 @@ __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint3
 }
 
 // ---------------------------------------------------------------------------------- bucket accumulation
-// thread (b, t): sums its 1/T share of bucket b's sorted run.  Values address the window tables:
-// point = table[w * n_srs + idx], negated when bit 31 is set.
-__global__ void __launch_bounds__(256)
-k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-             size_t n_srs, Xyzz* partials)
+// Load-balanced: the sorted entry array (without the key-0 prefix) is cut into segments of MSM_SEG entries, one lane
+// per segment, regardless of bucket boundaries -- every lane does the same number of mixed additions (a per-bucket
+// split leaves a wave waiting for its fullest bucket: ~77 % lane efficiency at Poisson(64)).  A lane walks its
+// segment; the bucket it is in comes from the offsets table (binary search once, then sequential).  Runs are emitted as
+//   head[lane]  : the run containing the segment's first entry (may continue from the previous lane)
+//   tail[lane]  : the run containing the segment's last entry, if different from the head run
+//   buckets[b]  : runs that start and end strictly inside the segment (complete buckets)
+// and k_combine adds head/tail pieces per bucket.  Values address the window tables: point = table[w*n_srs + idx],
+// negated when bit 31 is set.
+constexpr int MSM_SEG = 64;
+constexpr int MSM_LONG_SPAN = 48; // buckets spanning more lanes than this are summed by a whole block
+
+__device__ uint32_t g_debug_idx_mask = 0xffffffffu; // experiments only: confine the gathers to a cache-resident subset
+__device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ table, size_t n_srs, uint32_t v)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = gid / MSM_T + 1; // bucket 1 .. 2^15
-    const uint32_t t = gid % MSM_T;
-    if (b > MSM_BUCKETS) return;
-    const uint32_t s = offsets[b], e = offsets[b + 1];
-    const uint32_t cnt = e - s;
-    const uint32_t lo = s + (uint32_t)(((uint64_t)cnt * t) / MSM_T);
-    const uint32_t hi = s + (uint32_t)(((uint64_t)cnt * (t + 1)) / MSM_T);
-    Xyzz acc = xyzz_inf();
-    if (lo < hi) {
-        uint32_t v = vals[lo];
-        Affine p = aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
-        for (uint32_t q = lo; q < hi; q++) {
-            const uint32_t vc = v;
-            Affine pc = p;
-            if (q + 1 < hi) { // software prefetch of the next gather
-                v = vals[q + 1];
-                p = aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
-            }
-            acc = xyzz_madd(acc, aff_neg_if(pc, (vc >> 31) != 0));
-        }
-    }
-    xyzz_store(partials + (size_t)(b - 1) * MSM_T + t, acc);
+    return aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1) & g_debug_idx_mask));
 }
 
-// bucket[b-1] = sum_t partials[b-1][t]
-__global__ void __launch_bounds__(256) k_bucket_sum(const Xyzz* __restrict__ partials, Xyzz* buckets)
+__global__ void __launch_bounds__(256)
+k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
+             size_t n_srs, uint32_t total, Xyzz* head, Xyzz* tail, Xyzz* buckets)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= MSM_BUCKETS) return;
-    Xyzz acc = xyzz_load(partials + (size_t)b * MSM_T);
-    for (int t = 1; t < MSM_T; t++) acc = xyzz_add(acc, xyzz_load(partials + (size_t)b * MSM_T + t));
-    xyzz_store(buckets + b, acc);
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t base = offsets[1]; // entries with key 0 (zero digits) sort first and are skipped
+    const uint64_t s64 = (uint64_t)base + (uint64_t)lane * MSM_SEG;
+    if (s64 >= total) return;
+    const uint32_t s = (uint32_t)s64;
+    const uint32_t e = (total - s > (uint32_t)MSM_SEG) ? s + MSM_SEG : total;
+    // bucket containing position s: largest b in [1, 2^15] with offsets[b] <= s
+    uint32_t lo = 1, hi = MSM_BUCKETS;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (offsets[mid] <= s) lo = mid;
+        else hi = mid - 1;
+    }
+    uint32_t cur = lo;
+    uint32_t cur_end = offsets[cur + 1];
+    bool first_run = true;
+    Xyzz acc = xyzz_inf();
+    uint32_t v = vals[s];
+    Affine p = load_entry_point(table, n_srs, v);
+    for (uint32_t q = s; q < e; q++) {
+        if (q == cur_end) { // the run of bucket `cur` ended inside this segment
+            if (first_run) xyzz_store(head + lane, acc);
+            else xyzz_store(buckets + (cur - 1), acc);
+            first_run = false;
+            acc = xyzz_inf();
+            do {
+                cur++;
+                cur_end = offsets[cur + 1];
+            } while (cur_end <= q); // skip empty buckets
+        }
+        const uint32_t vc = v;
+        const Affine pc = p;
+        if (q + 1 < e) { // software prefetch of the next gather
+            v = vals[q + 1];
+            p = load_entry_point(table, n_srs, v);
+        }
+        acc = xyzz_madd(acc, aff_neg_if(pc, (vc >> 31) != 0));
+    }
+    if (first_run) xyzz_store(head + lane, acc);
+    else xyzz_store(tail + lane, acc);
+}
+
+// piece of bucket b held by lane l (see k_accumulate): head if the bucket starts at or before the lane's segment start
+__device__ __forceinline__ Xyzz bucket_piece(const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, uint32_t l, uint32_t l0,
+                                             bool starts_at_seg_start)
+{
+    if (l == l0 && !starts_at_seg_start) return xyzz_load(tail + l);
+    return xyzz_load(head + l);
+}
+
+// buckets[b-1] = sum of the pieces of bucket b; complete ("middle") runs were already written by k_accumulate.
+// Buckets spanning more than MSM_LONG_SPAN lanes (skewed scalar distributions) are queued for k_combine_long.
+__global__ void __launch_bounds__(256, 1)
+k_combine(const uint32_t* __restrict__ offsets, uint32_t total, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+          Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (b > MSM_BUCKETS) return;
+    const uint32_t base = offsets[1];
+    const uint32_t sb = offsets[b], eb = offsets[b + 1];
+    if (sb == eb) {
+        xyzz_store(buckets + (b - 1), xyzz_inf());
+        return;
+    }
+    const uint32_t l0 = (sb - base) / MSM_SEG, l1 = (eb - 1 - base) / MSM_SEG;
+    const bool at_start = (sb == base + l0 * MSM_SEG);
+    if (l0 == l1) {
+        uint32_t seg_end = base + (l0 + 1) * MSM_SEG;
+        if (seg_end > total || seg_end < base) seg_end = total;
+        if (at_start) xyzz_store(buckets + (b - 1), xyzz_load(head + l0));
+        else if (eb == seg_end) xyzz_store(buckets + (b - 1), xyzz_load(tail + l0));
+        return; // else: complete run, already stored
+    }
+    if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
+        const uint32_t slot = atomicAdd(long_count, 1u);
+        long_list[slot] = b;
+        return;
+    }
+    Xyzz acc = bucket_piece(head, tail, l0, l0, at_start);
+    for (uint32_t l = l0 + 1; l <= l1; l++) acc = xyzz_add(acc, xyzz_load(head + l));
+    xyzz_store(buckets + (b - 1), acc);
+}
+
+__device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads);
+
+// one block per queued long bucket (grid-stride over the queue)
+__global__ void __launch_bounds__(256, 1)
+k_combine_long(const uint32_t* __restrict__ offsets, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
+               const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list)
+{
+    __shared__ Xyzz sm[128];
+    const uint32_t cnt = *long_count;
+    const uint32_t base = offsets[1];
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        const uint32_t b = long_list[i];
+        const uint32_t sb = offsets[b], eb = offsets[b + 1];
+        const uint32_t l0 = (sb - base) / MSM_SEG, l1 = (eb - 1 - base) / MSM_SEG;
+        const bool at_start = (sb == base + l0 * MSM_SEG);
+        Xyzz acc = xyzz_inf();
+        for (uint32_t l = l0 + threadIdx.x; l <= l1; l += 256) acc = xyzz_add(acc, bucket_piece(head, tail, l, l0, at_start));
+        acc = block_reduce(acc, sm, 256);
+        if (threadIdx.x == 0) xyzz_store(buckets + (b - 1), acc);
+        __syncthreads();
+    }
 }
 
 // LDS tree reduction of one point per thread; result valid in thread 0.
@@ -274,7 +360,7 @@ __device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads)
 
 // weight of bucket index idx (0-based) is idx + 1 = hi*256 + lo + 1.
 // blocks 0..127: Row_hi = sum_lo B[hi][lo] ; blocks 128..383: Col_lo = sum_hi B[hi][lo].
-__global__ void __launch_bounds__(256) k_rowcol(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
+__global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
 {
     __shared__ Xyzz sm[128];
     const int tid = threadIdx.x;
@@ -303,7 +389,7 @@ __device__ Xyzz xyzz_mul_small(const Xyzz& p, uint32_t k)
 
 // one block of 512 threads: threads 0..127 weigh rows by hi, 256..511 weigh columns by lo+1; result =
 // 256 * sum(rows) + sum(cols), optionally added to `accumulate_into`, written as the reference's Jacobian.
-__global__ void __launch_bounds__(512) k_final(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Jacobian* out)
+__global__ void __launch_bounds__(512, 1) k_final(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Jacobian* out)
 {
     __shared__ Xyzz sm[256];
     __shared__ Xyzz rowsum;
@@ -334,7 +420,7 @@ __global__ void __launch_bounds__(512) k_final(const Xyzz* __restrict__ rows, co
 }
 
 // sum of n Jacobian points (g1_sum, reference c_bind.cpp:39-46): one block, serial per thread then tree.
-__global__ void __launch_bounds__(256) k_g1_sum(const Jacobian* __restrict__ pts, size_t n, Jacobian* out)
+__global__ void __launch_bounds__(256, 1) k_g1_sum(const Jacobian* __restrict__ pts, size_t n, Jacobian* out)
 {
     __shared__ Xyzz sm[128];
     Xyzz acc = xyzz_inf();
@@ -375,8 +461,10 @@ __global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ 
 
 // ---------------------------------------------------------------------------------- host side
 struct MsmLayout {
-    size_t entries;
-    size_t off_keys0, off_keys1, off_vals0, off_vals1, off_offsets, off_partials, off_buckets, off_rows, off_cols, off_sort;
+    size_t entries, lanes;
+    size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort;
+    // reduce-phase working set, double buffered so that the reduce of MSM i (aux stream) overlaps MSM i+1
+    size_t off_offsets[2], off_head[2], off_tail[2], off_buckets[2], off_rows[2], off_cols[2], off_long[2];
     size_t sort_bytes;
     size_t total;
 };
@@ -385,6 +473,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static int msm_layout(size_t n, MsmLayout& L)
 {
     L.entries = n * MSM_WINDOWS;
+    L.lanes = (L.entries + MSM_SEG - 1) / MSM_SEG;
     size_t tmp = 0;
     rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C);
@@ -396,12 +485,16 @@ static int msm_layout(size_t n, MsmLayout& L)
     L.off_keys1 = take(L.entries * 4);
     L.off_vals0 = take(L.entries * 4);
     L.off_vals1 = take(L.entries * 4);
-    L.off_offsets = take((MSM_BUCKETS + 2) * 4);
-    L.off_partials = take((size_t)MSM_BUCKETS * MSM_T * sizeof(Xyzz));
-    L.off_buckets = take((size_t)MSM_BUCKETS * sizeof(Xyzz));
-    L.off_rows = take(128 * sizeof(Xyzz));
-    L.off_cols = take(256 * sizeof(Xyzz));
     L.off_sort = take(L.sort_bytes);
+    for (int k = 0; k < 2; k++) {
+        L.off_offsets[k] = take((MSM_BUCKETS + 2) * 4);
+        L.off_head[k] = take(L.lanes * sizeof(Xyzz));
+        L.off_tail[k] = take(L.lanes * sizeof(Xyzz));
+        L.off_buckets[k] = take((size_t)MSM_BUCKETS * sizeof(Xyzz));
+        L.off_rows[k] = take(128 * sizeof(Xyzz));
+        L.off_cols[k] = take(256 * sizeof(Xyzz));
+        L.off_long[k] = take((MSM_BUCKETS + 1) * 4);
+    }
     L.total = o;
     return BBG_OK;
 }
@@ -455,17 +548,32 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     if (rc) return rc;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
+    if (!ctx->aux_stream) {
+        BBG_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            BBG_HIP(hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming));
+            BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
+        }
+    }
+    const int slot = (int)(ctx->msm_seq++ & 1);
     char* base = (char*)ctx->msm.buf;
     uint32_t* keys0 = (uint32_t*)(base + L.off_keys0);
     uint32_t* keys1 = (uint32_t*)(base + L.off_keys1);
     uint32_t* vals0 = (uint32_t*)(base + L.off_vals0);
     uint32_t* vals1 = (uint32_t*)(base + L.off_vals1);
-    uint32_t* offsets = (uint32_t*)(base + L.off_offsets);
-    Xyzz* partials = (Xyzz*)(base + L.off_partials);
-    Xyzz* buckets = (Xyzz*)(base + L.off_buckets);
-    Xyzz* rows = (Xyzz*)(base + L.off_rows);
-    Xyzz* cols = (Xyzz*)(base + L.off_cols);
+    uint32_t* offsets = (uint32_t*)(base + L.off_offsets[slot]);
+    Xyzz* head = (Xyzz*)(base + L.off_head[slot]);
+    Xyzz* tail = (Xyzz*)(base + L.off_tail[slot]);
+    Xyzz* buckets = (Xyzz*)(base + L.off_buckets[slot]);
+    Xyzz* rows = (Xyzz*)(base + L.off_rows[slot]);
+    Xyzz* cols = (Xyzz*)(base + L.off_cols[slot]);
+    uint32_t* long_count = (uint32_t*)(base + L.off_long[slot]);
+    uint32_t* long_list = long_count + 1;
+    const bool overlap = ctx->msm_async_reduce;
+    hipStream_t rst = overlap ? ctx->aux_stream : st; // stream of the reduce phase
 
+    // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM two calls ago
+    if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[slot], 0));
     {
         ProfScope ps(ctx, "msm_recode", st);
         hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
@@ -485,16 +593,40 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     }
     {
         ProfScope ps(ctx, "msm_accumulate", st);
-        hipLaunchKernelGGL(k_accumulate, dim3(grid_for((size_t)MSM_BUCKETS * MSM_T, 256)), dim3(256), 0, st, svals, offsets,
-                           (const Affine*)srs.points, srs.n, partials);
+        BBG_HIP(hipMemsetAsync(long_count, 0, 4, st));
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, (const Affine*)srs.points,
+                           srs.n, (uint32_t)L.entries, head, tail, buckets);
+    }
+    if (overlap) {
+        BBG_HIP(hipEventRecord(ctx->ev_acc[slot], st));
+        BBG_HIP(hipStreamWaitEvent(rst, ctx->ev_acc[slot], 0));
     }
     {
-        ProfScope ps(ctx, "msm_reduce", st);
-        hipLaunchKernelGGL(k_bucket_sum, dim3(grid_for(MSM_BUCKETS, 256)), dim3(256), 0, st, partials, buckets);
-        hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, st, buckets, rows, cols);
-        hipLaunchKernelGGL(k_final, dim3(1), dim3(512), 0, st, rows, cols, (Jacobian*)d_out_jac);
+        ProfScope ps(ctx, "msm_reduce", rst);
+        hipLaunchKernelGGL(k_combine, dim3(grid_for(MSM_BUCKETS, 256)), dim3(256), 0, rst, offsets, (uint32_t)L.entries, head, tail,
+                           buckets, long_count, long_list);
+        hipLaunchKernelGGL(k_combine_long, dim3(256), dim3(256), 0, rst, offsets, head, tail, buckets, long_count, long_list);
+        hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, rst, buckets, rows, cols);
+        hipLaunchKernelGGL(k_final, dim3(1), dim3(512), 0, rst, rows, cols, (Jacobian*)d_out_jac);
+    }
+    if (overlap) {
+        BBG_HIP(hipEventRecord(ctx->ev_done[slot], rst));
+        ctx->ev_done_valid[slot] = true;
     }
     BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+// makes the context stream wait for every reduce phase queued on the auxiliary stream (no host sync)
+int msm_debug_idx_mask(uint32_t mask)
+{
+    BBG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_debug_idx_mask), &mask, 4));
+    return BBG_OK;
+}
+int msm_join(bbg_ctx* ctx, hipStream_t st)
+{
+    for (int k = 0; k < 2; k++)
+        if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
     return BBG_OK;
 }
 

@@ -51,5 +51,6 @@ def msm_sharded_async(bbg, srs_local, d_scalars_ptr, n_local, d_partial, d_gathe
     d_gathered int64[world*12], d_result int64[12] are torch CUDA tensors; bbg must run on torch's current stream
     (bbg.set_stream) so that the RCCL all-gather is ordered after the MSM kernels and before the group sum."""
     bbg.msm_device(srs_local, d_scalars_ptr, n_local, d_partial.data_ptr())
+    bbg.join()  # the reduce phase may run on the auxiliary stream: order the all-gather after it (device-side wait)
     dist.all_gather_into_tensor(d_gathered, d_partial)
     bbg.g1_sum_device(d_gathered.data_ptr(), dist.get_world_size(), d_result.data_ptr())

@@ -68,6 +68,7 @@ def main():
     n = 1 << lg
     bbg = pkg.Bbg(local_rank)
     bbg.set_stream(torch.cuda.current_stream().cuda_stream)
+    bbg.set_option("msm_async_reduce", 1)  # bucket reduction of MSM i overlaps sort/accumulate of step i+1
 
     # ---- setup (untimed): SRS shard resident in HBM, scalars / coefficients resident, twiddles built
     start = rank * n  # weak scaling: every rank owns n points of a world*n-point SRS

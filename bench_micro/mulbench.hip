@@ -47,6 +47,7 @@ template <int V> __global__ void __launch_bounds__(256) mul_kernel(uint32_t* out
         if (V == 0) { x = fe_mul_cios(x, y); y = fe_mul_cios(y, x); }
         if (V == 1) { x = fe_mul(x, y); y = fe_mul(y, x); }
         if (V == 2) { x = fe_add(x, y); y = fe_sub(y, x); }
+        if (V == 4) { x = fe_mul_v1(x, y); y = fe_mul_v1(y, x); }
         if (V == 3) { // butterfly-shaped: 1 mul + add + sub
             Fr t = fe_mul(x, y);
             Fr s = fe_add(x, t);
@@ -93,11 +94,11 @@ int main()
         printf("raw %-18s %8.3f ms  %8.2f Gop/s  (%.2f lanes/clk/CU @2.4GHz)\n", names[OP], t * 1e3, ops / t / 1e9, ops / t / 2.4e9 / 256); }
     RAW(0) RAW(1) RAW(2) RAW(3) RAW(4) RAW(5) RAW(6)
 
-    const char* mnames[] = { "fe_mul CIOS (C++)", "fe_mul FIPS (asm mad+addc)", "add+sub", "butterfly mul+add+sub" };
-    double per[] = { 2, 2, 2, 1 };
+    const char* mnames[] = { "fe_mul CIOS (C++)", "fe_mul FIPS column-asm (shipping)", "add+sub", "butterfly mul+add+sub", "fe_mul FIPS v1 (asm per product)" };
+    double per[] = { 2, 2, 2, 1, 2 };
 #define MUL(V) { double t = time_it([&] { mul_kernel<V><<<blocks, threads>>>(out, in); }); \
         double cnt = (double)n * (ITERS / 4) * per[V]; \
         printf("%-28s %8.3f ms  %8.2f Gop/s\n", mnames[V], t * 1e3, cnt / t / 1e9); }
-    MUL(0) MUL(1) MUL(2) MUL(3)
+    MUL(0) MUL(1) MUL(2) MUL(3) MUL(4)
     return 0;
 }

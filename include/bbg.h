@@ -45,6 +45,11 @@ void bbg_destroy(bbg_ctx* ctx);
 const char* bbg_last_error(void);
 /* Blocks until everything queued on the context's stream has finished. */
 int bbg_sync(bbg_ctx* ctx);
+/* With the option "msm_async_reduce" = 1 the last phase of bbg_msm_device (bucket reduction) is queued on an auxiliary
+ * stream so that it overlaps the next call's sort / accumulation (the prover issues several independent MSMs per round,
+ * prover.cpp:66-73).  The result buffer is then complete after bbg_sync(), or, for stream-ordered consumers, after
+ * bbg_join(): it makes the context stream wait (on the device, no host sync) for all outstanding reductions. */
+int bbg_join(bbg_ctx* ctx);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*; e.g. torch.cuda.current_stream().cuda_stream). */
 int bbg_set_stream(bbg_ctx* ctx, void* hip_stream);
 
@@ -120,7 +125,8 @@ int bbg_dev_upload(bbg_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 
 /* ---- tuning / introspection ---- */
-/* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 6..11). */
+/* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
+ * "msm_async_reduce" (0/1, see bbg_join). */
 int bbg_set_option(bbg_ctx* ctx, const char* key, long value);
 /* Per-kernel timing with HIP events recorded on the launch stream.  Names: "msm_recode", "msm_sort", "msm_offsets",
  * "msm_accumulate", "msm_reduce", "ntt_pass".  enable(…, 1) clears previous samples. */

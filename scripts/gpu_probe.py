@@ -117,6 +117,23 @@ if "time" in stages:
             got = O.jac_to_affine(out.cpu().numpy().view(np.uint64))
             check("msm 2^16 vs oracle", got, O.pippenger(sc, pts))
         srs.free()
+if "msmexp" in stages:
+    import torch
+    n = 1 << 20
+    srs = B.srs_synth_hashed(0xBB254, n)
+    sc = inp.synthetic_scalars(1234, n)
+    ts = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    for mask in (0xFFFFFFFF, 0xFFFF, 0xFF):
+        B.set_option("msm_debug_idx_mask", mask)
+        B.msm_device(srs, ts.data_ptr(), n, out.data_ptr()); B.sync()
+        B.profile_enable(True)
+        for _ in range(5):
+            B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+        B.sync()
+        print(f"idx mask {mask:#x}:", {k: round(B.profile_get(k)[0] / 5, 4) for k in ("msm_recode", "msm_sort", "msm_offsets", "msm_accumulate", "msm_reduce")}, flush=True)
+        B.profile_enable(False)
+    B.set_option("msm_debug_idx_mask", 0xFFFFFFFF)
 if "tune" in stages:
     import torch
     for lg in (20, 22, 24):
