@@ -80,8 +80,8 @@ struct bbg_ctx {
     bool ev_done_valid[2] = { false, false };
     unsigned long msm_seq = 0;
     bool msm_async_reduce = false;
-    int ntt_tile_log = 12; // log2(elements per LDS tile)
-    int ntt_max_logr = 9;
+    int ntt_tile_log = 10; // log2(elements per LDS tile); 10/7 measured best on MI355X (profiles/r01_ntt_plan_sweep.txt)
+    int ntt_max_logr = 7;
 };
 
 struct bbg_srs {

@@ -78,8 +78,8 @@ def test_ntt_pass_plans(pkg, oracle, bbg, tile, maxr):
             assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), (tile, maxr, lg)
             assert np.array_equal(oracle.canon(0, bbg.ntt(c, COSET_IFFT)), oracle.ntt(c, 3)), (tile, maxr, lg)
     finally:
-        bbg.set_option("ntt_tile_log", 12)
-        bbg.set_option("ntt_max_logr", 9)
+        bbg.set_option("ntt_tile_log", 10)
+        bbg.set_option("ntt_max_logr", 7)
 
 
 def test_fft_matches_horner(pkg, oracle, bbg):
