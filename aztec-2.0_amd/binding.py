@@ -55,6 +55,7 @@ def load_library():
         "bbg_last_error": (ctypes.c_char_p, []),
         "bbg_sync": (cint, [vp]),
         "bbg_join": (cint, [vp]),
+        "bbg_join_lag": (cint, [vp, cint]),
         "bbg_set_stream": (cint, [vp, vp]),
         "bbg_srs_register": (cint, [vp, vp, sz, sz, ctypes.POINTER(vp)]),
         "bbg_srs_register_device": (cint, [vp, vp, sz, ctypes.POINTER(vp)]),
@@ -92,7 +93,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_set_stream", "bbg_srs_register",
+    "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
     "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_dev_alloc", "bbg_dev_free",
@@ -155,8 +156,8 @@ class Bbg:
     def sync(self):
         self._ck(self.lib.bbg_sync(self.ctx))
 
-    def join(self):
-        self._ck(self.lib.bbg_join(self.ctx))
+    def join(self, lag=0):
+        self._ck(self.lib.bbg_join_lag(self.ctx, lag) if lag else self.lib.bbg_join(self.ctx))
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.bbg_set_stream(self.ctx, ctypes.c_void_p(stream_ptr)))

@@ -146,6 +146,17 @@ int bbg_join(bbg_ctx* ctx)
     return msm_join(ctx, ctx->stream);
 }
 
+int bbg_join_lag(bbg_ctx* ctx, int lag)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (lag <= 0) return msm_join(ctx, ctx->stream);
+    if (lag > 1) return BBG_OK; // only two reductions can be outstanding: nothing older to wait for
+    const int older = (int)(ctx->msm_seq & 1); // slot of the MSM before the most recent one
+    if (ctx->ev_done_valid[older]) BBG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_done[older], 0));
+    return BBG_OK;
+}
+
 int bbg_set_stream(bbg_ctx* ctx, void* hip_stream)
 {
     CHECK_CTX(ctx);

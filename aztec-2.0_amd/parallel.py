@@ -46,6 +46,57 @@ def msm_sharded(bbg, srs_local, d_scalars_ptr, n_local, d_out_tensor, dist):
     return bbg.g1_sum(parts)
 
 
+class BbgOps:
+    """Adapter: the three device operations the sharded pipeline needs, on torch CUDA tensors."""
+
+    def __init__(self, bbg, srs):
+        self.bbg, self.srs = bbg, srs
+
+    def msm(self, d_scalars, n, d_out):
+        self.bbg.msm_device(self.srs, d_scalars.data_ptr(), n, d_out.data_ptr())
+
+    def join(self, lag):
+        self.bbg.join(lag)
+
+    def g1_sum(self, d_jacobians, count, d_out):
+        self.bbg.g1_sum_device(d_jacobians.data_ptr(), count, d_out.data_ptr())
+
+
+class ShardedMsmPipeline:
+    """One global MSM per submit(), sharded by point range over the ranks of `dist`, software-pipelined by one call:
+    while rank-local MSM i is still in its bucket-reduction phase (auxiliary stream), the 96-byte partials of MSM i-1
+    are all-gathered (RCCL) and summed.  flush() completes the last one.  Everything is stream-ordered; nothing
+    returns to the host.  results[i & 1] holds global result i after the corresponding finish step."""
+
+    def __init__(self, ops, dist, new_tensor):
+        self.ops, self.dist = ops, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.partial = [new_tensor(12), new_tensor(12)]
+        self.gathered = new_tensor(12 * self.world)
+        self.results = [new_tensor(12), new_tensor(12)]
+        self.count = 0
+
+    def _finish(self, j, lag):
+        self.ops.join(lag)  # device-side wait for the reduction of MSM j (not for the one issued after it)
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.gathered, self.partial[j & 1])
+            self.ops.g1_sum(self.gathered, self.world, self.results[j & 1])
+        else:
+            self.results[j & 1].copy_(self.partial[j & 1])
+
+    def submit(self, d_scalars, n):
+        i = self.count
+        self.ops.msm(d_scalars, n, self.partial[i & 1])
+        if i >= 1:
+            self._finish(i - 1, 1)
+        self.count += 1
+
+    def flush(self):
+        if self.count >= 1:
+            self._finish(self.count - 1, 0)
+        return self.results[(self.count - 1) & 1] if self.count else None
+
+
 def msm_sharded_async(bbg, srs_local, d_scalars_ptr, n_local, d_partial, d_gathered, d_result, dist):
     """Stream-ordered variant used in the timed loop of bench.py: nothing leaves the GPU.  d_partial int64[12],
     d_gathered int64[world*12], d_result int64[12] are torch CUDA tensors; bbg must run on torch's current stream

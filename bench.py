@@ -54,10 +54,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("BBG_FORCE_DIST") == "1"  # exercise the RCCL + pipeline code path with a world of 1
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
@@ -78,19 +80,24 @@ def main():
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
     d_coeffs = torch.from_numpy(coeffs.view(np.int64)).to(dev)
     d_coeffs_work = d_coeffs.clone()
-    d_partial = torch.zeros(12, dtype=torch.int64, device=dev)
-    d_gathered = torch.zeros(12 * world, dtype=torch.int64, device=dev)
     d_result = torch.zeros(12, dtype=torch.int64, device=dev)
     bbg.ntt_prepare(lg)
 
+    # N > 1: one world*n-point MSM per step, sharded by point range; the all-gather + group sum of step i-1 is issued
+    # while step i's local MSM is still reducing (parallel.ShardedMsmPipeline); flush() inside the timed region
+    # completes the last one, so exactly K global MSMs are finished when the clock stops.
+    pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev)) if dist is not None else None
+
     def step():
-        if world > 1:
-            par.msm_sharded_async(bbg, srs, d_scalars.data_ptr(), n, d_partial, d_gathered, d_result, dist)
+        if pipe is not None:
+            pipe.submit(d_scalars, n)
         else:
             bbg.msm_device(srs, d_scalars.data_ptr(), n, d_result.data_ptr())
         bbg.ntt_device(d_coeffs_work.data_ptr(), lg, 0)
 
     def fence():
+        if pipe is not None:
+            pipe.flush()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -98,6 +105,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if pipe is not None:
+        pipe.count = 0
     bbg.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -155,6 +164,8 @@ def main():
         "roofline": roofline, "extra": extra,
     }
 
+    if pipe is not None:
+        d_result = pipe.results[(pipe.count - 1) & 1]
     # ---- CPU baseline + bit-exact check against it (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, value)

@@ -50,6 +50,9 @@ int bbg_sync(bbg_ctx* ctx);
  * prover.cpp:66-73).  The result buffer is then complete after bbg_sync(), or, for stream-ordered consumers, after
  * bbg_join(): it makes the context stream wait (on the device, no host sync) for all outstanding reductions. */
 int bbg_join(bbg_ctx* ctx);
+/* Like bbg_join but leaves the `lag` most recent reductions outstanding (lag = 1: wait for everything except the
+ * MSM issued last) -- lets a caller consume result i-1 while MSM i is still reducing. */
+int bbg_join_lag(bbg_ctx* ctx, int lag);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*; e.g. torch.cuda.current_stream().cuda_stream). */
 int bbg_set_stream(bbg_ctx* ctx, void* hip_stream);
 

@@ -37,6 +37,30 @@ whole = O.pippenger(sc, pts)
 assert np.array_equal(total, whole), "sharded MSM != whole MSM"
 covered = sum(par.shard_range(n, r, world)[1] for r in range(world))
 assert covered == n
+
+# the software-pipelined sharded MSM used by bench.py, with the device operations emulated by the oracle
+import torch
+def to_jac(aff):
+    return np.concatenate([aff, one]) if (int(aff[3]) >> 63) == 0 else np.concatenate([aff, np.zeros(4, dtype=np.uint64)])
+class CpuOps:
+    def msm(self, scal, cnt, out):
+        s_np = scal.numpy().view(np.uint64).reshape(-1, 4)
+        out.copy_(torch.from_numpy(to_jac(O.pippenger(s_np[:cnt], pts[start:start + cnt])).view(np.int64).copy()))
+    def join(self, lag):
+        pass
+    def g1_sum(self, gathered, cnt, out):
+        g = gathered.numpy().view(np.uint64).reshape(cnt, 12)
+        out.copy_(torch.from_numpy(to_jac(O.g1_sum(g)).view(np.int64).copy()))
+pipe = par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64))
+batches = [pkg.synthetic_scalars(100 + b, n) for b in range(3)]
+got = []
+for b in range(3):
+    pipe.submit(torch.from_numpy(batches[b][start:start + count].view(np.int64).copy()), count)
+    if b >= 1:
+        got.append(pipe.results[(b - 1) & 1].numpy().view(np.uint64).copy())
+got.append(pipe.flush().numpy().view(np.uint64).copy())
+for b in range(3):
+    assert np.array_equal(O.jac_to_affine(got[b]), O.pippenger(batches[b], pts)), ("pipeline", b)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

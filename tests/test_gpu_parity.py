@@ -335,3 +335,24 @@ def test_shim_reference_api_on_gpu():
     r = subprocess.run([exe, "14"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and "shim_check PASS" in out, out
+
+
+def test_bench_contract_and_dist_path():
+    """bench.py prints one JSON line with the contract's fields; BBG_FORCE_DIST=1 drives the RCCL all-gather +
+    software-pipelined sharded-MSM path (world of 1) and the result must still be bit-exact against the CPU reference."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "16"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["cpu_baseline"]["gpu_bit_exact_vs_cpu"] is True
+    assert out["roofline"]["frac"] > 0 and out["value"] > 0
