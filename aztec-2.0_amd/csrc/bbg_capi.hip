@@ -181,6 +181,12 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     if (!strcmp(key, "ntt_tile_log")) {
         if (value < 9 || value > 12) { set_error("ntt_tile_log must be 9..12"); return BBG_E_INVALID; }
         ctx->ntt_tile_log = (int)value;
+    } else if (!strcmp(key, "ntt_kernel")) {
+        if (value != 1 && value != 2) { set_error("ntt_kernel must be 1 or 2"); return BBG_E_INVALID; }
+        ctx->ntt_kernel = (int)value;
+    } else if (!strcmp(key, "ntt_max_logr8")) {
+        if (value < 6 || value > 11) { set_error("ntt_max_logr8 must be 6..11"); return BBG_E_INVALID; }
+        ctx->ntt_max_logr8 = (int)value;
     } else if (!strcmp(key, "ntt_max_logr")) {
         if (value < 4 || value > 10) { set_error("ntt_max_logr must be 4..10"); return BBG_E_INVALID; }
         ctx->ntt_max_logr = (int)value;

@@ -29,6 +29,7 @@ constexpr int NTT_MAX_PASSES = 4;
 struct NttDomain {
     unsigned log2n = 0;
     int passes = 0;
+    bool use_pass8 = false; // register-resident radix-8 pass kernel (ntt_pass8.hip.h) vs the radix-2-in-LDS one
     int logR[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
     int logW[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
     void* consts = nullptr;                          // DomainConsts (device)
@@ -82,6 +83,8 @@ struct bbg_ctx {
     bool msm_async_reduce = false;
     int ntt_tile_log = 10; // log2(elements per LDS tile); 10/7 measured best on MI355X (profiles/r01_ntt_plan_sweep.txt)
     int ntt_max_logr = 7;
+    int ntt_kernel = 2;      // 2 = k_ntt_pass8 where applicable (n >= 2^11), 1 = k_ntt_pass only
+    int ntt_max_logr8 = 10;  // max log-radix per pass for k_ntt_pass8
 };
 
 struct bbg_srs {

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "addsub_chains.hip.h"
 #include "mac_chains.hip.h"
 
 namespace bbg {
@@ -32,6 +33,10 @@ struct FrP {
     static constexpr uint32_t R2[8] = { 0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
                                         0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u };
     static constexpr uint32_t INV = 0xefffffffu; // -p^-1 mod 2^32
+    static constexpr uint32_t NEG2P[8] = { 0x1ffffffeu, 0x783c14d8u, 0x0c8d1eddu, 0xaf982f6fu,
+                                           0xfcfd4f45u, 0x8f5f7492u, 0x3d9cbfacu, 0x9f37631au }; // 2^256 - 2p
+    static constexpr uint32_t NEGP[8] = { 0x0fffffffu, 0xbc1e0a6cu, 0x86468f6eu, 0xd7cc17b7u,
+                                          0x7e7ea7a2u, 0x47afba49u, 0x1ece5fd6u, 0xcf9bb18du };  // 2^256 - p
 };
 struct FqP {
     static constexpr uint32_t MOD[8] = { 0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
@@ -43,6 +48,10 @@ struct FqP {
     static constexpr uint32_t R2[8] = { 0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
                                         0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u };
     static constexpr uint32_t INV = 0xe4866389u;
+    static constexpr uint32_t NEG2P[8] = { 0x4f060572u, 0x87bee7d2u, 0x2f1c6ae5u, 0xd0fd2addu,
+                                           0xfcfd4f44u, 0x8f5f7492u, 0x3d9cbfacu, 0x9f37631au };
+    static constexpr uint32_t NEGP[8] = { 0x278302b9u, 0xc3df73e9u, 0x978e3572u, 0x687e956eu,
+                                          0x7e7ea7a2u, 0x47afba49u, 0x1ece5fd6u, 0xcf9bb18du };
 };
 
 // ------------------------------------------------------------------- element
@@ -85,76 +94,42 @@ template <class P> __device__ __forceinline__ uint32_t sub_limbs(uint32_t* r, co
     return (uint32_t)br;
 }
 
+// The four carry-chain primitives are single asm statements (addsub_chains.hip.h): hipcc lowers the portable
+// `uint64_t carry` idiom to ~5 VALU instructions per limb; the native v_add_co / v_addc_co chain is 1 per limb
+// (measured on the NTT pass kernel: 1950 -> see profiles/ for the instruction mix).
+#define BBG_K8(A) A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7]
+
 // coarse add: inputs in [0,2p) -> output in [0,2p)   (field_impl_generic.hpp:196-234)
 template <class P> __device__ __forceinline__ Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b)
 {
-    Fe<P> s, d;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        s.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)s.v[i] - P::MOD2[i] - br;
-        d.v[i] = (uint32_t)x;
-        br = (x >> 32) & 1u;
-    }
-    Fe<P> r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = br ? s.v[i] : d.v[i];
+    Fe<P> r = a;
+    asm_add_coarse<BBG_K8(P::NEG2P)>(r.v, b.v);
     return r;
 }
 
 // coarse sub: inputs in [0,2p) -> output in [0,2p)   (field_impl_generic.hpp:254-271)
 template <class P> __device__ __forceinline__ Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b)
 {
-    Fe<P> d;
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)a.v[i] - b.v[i] - br;
-        d.v[i] = (uint32_t)x;
-        br = (x >> 32) & 1u;
-    }
-    uint32_t mask = 0u - (uint32_t)br;
-    uint64_t c = 0;
-    Fe<P> r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)d.v[i] + (P::MOD2[i] & mask);
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    Fe<P> r = a;
+    asm_sub_coarse<BBG_K8(P::MOD2)>(r.v, b.v);
     return r;
 }
 
 // 2p - a (a in [0,2p]); maps 0 -> 2p which reduce_once() canonicalises (field_impl.hpp:148-157)
 template <class P> __device__ __forceinline__ Fe<P> fe_neg(const Fe<P>& a)
 {
-    Fe<P> r;
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)P::MOD2[i] - a.v[i] - br;
-        r.v[i] = (uint32_t)x;
-        br = (x >> 32) & 1u;
-    }
+    Fe<P> r = a;
+    asm_neg<BBG_K8(P::MOD2)>(r.v);
     return r;
 }
 
 template <class P> __device__ __forceinline__ Fe<P> fe_dbl(const Fe<P>& a) { return fe_add(a, a); }
 
-// one conditional subtraction of p: [0,2p) -> [0,p)   (field_impl.hpp:100-112 reduce_once)
+// one conditional subtraction of p: any 256-bit a -> a - p if a >= p   (field_impl.hpp:100-112 reduce_once)
 template <class P> __device__ __forceinline__ Fe<P> fe_reduce_once(const Fe<P>& a)
 {
-    Fe<P> d, r;
-    uint32_t br = sub_limbs<P>(d.v, a.v, P::MOD);
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
+    Fe<P> r = a;
+    asm_reduce_once<BBG_K8(P::NEGP)>(r.v);
     return r;
 }
 

@@ -334,12 +334,46 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(PassParams p)
     }
 }
 
+} // namespace bbg
+#include "ntt_pass8.hip.h"
+namespace bbg {
+
 // ------------------------------------------------------------------------------------------ host side
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
 static void plan_passes(bbg_ctx* ctx, NttDomain& d)
 {
     const int L = (int)d.log2n;
+    d.use_pass8 = false;
+    if (ctx->ntt_kernel == 2 && L >= P8_TILE_LOG) {
+        // register-resident radix-8 kernel: 2048-element tiles, log-radix 3..11 per pass, balanced split
+        int maxr = ctx->ntt_max_logr8;
+        if (maxr > 11) maxr = 11;
+        if (maxr < 6) maxr = 6;
+        int p = (L + maxr - 1) / maxr;
+        if (p <= NTT_MAX_PASSES) {
+            d.passes = p;
+            int rem = L;
+            bool ok = true;
+            for (int q = 0; q < p; q++) {
+                int r = (rem + (p - q) - 1) / (p - q);
+                d.logR[q] = r;
+                d.logW[q] = P8_TILE_LOG - r;
+                rem -= r;
+                if (r < 3 || r > 11) ok = false;
+            }
+            int logS = L;
+            for (int q = 0; q < p && ok; q++) {
+                logS -= d.logR[q];
+                if (q < p - 1 && d.logW[q] > logS) ok = false;
+                if (q == p - 1 && p > 1 && d.logW[q] > d.logR[0]) ok = false;
+            }
+            if (ok) {
+                d.use_pass8 = true;
+                return;
+            }
+        }
+    }
     const int tile = ctx->ntt_tile_log;
     int maxr = ctx->ntt_max_logr;
     if (maxr > tile) maxr = tile;
@@ -406,7 +440,7 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
             const int logR = d.logR[q];
             logS -= logR;
             // radix twiddles w_R^j = w_n^(j * n/R)
-            const size_t half = (size_t)1 << (logR > 0 ? logR - 1 : 0);
+            const size_t half = (size_t)1 << logR; // w_R^x for x < R (k_ntt_pass uses the first half, k_ntt_pass8 all of it)
             BBG_HIP(hipMalloc(&d.tw_radix[inv][q], half * sizeof(Fr)));
             d.bytes += half * sizeof(Fr);
             hipLaunchKernelGGL(k_twiddle_1d, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix[inv][q], pow2, half,
@@ -462,6 +496,28 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     const int R = 1 << p.logR, W = 1 << p.logW;
     const size_t lds_bytes = ((size_t)2 * W * (R + 1) + R) * 16 + 64;
     const size_t tiles = ((size_t)1 << d.log2n) >> (p.logR + p.logW);
+    if (d.use_pass8) {
+        static bool attr8 = false;
+        if (!attr8) {
+            BBG_HIP(p8_attr<3>()); BBG_HIP(p8_attr<4>()); BBG_HIP(p8_attr<5>()); BBG_HIP(p8_attr<6>()); BBG_HIP(p8_attr<7>());
+            BBG_HIP(p8_attr<8>()); BBG_HIP(p8_attr<9>()); BBG_HIP(p8_attr<10>()); BBG_HIP(p8_attr<11>());
+            attr8 = true;
+        }
+        ProfScope ps(ctx, "ntt_pass", st);
+        switch (p.logR) {
+        case 3: p8_launch<3>(p, tiles, st); break;
+        case 4: p8_launch<4>(p, tiles, st); break;
+        case 5: p8_launch<5>(p, tiles, st); break;
+        case 6: p8_launch<6>(p, tiles, st); break;
+        case 7: p8_launch<7>(p, tiles, st); break;
+        case 8: p8_launch<8>(p, tiles, st); break;
+        case 9: p8_launch<9>(p, tiles, st); break;
+        case 10: p8_launch<10>(p, tiles, st); break;
+        case 11: p8_launch<11>(p, tiles, st); break;
+        default: set_error("ntt: bad pass8 radix"); return BBG_E_INVALID;
+        }
+        return BBG_OK;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         BBG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -58,6 +58,36 @@ template <int V> __global__ void __launch_bounds__(256) mul_kernel(uint32_t* out
     fe_store<FrP>(out + (size_t)tid * 8, fe_add(x, y));
 }
 
+// occupancy probe: same dependent-mul kernel, but dynamic LDS limits resident blocks per CU (1 block = 1 wave per SIMD)
+__global__ void __launch_bounds__(256) occ_kernel(uint32_t* out, const uint32_t* in)
+{
+    extern __shared__ uint32_t lds_dummy[];
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr x = fe_load<FrP>(in + (size_t)tid * 8);
+    Fr y = fe_load<FrP>(in + (size_t)(tid ^ 1) * 8);
+    if (in[0] == 0x12345678u) lds_dummy[threadIdx.x] = 1;
+    for (int it = 0; it < ITERS / 4; it++) { x = fe_mul(x, y); y = fe_mul(y, x); }
+    fe_store<FrP>(out + (size_t)tid * 8, fe_add(x, y));
+}
+// 4 independent chains per thread (ILP) at limited occupancy
+__global__ void __launch_bounds__(256) occ_kernel_ilp4(uint32_t* out, const uint32_t* in)
+{
+    extern __shared__ uint32_t lds_dummy[];
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr x[4], y[4];
+    for (int k = 0; k < 4; k++) { x[k] = fe_load<FrP>(in + (size_t)((tid + k * 64) % (256 * 8 * 256)) * 8); y[k] = fe_load<FrP>(in + (size_t)(((tid ^ 1) + k * 64) % (256 * 8 * 256)) * 8); }
+    if (in[0] == 0x12345678u) lds_dummy[threadIdx.x] = 1;
+    for (int it = 0; it < ITERS / 16; it++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = fe_mul(x[k], y[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) y[k] = fe_mul(y[k], x[k]);
+    }
+    Fr s = fe_add(x[0], y[0]);
+    for (int k = 1; k < 4; k++) s = fe_add(s, fe_add(x[k], y[k]));
+    fe_store<FrP>(out + (size_t)tid * 8, s);
+}
+
 template <class F> double time_it(F launch, int reps = 5)
 {
     hipEvent_t e0, e1;
@@ -100,5 +130,16 @@ int main()
         double cnt = (double)n * (ITERS / 4) * per[V]; \
         printf("%-28s %8.3f ms  %8.2f Gop/s\n", mnames[V], t * 1e3, cnt / t / 1e9); }
     MUL(0) MUL(1) MUL(2) MUL(3) MUL(4)
+    CK(hipFuncSetAttribute((const void*)occ_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)occ_kernel_ilp4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int k : { 1, 2, 3, 4, 5, 8 }) {
+        size_t lds = (160 * 1024) / k - 512;
+        if (k == 8) lds = 16 * 1024;
+        double t = time_it([&] { occ_kernel<<<blocks, threads, lds>>>(out, in); });
+        double cnt = (double)n * (ITERS / 4) * 2;
+        double t4 = time_it([&] { occ_kernel_ilp4<<<blocks, threads, lds>>>(out, in); });
+        double cnt4 = (double)n * (ITERS / 16) * 8;
+        printf("occupancy %d waves/SIMD: 1 chain/thread %8.2f Gmul/s   4 chains/thread %8.2f Gmul/s\n", k, cnt / t / 1e9, cnt4 / t4 / 1e9);
+    }
     return 0;
 }

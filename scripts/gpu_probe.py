@@ -153,4 +153,31 @@ if "tune" in stages:
             B.sync()
             dt = (time.perf_counter() - t0) / reps
             print(f"ntt 2^{lg} tile={tile} maxr={maxr}: {dt*1e3:.3f} ms  {1.5*n*lg/dt/1e9:.2f} Gfield-op/s", flush=True)
+if "nttprof" in stages:
+    import torch
+    for lg in (20, 24):
+        n = 1 << lg
+        t = torch.from_numpy(inp.synthetic_scalars(lg, n).view(np.int64)).cuda()
+        B.ntt_prepare(lg)
+        for _ in range(5):
+            B.ntt_device(t.data_ptr(), lg, 0)
+        B.sync()
+if "tune8" in stages:
+    import torch
+    for lg in (18, 20, 22, 24):
+        n = 1 << lg
+        c = inp.synthetic_scalars(lg, n)
+        t = torch.from_numpy(c.view(np.int64)).cuda()
+        for maxr8 in (7, 8, 9, 10, 11):
+            B.set_option("ntt_max_logr8", maxr8)
+            B.ntt_prepare(lg)
+            B.ntt_device(t.data_ptr(), lg, 0)
+            B.sync()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                B.ntt_device(t.data_ptr(), lg, 0)
+            B.sync()
+            dt = (time.perf_counter() - t0) / reps
+            print(f"ntt8 2^{lg} maxr8={maxr8}: {dt*1e3:.3f} ms  {1.5*n*lg/dt/1e9:.2f} Gfield-op/s", flush=True)
 print("probe done")

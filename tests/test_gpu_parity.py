@@ -82,6 +82,31 @@ def test_ntt_pass_plans(pkg, oracle, bbg, tile, maxr):
         bbg.set_option("ntt_max_logr", 7)
 
 
+@pytest.mark.parametrize("maxr8", [6, 7, 8, 9, 10, 11])
+def test_ntt_pass8_plans(pkg, oracle, bbg, maxr8):
+    """k_ntt_pass8 (register radix-8 steps) under every per-pass radix limit: 1, 2, 3 and 4-pass decompositions with
+    full (3,3,..) and partial (..,2) / (..,1) last steps, column and row flavours."""
+    bbg.set_option("ntt_kernel", 2)
+    bbg.set_option("ntt_max_logr8", maxr8)
+    try:
+        for lg in (11, 12, 13, 14, 16, 17, 19):
+            c = pkg.synthetic_scalars(8000 + lg, 1 << lg)
+            assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), (maxr8, lg)
+            assert np.array_equal(oracle.canon(0, bbg.ntt(c, COSET_IFFT)), oracle.ntt(c, 3)), (maxr8, lg)
+    finally:
+        bbg.set_option("ntt_max_logr8", 10)
+
+
+def test_ntt_kernel_v1_still_matches(pkg, oracle, bbg):
+    bbg.set_option("ntt_kernel", 1)
+    try:
+        for lg in (11, 14, 18):
+            c = pkg.synthetic_scalars(8100 + lg, 1 << lg)
+            assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), lg
+    finally:
+        bbg.set_option("ntt_kernel", 2)
+
+
 def test_fft_matches_horner(pkg, oracle, bbg):
     """fft_with_small_degree (polynomial_arithmetic.test.cpp:45-68) on the GPU transform."""
     n = 16
