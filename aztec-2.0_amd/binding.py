@@ -75,6 +75,10 @@ def load_library():
         "bbg_ntt_prepare": (cint, [vp, ctypes.c_uint]),
         "bbg_coset_fft_split": (cint, [vp, vp, ctypes.c_uint, sz]),
         "bbg_coset_fft_split_device": (cint, [vp, vp, ctypes.c_uint, sz]),
+        "bbg_scale_powers_device": (cint, [vp, vp, sz, vp, vp]),
+        "bbg_fr_root_pow": (cint, [vp, ctypes.c_uint, ctypes.c_uint64, cint, vp]),
+        "bbg_fr_pow": (cint, [vp, vp, ctypes.c_uint64, vp]),
+        "bbg_cross_dft_device": (cint, [vp, vp, vp, ctypes.c_uint, sz, ctypes.c_uint, cint]),
         "bbg_dev_alloc": (cint, [vp, sz, ctypes.POINTER(vp)]),
         "bbg_dev_free": (cint, [vp, vp]),
         "bbg_dev_upload": (cint, [vp, vp, vp, sz]),
@@ -96,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
     "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
-    "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_dev_alloc", "bbg_dev_free",
+    "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
 ]
 
@@ -245,6 +249,28 @@ class Bbg:
         buf[:n] = a
         self._ck(self.lib.bbg_coset_fft_split(self.ctx, buf.ctypes.data, log2n, ext))
         return buf
+
+    # ---- sharded-NTT building blocks
+    def scale_powers_device(self, d_a, count, base, start=None):
+        b = np.ascontiguousarray(base, dtype=np.uint64)
+        s_ = None if start is None else np.ascontiguousarray(start, dtype=np.uint64)
+        self._ck(self.lib.bbg_scale_powers_device(self.ctx, ctypes.c_void_p(d_a), count, None if s_ is None else s_.ctypes.data,
+                                                  b.ctypes.data))
+
+    def fr_root_pow(self, log2n, e, inverse=False):
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.bbg_fr_root_pow(self.ctx, log2n, e, 1 if inverse else 0, out.ctypes.data))
+        return out
+
+    def fr_pow(self, base, e):
+        b = np.ascontiguousarray(base, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.bbg_fr_pow(self.ctx, b.ctypes.data, e, out.ctypes.data))
+        return out
+
+    def cross_dft_device(self, d_in, d_out, log2g, length, log2n, inverse=False):
+        self._ck(self.lib.bbg_cross_dft_device(self.ctx, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), log2g, length, log2n,
+                                               1 if inverse else 0))
 
     # ---- raw device memory (for hosts without torch)
     def dev_alloc(self, nbytes):

@@ -490,6 +490,31 @@ int bbg_ntt(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, int op, size_t gener
     return BBG_OK;
 }
 
+int bbg_scale_powers_device(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_scale_powers(ctx, d_a, count, start, base, ctx->stream);
+}
+int bbg_fr_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t out[4])
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_root_pow(ctx, log2n, e, inverse, out, ctx->stream);
+}
+int bbg_fr_pow(bbg_ctx* ctx, const uint64_t base[4], uint64_t e, uint64_t out[4])
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_fr_pow(ctx, base, e, out, ctx->stream);
+}
+int bbg_cross_dft_device(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_cross_dft(ctx, d_in, d_out, log2G, len, log2n, inverse, ctx->stream);
+}
+
 int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext)
 {
     CHECK_CTX(ctx);

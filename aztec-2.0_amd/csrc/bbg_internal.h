@@ -119,6 +119,10 @@ int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generat
 void ntt_free_domain(NttDomain& d);
 int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n);
+int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base, hipStream_t stream);
+int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t* out, hipStream_t stream);
+int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hipStream_t stream);
+int ntt_cross_dft(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse, hipStream_t stream);
 int field_op_device(int which, int op, const void* a, const void* b, void* out, size_t n, hipStream_t stream);
 int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
             hipStream_t stream);

@@ -659,6 +659,121 @@ int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hi
     return BBG_OK;
 }
 
+// ---------------------------------------------------------------------------------- building blocks of the sharded NTT
+// (aztec-2.0_amd/parallel.py: residue-class decomposition across GPUs)
+
+// out = base^e for a device-resident or staged base; single lane (setup-time helper)
+__global__ void k_fr_pow(Fr* out, const Fr* base, uint64_t e)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fr acc = Fr::one(), b = *base;
+    while (e) {
+        if (e & 1) acc = fe_mul(acc, b);
+        b = fe_sqr(b);
+        e >>= 1;
+    }
+    *out = fe_reduce_once(acc);
+}
+
+// out[t][q] = sum_s w_G^(s*t) in[s][q], s,t < G = 2^LOGG, q < len: the size-G DFT across the chunks received from the G ranks.
+template <int LOGG> __global__ void __launch_bounds__(256) k_cross_dft(const Fr* __restrict__ in, Fr* out, size_t len, const Fr* wtab /* w_G^j, j < G */)
+{
+    constexpr int G = 1 << LOGG;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= len) return;
+    Fr x[G];
+#pragma unroll
+    for (int s = 0; s < G; s++) x[s] = fe_load<FrP>(in + (size_t)s * len + q);
+    // radix-2 DIF in registers, natural order in, bit-reversed out
+#pragma unroll
+    for (int st = LOGG - 1; st >= 0; st--) {
+        const int m = 1 << st;
+#pragma unroll
+        for (int b = 0; b < G / 2; b++) {
+            const int j = b & (m - 1);
+            const int k = ((b >> st) << (st + 1)) + j;
+            const Fr u = fe_add(x[k], x[k + m]);
+            Fr v = fe_sub(x[k], x[k + m]);
+            if (j != 0) v = fe_mul(v, wtab[j << (LOGG - 1 - st)]);
+            x[k] = u;
+            x[k + m] = v;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < G; s++) {
+        const int t = (int)(__brev((uint32_t)s) >> (32 - (LOGG > 0 ? LOGG : 1))) & (G - 1);
+        fe_store<FrP>(out + (size_t)(LOGG > 0 ? t : 0) * len + q, x[s]);
+    }
+}
+
+// a[j] *= start * base^j (j < count); start may be null.  base / start: host limbs (Montgomery).
+int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base, hipStream_t st)
+{
+    if (!d_a || !base) { set_error("bbg_scale_powers: null argument"); return BBG_E_INVALID; }
+    if (count == 0) return BBG_OK;
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, 0, &dp); // the size-1 domain only lends its scratch constants block
+    if (rc) return rc;
+    DomainConsts* dc = (DomainConsts*)dp->consts;
+    BBG_HIP(hipMemcpyAsync(&dc->gk, base, 32, hipMemcpyHostToDevice, st));
+    if (start) BBG_HIP(hipMemcpyAsync(&dc->constant, start, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, (const Fr*)&dc->gk, (const Fr*)nullptr);
+    hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((count + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d_a, dc->pow2_tmp,
+                       start ? (const Fr*)&dc->constant : (const Fr*)nullptr, count);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+// out = w_n^e (forward root of the 2^log2n domain; inverse != 0 -> its inverse), returned to the host
+int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t* out, hipStream_t st)
+{
+    if (log2n > 28 || !out) { set_error("bbg_fr_root_pow: bad argument"); return BBG_E_INVALID; }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    DomainConsts* dc = (DomainConsts*)dp->consts;
+    hipLaunchKernelGGL(k_fr_pow, dim3(1), dim3(64), 0, st, &dc->gk, inverse ? &dc->root_inv : &dc->root, e);
+    BBG_HIP(hipMemcpyAsync(out, &dc->gk, 32, hipMemcpyDeviceToHost, st));
+    BBG_HIP(hipStreamSynchronize(st));
+    return BBG_OK;
+}
+int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hipStream_t st)
+{
+    if (!base || !out) { set_error("bbg_fr_pow: null argument"); return BBG_E_INVALID; }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, 0, &dp);
+    if (rc) return rc;
+    DomainConsts* dc = (DomainConsts*)dp->consts;
+    BBG_HIP(hipMemcpyAsync(&dc->constant, base, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fr_pow, dim3(1), dim3(64), 0, st, &dc->gk, (const Fr*)&dc->constant, e);
+    BBG_HIP(hipMemcpyAsync(out, &dc->gk, 32, hipMemcpyDeviceToHost, st));
+    BBG_HIP(hipStreamSynchronize(st));
+    return BBG_OK;
+}
+
+// out[t*len + q] = sum_s w_G^(s t) in[s*len + q]; w_G = w_n^(n/G) of the 2^log2n domain (inverse: its inverse)
+int ntt_cross_dft(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse, hipStream_t st)
+{
+    if (!d_in || !d_out || log2G > 3 || log2G > log2n || log2n > 28) { set_error("bbg_cross_dft: bad argument (G <= 8)"); return BBG_E_INVALID; }
+    if (len == 0) return BBG_OK;
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    DomainConsts* dc = (DomainConsts*)dp->consts;
+    // w_G^j = w_n^(j * n/G): reuse the twiddle generator into pow2_tmp[0..G)
+    const Fr* pow2 = inverse ? dc->pow2_root_inv : dc->pow2_root;
+    hipLaunchKernelGGL(k_twiddle_1d, dim3(1), dim3(64), 0, st, dc->pow2_tmp, pow2, (size_t)1 << log2G, (uint64_t)(((size_t)1 << log2n) >> log2G));
+    const dim3 grid(grid_for(len, 256)), block(256);
+    switch (log2G) {
+    case 0: hipLaunchKernelGGL(k_cross_dft<0>, grid, block, 0, st, (const Fr*)d_in, (Fr*)d_out, len, (const Fr*)dc->pow2_tmp); break;
+    case 1: hipLaunchKernelGGL(k_cross_dft<1>, grid, block, 0, st, (const Fr*)d_in, (Fr*)d_out, len, (const Fr*)dc->pow2_tmp); break;
+    case 2: hipLaunchKernelGGL(k_cross_dft<2>, grid, block, 0, st, (const Fr*)d_in, (Fr*)d_out, len, (const Fr*)dc->pow2_tmp); break;
+    default: hipLaunchKernelGGL(k_cross_dft<3>, grid, block, 0, st, (const Fr*)d_in, (Fr*)d_out, len, (const Fr*)dc->pow2_tmp); break;
+    }
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n)
 {
     if (log2n > 28) { set_error("bbg_ntt_prepare: log2n > 28"); return BBG_E_INVALID; }

@@ -105,3 +105,76 @@ def msm_sharded_async(bbg, srs_local, d_scalars_ptr, n_local, d_partial, d_gathe
     bbg.join()  # the reduce phase may run on the auxiliary stream: order the all-gather after it (device-side wait)
     dist.all_gather_into_tensor(d_gathered, d_partial)
     bbg.g1_sum_device(d_gathered.data_ptr(), dist.get_world_size(), d_result.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------ NTT sharded across GPUs
+_R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def _mont_limbs(value):
+    """Plain integer -> Montgomery-form Fr as 4 uint64 limbs (host-side constant preparation only)."""
+    v = (value % _R_MOD) * (1 << 256) % _R_MOD
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+class BbgNttOps:
+    """Device operations of the sharded NTT on torch CUDA tensors (int64 views of n x 4 limbs)."""
+
+    def __init__(self, bbg):
+        self.bbg = bbg
+
+    def ntt(self, d_x, log2m, op):
+        self.bbg.ntt_device(d_x.data_ptr(), log2m, op)
+
+    def scale_powers(self, d_x, count, base, start=None):
+        self.bbg.scale_powers_device(d_x.data_ptr(), count, base, start)
+
+    def root_pow(self, log2n, e, inverse):
+        return self.bbg.fr_root_pow(log2n, e, inverse)
+
+    def fr_pow(self, base, e):
+        return self.bbg.fr_pow(base, e)
+
+    def cross_dft(self, d_in, d_out, log2g, length, log2n, inverse):
+        self.bbg.cross_dft_device(d_in.data_ptr(), d_out.data_ptr(), log2g, length, log2n, inverse)
+
+
+def ntt_sharded(ops, dist, x_local, log2n, inverse=False, coset_shift=None, new_like=None):
+    """One size-n = 2^log2n (coset) NTT over G = world ranks (G a power of two <= 8, G^2 | n).
+
+    In : rank g holds the residue class x_local[j] = a[g + G*j], j < m = n/G   (int64 tensor of 4*m words).
+    Out: rank g holds out[t*(m/G) + q'] = A[(g*m/G + q') + m*t], q' < m/G, t < G   (same size).
+
+    Decomposition (the reference's own precedent is the 4-way coset split of work_queue.hpp:166-199):
+      A[q + m t] = sum_g w_G^(g t) * ( w_n^(g q) * NTT_m(x_g)[q] )
+    i.e. a local size-m transform, a twiddle by powers of w_n^g, ONE all-to-all that moves (G-1)/G^2 of the data per
+    rank (RCCL over xGMI on the GPU box), and a size-G DFT across the received chunks.  A coset transform
+    (a_j -> a_j c^j first) scales the local residue class by c^g (c^G)^j.  The inverse transform uses the inverse roots,
+    the local iNTT's 1/m and a final 1/G folded into the twiddle step.
+    """
+    G = dist.get_world_size() if dist is not None else 1
+    g = dist.get_rank() if dist is not None else 0
+    log2g = G.bit_length() - 1
+    if (1 << log2g) != G or G > 8:
+        raise ValueError("world size must be a power of two <= 8")
+    n = 1 << log2n
+    m = n // G
+    if m % G or x_local.numel() != 4 * m:
+        raise ValueError("need G^2 | n and a local slice of n/G elements")
+    log2m = log2n - log2g
+    lenq = m // G
+    if coset_shift is not None:  # a[g + G j] * c^(g + G j)
+        ops.scale_powers(x_local, m, ops.fr_pow(coset_shift, G), ops.fr_pow(coset_shift, g))
+    ops.ntt(x_local, log2m, 1 if inverse else 0)
+    start = None
+    if inverse and G > 1:
+        start = _mont_limbs(pow(G, -1, _R_MOD))
+    if G > 1 or start is not None:
+        ops.scale_powers(x_local, m, ops.root_pow(log2n, g, inverse), start)  # * w_n^(+-g q) [* 1/G]
+    if G == 1:
+        return x_local
+    recv = new_like(x_local) if new_like is not None else x_local.clone()
+    dist.all_to_all_single(recv, x_local)  # chunk s of recv = Z_s[g*lenq : (g+1)*lenq]
+    out = new_like(x_local) if new_like is not None else x_local.clone()
+    ops.cross_dft(recv, out, log2g, lenq, log2n, inverse)
+    return out

@@ -121,6 +121,17 @@ int bbg_ntt_prepare(bbg_ctx* ctx, unsigned log2n);
 int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t ext);
 int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext);
 
+/* ---- building blocks of an NTT sharded across GPUs by residue class (aztec-2.0_amd/parallel.py::ntt_sharded; the
+ *      reference's precedent is the 4-way coset split, work_queue.hpp:166-199, polynomial_arithmetic.cpp:401-456) ---- */
+/* a[j] *= start * base^j, j < count (start may be NULL = 1); base/start Montgomery Fr on the host. */
+int bbg_scale_powers_device(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base);
+/* out = w_n^e for the 2^log2n domain (inverse != 0: w_n^-e); out = base^e. */
+int bbg_fr_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t out[4]);
+int bbg_fr_pow(bbg_ctx* ctx, const uint64_t base[4], uint64_t e, uint64_t out[4]);
+/* out[t*len + q] = sum_{s<G} w_G^(s*t) in[s*len + q], G = 2^log2G <= 8, w_G = w_n^(n/G): the cross-rank DFT after the
+ * all-to-all exchange. */
+int bbg_cross_dft_device(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse);
+
 /* ---- device memory helpers for hosts that do not link HIP (bbmalloc/bbfree analogue, c_bind.cpp:11-15) ---- */
 int bbg_dev_alloc(bbg_ctx* ctx, size_t bytes, void** d_ptr);
 int bbg_dev_free(bbg_ctx* ctx, void* d_ptr);

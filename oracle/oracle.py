@@ -27,7 +27,7 @@ def build(with_ref=True):
 
 def _arr(a, last):
     a = np.ascontiguousarray(a, dtype=np.uint64)
-    if a.ndim == 1:
+    if a.ndim != 2:
         a = a.reshape(-1, last)
     assert a.shape[-1] == last, (a.shape, last)
     return a

@@ -61,6 +61,53 @@ for b in range(3):
 got.append(pipe.flush().numpy().view(np.uint64).copy())
 for b in range(3):
     assert np.array_equal(O.jac_to_affine(got[b]), O.pippenger(batches[b], pts)), ("pipeline", b)
+
+# NTT sharded by residue class with one all-to-all: device ops emulated with the oracle
+class CpuNttOps:
+    def _np(self, t): return t.numpy().view(np.uint64).reshape(-1, 4)
+    def ntt(self, t, log2m, op):
+        a = self._np(t); a[:] = O.ntt(a.copy(), op)
+    def scale_powers(self, t, cnt, base, start=None):
+        a = self._np(t)
+        cur = start if start is not None else O.to_mont(0, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+        for j in range(cnt):
+            a[j] = O.fe_mul(0, a[j], cur)[0]
+            cur = O.fe_mul(0, cur, base)[0]
+    def _pow(self, base, e):
+        acc = O.to_mont(0, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+        b = np.array(base, dtype=np.uint64)
+        while e:
+            if e & 1: acc = O.fe_mul(0, acc, b)[0]
+            b = O.fe_mul(0, b, b)[0]
+            e >>= 1
+        return acc
+    def root_pow(self, log2n, e, inverse):
+        w = O.root_of_unity(log2n)
+        if inverse: w = O.fe_inv(0, w)[0]
+        return self._pow(w, e)
+    def fr_pow(self, base, e): return self._pow(base, e)
+    def cross_dft(self, tin, tout, log2g, length, log2n, inverse):
+        Gn = 1 << log2g
+        a, o = self._np(tin).reshape(Gn, length, 4), self._np(tout).reshape(Gn, length, 4)
+        wG = self.root_pow(log2n, (1 << log2n) // Gn, inverse)
+        for t_ in range(Gn):
+            acc = np.zeros((length, 4), dtype=np.uint64)
+            for s_ in range(Gn):
+                acc = O.fe_add(0, acc, O.fe_mul(0, a[s_], np.tile(self._pow(wG, s_ * t_), (length, 1))))
+            o[t_] = acc
+lg = 8
+nn = 1 << lg
+coeffs = pkg.synthetic_scalars(777, nn)
+five = O.to_mont(0, np.array([[5, 0, 0, 0]], dtype=np.uint64))[0]
+for inverse, shift, op in ((False, None, 0), (True, None, 1), (False, five, 2)):
+    xl = torch.from_numpy(O.canon(0, coeffs)[rank::world].copy().view(np.int64).reshape(-1))
+    res = par.ntt_sharded(CpuNttOps(), dist, xl, lg, inverse=inverse, coset_shift=shift)
+    whole = O.ntt(coeffs, op)
+    mm = nn // world; lenq = mm // world
+    got = O.canon(0, res.numpy().view(np.uint64).reshape(-1, 4)).reshape(world, lenq, 4)
+    for t_ in range(world):
+        for q_ in range(lenq):
+            assert np.array_equal(got[t_, q_], whole[(rank * lenq + q_) + mm * t_]), ("sharded ntt", op, t_, q_)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

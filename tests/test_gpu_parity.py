@@ -381,3 +381,50 @@ def test_bench_contract_and_dist_path():
         assert key in out, key
     assert out["cpu_baseline"]["gpu_bit_exact_vs_cpu"] is True
     assert out["roofline"]["frac"] > 0 and out["value"] > 0
+
+
+@pytest.mark.parametrize("G,lg,inverse,coset", [(2, 12, False, False), (4, 12, False, True), (8, 13, False, False), (8, 12, True, False),
+                                                 (4, 14, True, True)])
+def test_sharded_ntt_device_blocks(pkg, oracle, bbg, G, lg, inverse, coset):
+    """The device building blocks of parallel.ntt_sharded (scale_powers, local NTT, cross-rank DFT) on ONE GPU: the G ranks
+    are emulated one after another and the all-to-all by slicing; the result must equal the oracle's whole transform.
+    (The all-to-all plumbing itself is covered by tests/test_distributed_cpu.py on gloo.)"""
+    import importlib
+    import torch
+    par = importlib.import_module("aztec_amd.parallel")
+    ops = par.BbgNttOps(bbg)
+    n = 1 << lg
+    m, lenq, log2g = n // G, n // G // G, G.bit_length() - 1
+    a = oracle.canon(0, pkg.synthetic_scalars(600 + lg + G, n))
+    five = oracle.to_mont(0, np.array([[5, 0, 0, 0]], dtype=np.uint64))[0]
+    if inverse:
+        want = oracle.ntt(a, 3 if coset else 1)
+    else:
+        want = oracle.ntt(a, 2 if coset else 0)
+    Z = []
+    for g in range(G):
+        x = torch.from_numpy(a[g::G].copy().view(np.int64).reshape(-1)).cuda()
+        if coset and not inverse:
+            ops.scale_powers(x, m, ops.fr_pow(five, G), ops.fr_pow(five, g))
+        ops.ntt(x, lg - log2g, 1 if inverse else 0)
+        start = par._mont_limbs(pow(G, -1, par._R_MOD)) if inverse else None
+        ops.scale_powers(x, m, ops.root_pow(lg, g, inverse), start)
+        Z.append(x)
+    bbg.sync()
+    got = np.zeros((n, 4), dtype=np.uint64)
+    for r in range(G):
+        recv = torch.cat([Z[s][4 * r * lenq: 4 * (r + 1) * lenq] for s in range(G)])
+        out = torch.empty_like(recv)
+        ops.cross_dft(recv, out, log2g, lenq, lg, inverse)
+        bbg.sync()
+        o = out.cpu().numpy().view(np.uint64).reshape(G, lenq, 4)
+        for t in range(G):
+            got[r * lenq + m * t: r * lenq + m * t + lenq] = o[t]
+    got = oracle.canon(0, got)
+    if inverse and coset:  # coset_ifft = ifft then g^-j over the whole domain (polynomial_arithmetic.cpp:480-484)
+        ginv = oracle.fe_inv(0, five)[0]
+        cur = oracle.to_mont(0, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+        for j in range(n):
+            got[j] = oracle.fe_mul(0, got[j], cur)[0]
+            cur = oracle.fe_mul(0, cur, ginv)[0]
+    assert np.array_equal(got, want)
