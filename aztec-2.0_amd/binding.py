@@ -79,6 +79,10 @@ def load_library():
         "bbg_fr_root_pow": (cint, [vp, ctypes.c_uint, ctypes.c_uint64, cint, vp]),
         "bbg_fr_pow": (cint, [vp, vp, ctypes.c_uint64, vp]),
         "bbg_cross_dft_device": (cint, [vp, vp, vp, ctypes.c_uint, sz, ctypes.c_uint, cint]),
+        "bbg_poly_op_device": (cint, [vp, cint, vp, vp, vp, sz]),
+        "bbg_poly_evaluate_device": (cint, [vp, vp, sz, vp, vp]),
+        "bbg_kate_opening_device": (cint, [vp, vp, vp, sz, vp, vp]),
+        "bbg_divide_by_pseudo_vanishing_device": (cint, [vp, vp, ctypes.c_uint, ctypes.c_uint, sz]),
         "bbg_dev_alloc": (cint, [vp, sz, ctypes.POINTER(vp)]),
         "bbg_dev_free": (cint, [vp, vp]),
         "bbg_dev_upload": (cint, [vp, vp, vp, sz]),
@@ -100,7 +104,8 @@ EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
     "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
-    "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_dev_alloc", "bbg_dev_free",
+    "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
+    "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
 ]
 
@@ -271,6 +276,26 @@ class Bbg:
     def cross_dft_device(self, d_in, d_out, log2g, length, log2n, inverse=False):
         self._ck(self.lib.bbg_cross_dft_device(self.ctx, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), log2g, length, log2n,
                                                1 if inverse else 0))
+
+    # ---- polynomial helpers (device pointers)
+    def poly_op_device(self, op, d_a, d_b, d_r, n):
+        self._ck(self.lib.bbg_poly_op_device(self.ctx, op, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_r), n))
+
+    def poly_evaluate_device(self, d_coeffs, n, z):
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.bbg_poly_evaluate_device(self.ctx, ctypes.c_void_p(d_coeffs), n, zz.ctypes.data, out.ctypes.data))
+        return out
+
+    def kate_opening_device(self, d_src, d_dest, n, z):
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.bbg_kate_opening_device(self.ctx, ctypes.c_void_p(d_src), ctypes.c_void_p(d_dest), n, zz.ctypes.data,
+                                                  out.ctypes.data))
+        return out
+
+    def divide_by_pseudo_vanishing_device(self, d_evals, log2_src, log2_target, num_roots_cut=4):
+        self._ck(self.lib.bbg_divide_by_pseudo_vanishing_device(self.ctx, ctypes.c_void_p(d_evals), log2_src, log2_target, num_roots_cut))
 
     # ---- raw device memory (for hosts without torch)
     def dev_alloc(self, nbytes):

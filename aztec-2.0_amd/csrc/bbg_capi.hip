@@ -120,6 +120,7 @@ void bbg_destroy(bbg_ctx* ctx)
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
+    if (ctx->poly_scratch) (void)hipFree(ctx->poly_scratch);
     if (ctx->aux_stream) {
         (void)hipStreamDestroy(ctx->aux_stream);
         for (int k = 0; k < 2; k++) {
@@ -538,6 +539,33 @@ int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t e
     BBG_HIP(hipMemcpyAsync(coeffs, ctx->staging, n * ext * 32, hipMemcpyDeviceToHost, ctx->stream));
     BBG_HIP(hipStreamSynchronize(ctx->stream));
     return BBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ polynomial helpers
+int bbg_poly_op_device(bbg_ctx* ctx, int op, const void* d_a, const void* d_b, void* d_r, size_t n)
+{
+    CHECK_CTX(ctx);
+    if ((!d_a || !d_b || !d_r) && n) { set_error("bbg_poly_op_device: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_binop(op, d_a, d_b, d_r, n, ctx->stream);
+}
+int bbg_poly_evaluate_device(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4])
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_evaluate(ctx, d_coeffs, n, z, out, ctx->stream);
+}
+int bbg_kate_opening_device(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t z[4], uint64_t f_out[4])
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_kate_opening(ctx, d_src, d_dest, n, z, f_out, ctx->stream);
+}
+int bbg_divide_by_pseudo_vanishing_device(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t num_roots_cut)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_divide_pseudo_vanishing(ctx, d_evals, log2_src, log2_target, num_roots_cut, ctx->stream);
 }
 
 int bbg_field_op(bbg_ctx* ctx, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n)

@@ -75,6 +75,8 @@ struct bbg_ctx {
     void* staging = nullptr; // device staging for host-pointer entry points
     size_t staging_bytes = 0;
     bbg::MsmScratch msm;
+    void* poly_scratch = nullptr; // evaluate / kate partial sums, pow tables
+    size_t poly_scratch_bytes = 0;
     // MSM reduce phase may run on an auxiliary stream so that it overlaps the next MSM's sort / accumulation
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_acc[2] = { nullptr, nullptr }, ev_done[2] = { nullptr, nullptr };
@@ -119,6 +121,11 @@ int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generat
 void ntt_free_domain(NttDomain& d);
 int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n);
+int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
+int poly_binop(int op, const void* a, const void* b, void* r, size_t n, hipStream_t st);
+int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* z, uint64_t* out, hipStream_t st);
+int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st);
+int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t roots_cut, hipStream_t st);
 int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base, hipStream_t stream);
 int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t* out, hipStream_t stream);
 int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hipStream_t stream);

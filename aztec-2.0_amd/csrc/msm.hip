@@ -431,7 +431,10 @@ __global__ void __launch_bounds__(256, 1) k_g1_sum(const Jacobian* __restrict__ 
         j.z = fe_load<FqP>(&pts[i].z);
         acc = xyzz_add(acc, xyzz_from_jacobian(j));
     }
-    acc = block_reduce(acc, sm, 256);
+    // tree depth follows the input count: combining the 8 partials of an 8-GPU MSM is 3 levels, not 8
+    int width = 256;
+    while (width > 1 && (size_t)(width >> 1) >= n) width >>= 1;
+    acc = block_reduce(acc, sm, width);
     if (threadIdx.x == 0) {
         Jacobian j = xyzz_to_jacobian(acc);
         fe_store<FqP>(&out->x, j.x);

@@ -23,17 +23,9 @@
 // not HBM bound -- the 64n algorithmic bytes cross HBM p (2..3) times plus one twiddle-table read.
 #include "bbg_internal.h"
 #include "field.hip.h"
+#include "ntt_consts.hip.h"
 
 namespace bbg {
-
-struct DomainConsts {
-    Fr root, root_inv, n_inv, gen, gen_inv;
-    Fr pow2_root[32];     // root^(2^b)
-    Fr pow2_root_inv[32]; // root_inv^(2^b)
-    Fr pow2_tmp[32];      // scratch table for arbitrary bases (generator shift paths)
-    Fr constant;          // staged caller constant (ops 4..7)
-    Fr gk;                // running generator of the split coset FFT
-};
 
 // Primitive 2^28-th root of unity, Montgomery form (reference ecc/curves/bn254/fr.hpp:27-30).
 __device__ __constant__ uint32_t FR_PRIMITIVE_ROOT_28[8] = { 0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u,
@@ -99,18 +91,6 @@ __global__ void k_pow2_table(Fr* pow2, const Fr* base_a, const Fr* base_b)
         pow2[i] = a;
         a = fe_reduce_once(fe_sqr(a));
     }
-}
-
-__device__ __forceinline__ Fr pow_from_table(const Fr* __restrict__ pow2, uint64_t e)
-{
-    Fr acc = Fr::one();
-    int b = 0;
-    while (e) {
-        if (e & 1) acc = fe_mul(acc, pow2[b]);
-        e >>= 1;
-        b++;
-    }
-    return acc;
 }
 
 // out[(i << logS) + lo] = w^(i * lo)   (inter-pass twiddles, canonical so that a < 4p operand bound holds)
@@ -774,6 +754,16 @@ int ntt_cross_dft(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, s
     return BBG_OK;
 }
 
+int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts)
+{
+    if (log2n > 28) { set_error("domain: log2n > 28"); return BBG_E_INVALID; }
+    NttDomain* d = nullptr;
+    int rc = build_domain(ctx, log2n, &d);
+    if (rc) return rc;
+    *consts = d->consts;
+    return BBG_OK;
+}
+
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n)
 {
     if (log2n > 28) { set_error("bbg_ntt_prepare: log2n > 28"); return BBG_E_INVALID; }
@@ -787,6 +777,11 @@ template <class P> __global__ void k_field_op(int op, const Fe<P>* a, const Fe<P
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fe<P> x = fe_load<P>(a + i), y = b ? fe_load<P>(b + i) : Fe<P>::zero(), z;
+    if (op == 6 || op == 7) { // raw: no pre-reduction (inputs promised < 2p): exercises the coarse representation
+        z = op == 6 ? fe_mul(x, y) : fe_mul_cios(x, y);
+        fe_store<P>(out + i, fe_reduce_once(z));
+        return;
+    }
     // inputs may be any 256-bit value: bring into [0,2p) the way the reference assumes its inputs are
     for (int k = 0; k < 5; k++) { // 2^256 < 6p
         x = fe_reduce_once(x);

@@ -1,0 +1,319 @@
+// Polynomial helpers of the prover that sit between the NTTs and the MSMs, on device-resident
+// coefficient arrays.  Reference: barretenberg/src/aztec/polynomials/polynomial_arithmetic.cpp
+//   add / sub / mul                      :486-505   pointwise over a domain                       (HBM-bound: 96 B per element)
+//   evaluate                             :507-538   sum_i c_i z^i (Horner in per-thread slices)
+//   compute_kate_opening_coefficients    :727-750   W(X) = (F(X) - F(z)) / (X - z), returns F(z)
+//   divide_by_pseudo_vanishing_polynomial:628-725   pointwise division by Z*_H on the coset of the target domain
+// All results are the same field elements the reference computes (compared on canonical values).
+#include "bbg_internal.h"
+#include "ntt_consts.hip.h"
+
+namespace bbg {
+
+static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
+
+// ---------------------------------------------------------------------------------------------- pointwise
+template <int OP> __global__ void __launch_bounds__(256) k_poly_binop(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* r, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Fr x = fe_load<FrP>(a + i), y = fe_load<FrP>(b + i);
+        Fr z;
+        if (OP == 0) z = fe_add(x, y);
+        else if (OP == 1) z = fe_sub(x, y);
+        else z = fe_mul(x, y);
+        fe_store<FrP>(r + i, z);
+    }
+}
+int poly_binop(int op, const void* a, const void* b, void* r, size_t n, hipStream_t st)
+{
+    if (op < 0 || op > 2) { set_error("bbg_poly_op: op must be 0 (add), 1 (sub) or 2 (mul)"); return BBG_E_INVALID; }
+    if (n == 0) return BBG_OK;
+    int grid = grid_for(n, 256);
+    if (grid > 256 * 16) grid = 256 * 16; // grid-stride beyond 16 blocks per CU
+    if (op == 0) hipLaunchKernelGGL(k_poly_binop<0>, dim3(grid), dim3(256), 0, st, (const Fr*)a, (const Fr*)b, (Fr*)r, n);
+    else if (op == 1) hipLaunchKernelGGL(k_poly_binop<1>, dim3(grid), dim3(256), 0, st, (const Fr*)a, (const Fr*)b, (Fr*)r, n);
+    else hipLaunchKernelGGL(k_poly_binop<2>, dim3(grid), dim3(256), 0, st, (const Fr*)a, (const Fr*)b, (Fr*)r, n);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- shared pieces
+constexpr int PV_E = 16;     // consecutive coefficients per thread
+constexpr int PV_LOG_E = 4;
+struct PolyScratch {
+    Fr z;          // staged evaluation point
+    Fr pow2z[48];  // z^(2^b)
+    Fr result;     // F(z)
+    Fr tmp[8];
+};
+
+__global__ void k_poly_pow2(PolyScratch* s)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fr a = fe_reduce_once(fe_reduce_once(s->z));
+    for (int i = 0; i < 48; i++) {
+        s->pow2z[i] = a;
+        a = fe_reduce_once(fe_sqr(a));
+    }
+}
+// LDS tree sum of one field element per thread (256 threads); result valid in thread 0
+__device__ Fr block_sum(Fr v, Fr* sm)
+{
+    const int tid = threadIdx.x;
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) sm[tid - stride] = v;
+        __syncthreads();
+        if (tid < stride) v = fe_add(v, sm[tid]);
+        __syncthreads();
+    }
+    return v;
+}
+// S = sum_{e < E} c[i0 + e] z^e  (Horner from the top of the slice; coefficients beyond n count as zero)
+__device__ __forceinline__ Fr slice_horner(const Fr* __restrict__ c, size_t i0, size_t n, const Fr& z)
+{
+    Fr s = Fr::zero();
+#pragma unroll 4
+    for (int e = PV_E - 1; e >= 0; e--) {
+        s = fe_mul(s, z);
+        if (i0 + e < n) s = fe_add(s, fe_load<FrP>(c + i0 + e));
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------- evaluate
+// block partial = sum over the block's 256 slices of S_t * z^(i0_t)
+__global__ void __launch_bounds__(256) k_eval_partial(const Fr* __restrict__ c, size_t n, const PolyScratch* ps, Fr* partials)
+{
+    __shared__ Fr sm[128];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i0 = t * PV_E;
+    Fr s = Fr::zero();
+    if (i0 < n) s = fe_mul(slice_horner(c, i0, n, ps->pow2z[0]), pow_from_table(ps->pow2z, i0));
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_eval_final(const Fr* __restrict__ partials, size_t count, PolyScratch* ps)
+{
+    __shared__ Fr sm[128];
+    Fr s = Fr::zero();
+    for (size_t i = threadIdx.x; i < count; i += 256) s = fe_add(s, partials[i]);
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) ps->result = fe_reduce_once(s);
+}
+
+static int poly_setup(bbg_ctx* ctx, size_t n, const uint64_t* z, PolyScratch** ps, Fr** partials, size_t* nblocks, hipStream_t st)
+{
+    const size_t slices = (n + PV_E - 1) / PV_E;
+    *nblocks = (slices + 255) / 256;
+    const size_t need = sizeof(PolyScratch) + 256 + (*nblocks + 1) * 2 * sizeof(Fr);
+    int rc = ensure_buffer(&ctx->poly_scratch, &ctx->poly_scratch_bytes, need);
+    if (rc) return rc;
+    *ps = (PolyScratch*)ctx->poly_scratch;
+    *partials = (Fr*)((char*)ctx->poly_scratch + ((sizeof(PolyScratch) + 255) / 256) * 256);
+    BBG_HIP(hipMemcpyAsync(&(*ps)->z, z, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(64), 0, st, *ps);
+    return BBG_OK;
+}
+
+int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* z, uint64_t* out, hipStream_t st)
+{
+    if ((!d_coeffs && n) || !z || !out) { set_error("bbg_poly_evaluate: null argument"); return BBG_E_INVALID; }
+    PolyScratch* ps;
+    Fr* partials;
+    size_t nblocks;
+    int rc = poly_setup(ctx, n ? n : 1, z, &ps, &partials, &nblocks, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_coeffs, n, ps, partials);
+    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, partials, nblocks, ps);
+    BBG_HIP(hipMemcpyAsync(out, &ps->result, 32, hipMemcpyDeviceToHost, st));
+    BBG_HIP(hipStreamSynchronize(st));
+    return BBG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Kate opening quotient
+// The reference runs the first-order recurrence dest[i] = (src[i] - dest[i-1]) * (-1/z) from i = 0 (one thread).  The
+// same polynomial W(X) = (F(X) - F(z)) / (X - z) has the closed form  w_i = sum_{j > i} f_j z^(j-i-1)  (synthetic division
+// from the top), which is a suffix scan: T_t = S_t + z^E T_{t+1} over the per-thread slice sums S_t, first inside a
+// block (Hillis-Steele with multipliers z^(E 2^k)), then across blocks; each thread then unrolls its slice downwards.
+__global__ void __launch_bounds__(256) k_kate_block_totals(const Fr* __restrict__ f, size_t n, const PolyScratch* ps, Fr* totals)
+{
+    __shared__ Fr sm[128];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i0 = t * PV_E;
+    Fr s = Fr::zero();
+    if (i0 < n) s = fe_mul(slice_horner(f, i0, n, ps->pow2z[0]), pow_from_table(ps->pow2z, (uint64_t)threadIdx.x * PV_E));
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) totals[blockIdx.x] = s; // suffix evaluation of the block's 4096 coefficients from its first one
+}
+// carry[b] = sum_{u > b} totals[u] z^(4096 (u - b - 1))   (one block, blocks processed from the top in rounds of 256)
+__global__ void __launch_bounds__(256) k_kate_block_scan(const Fr* __restrict__ totals, size_t nblocks, const PolyScratch* ps, Fr* carry)
+{
+    __shared__ Fr sm[256];
+    __shared__ Fr incoming;
+    const int tid = threadIdx.x;
+    if (tid == 0) incoming = Fr::zero();
+    __syncthreads();
+    const size_t rounds = (nblocks + 255) / 256;
+    for (size_t r = rounds; r-- > 0;) {
+        const size_t b = r * 256 + tid;
+        Fr v = b < nblocks ? totals[b] : Fr::zero();
+        // inclusive suffix scan inside the round: G_b = v_b + z^4096 G_{b+1}
+        sm[tid] = v;
+        __syncthreads();
+        for (int k = 0; k < 8; k++) {
+            const int d = 1 << k;
+            Fr add = Fr::zero();
+            if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[12 + k]);
+            __syncthreads();
+            v = fe_add(v, add);
+            sm[tid] = v;
+            __syncthreads();
+        }
+        // plus the carry from the rounds above: z^(4096 (256 - tid)) * incoming
+        const Fr inc = incoming;
+        Fr g = fe_add(v, fe_mul(inc, pow_from_table(ps->pow2z, (uint64_t)(256 - tid) << 12)));
+        // carry INTO block b is the suffix starting at block b+1
+        __syncthreads();
+        sm[tid] = g;
+        __syncthreads();
+        if (b < nblocks) carry[b] = (tid + 1 < 256) ? sm[tid + 1] : inc;
+        __syncthreads();
+        if (tid == 0) incoming = g;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_kate_finish(const Fr* __restrict__ f, Fr* dest, size_t n, const PolyScratch* ps, const Fr* __restrict__ carry)
+{
+    __shared__ Fr sm[256];
+    const int tid = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * 256 + tid;
+    const size_t i0 = t * PV_E;
+    const Fr z = ps->pow2z[0];
+    Fr v = i0 < n ? slice_horner(f, i0, n, z) : Fr::zero();
+    sm[tid] = v;
+    __syncthreads();
+    for (int k = 0; k < 8; k++) { // T_t = S_t + z^E T_{t+1} within the block
+        const int d = 1 << k;
+        Fr add = Fr::zero();
+        if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[PV_LOG_E + k]);
+        __syncthreads();
+        v = fe_add(v, add);
+        sm[tid] = v;
+        __syncthreads();
+    }
+    if (i0 >= n) return;
+    // suffix evaluation starting at the NEXT slice: in-block part + the blocks above
+    Fr T = (tid + 1 < 256) ? sm[tid + 1] : Fr::zero();
+    T = fe_add(T, fe_mul(carry[blockIdx.x], pow_from_table(ps->pow2z, (uint64_t)(255 - tid) * PV_E)));
+    // w_{i0+E-1} = T ; w_{i-1} = f_i + z w_i
+    Fr w = T;
+    for (int e = PV_E - 1; e >= 0; e--) {
+        const size_t i = i0 + e;
+        if (i < n) {
+            fe_store<FrP>(dest + i, fe_reduce_once(w));
+            w = fe_add(fe_mul(w, z), fe_load<FrP>(f + i));
+        }
+    }
+}
+
+int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st)
+{
+    if (!d_src || !d_dest || !z || !f_out || n == 0) { set_error("bbg_kate_opening: bad argument"); return BBG_E_INVALID; }
+    if (d_src == d_dest) { set_error("bbg_kate_opening: src and dest must differ"); return BBG_E_INVALID; }
+    PolyScratch* ps;
+    Fr* partials;
+    size_t nblocks;
+    int rc = poly_setup(ctx, n, z, &ps, &partials, &nblocks, st);
+    if (rc) return rc;
+    Fr* carry = partials + nblocks + 1;
+    // F(z)
+    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, n, ps, partials);
+    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, partials, nblocks, ps);
+    BBG_HIP(hipMemcpyAsync(f_out, &ps->result, 32, hipMemcpyDeviceToHost, st));
+    // W(X)
+    hipLaunchKernelGGL(k_kate_block_totals, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, n, ps, partials);
+    hipLaunchKernelGGL(k_kate_block_scan, dim3(1), dim3(256), 0, st, partials, nblocks, ps, carry);
+    hipLaunchKernelGGL(k_kate_finish, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, (Fr*)d_dest, n, ps, carry);
+    BBG_HIP(hipGetLastError());
+    BBG_HIP(hipStreamSynchronize(st));
+    return BBG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- divide by Z*_H
+constexpr int DPV_MAX_EXT = 16, DPV_MAX_CUT = 8;
+struct DpvConsts {
+    Fr inv_sub[DPV_MAX_EXT]; // 1 / ((g w_ext^j)^n - 1)
+    Fr numer[DPV_MAX_CUT];   // -w_src^-(k+1)
+};
+__device__ Fr fr_inv_fermat(Fr a)
+{
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = FrP::MOD[i];
+    e[0] -= 2;
+    Fr acc = Fr::one();
+    for (int i = 255; i >= 0; i--) {
+        acc = fe_sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
+    }
+    return acc;
+}
+// compute_multiplicative_subgroup (:119-138) + the "- 1", invert, numerator constants (:680-697)
+__global__ void k_dpv_setup(DpvConsts* c, const DomainConsts* src, const DomainConsts* ext_dom, int log2_src, int ext, int cut)
+{
+    const int j = threadIdx.x;
+    if (j < ext) {
+        Fr acc = src->gen; // g^n
+        for (int i = 0; i < log2_src; i++) acc = fe_sqr(acc);
+        // * w_ext^j, w_ext = root of the size-ext domain
+        acc = fe_mul(acc, pow_from_table(ext_dom->pow2_root, (uint64_t)j));
+        acc = fe_sub(acc, Fr::one());
+        c->inv_sub[j] = fe_reduce_once(fr_inv_fermat(acc));
+    }
+    if (j == 0) {
+        Fr k = fe_neg(src->root_inv);
+        for (int i = 0; i < cut; i++) {
+            c->numer[i] = fe_reduce_once(fe_reduce_once(k));
+            k = fe_mul(k, src->root_inv);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_dpv_apply(Fr* evals, size_t n, const DpvConsts* c, const DomainConsts* target, int ext_mask, int cut)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i0 = t * PV_E;
+    if (i0 >= n) return;
+    Fr x = fe_mul(target->gen, pow_from_table(target->pow2_root, i0)); // g * w_T^i
+    const Fr w = target->root;
+    for (int e = 0; e < PV_E && i0 + e < n; e++) {
+        const size_t i = i0 + e;
+        Fr v = fe_mul(fe_load<FrP>(evals + i), c->inv_sub[i & ext_mask]);
+        for (int k = 0; k < cut; k++) v = fe_mul(v, fe_add(x, c->numer[k]));
+        fe_store<FrP>(evals + i, v);
+        x = fe_mul(x, w);
+    }
+}
+int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t roots_cut, hipStream_t st)
+{
+    if (!d_evals || log2_target < log2_src || log2_target > 28 || log2_target - log2_src > 4 || roots_cut > DPV_MAX_CUT) {
+        set_error("bbg_divide_by_pseudo_vanishing: need src <= target <= 2^28, target/src <= 16, roots_cut <= 8");
+        return BBG_E_INVALID;
+    }
+    void *csrc, *ctgt, *cext;
+    int rc = ntt_domain_consts(ctx, log2_src, &csrc);
+    if (!rc) rc = ntt_domain_consts(ctx, log2_target, &ctgt);
+    if (!rc) rc = ntt_domain_consts(ctx, log2_target - log2_src, &cext);
+    if (rc) return rc;
+    rc = ensure_buffer(&ctx->poly_scratch, &ctx->poly_scratch_bytes, sizeof(PolyScratch) + 256 + sizeof(DpvConsts));
+    if (rc) return rc;
+    DpvConsts* dc = (DpvConsts*)((char*)ctx->poly_scratch + ((sizeof(PolyScratch) + 255) / 256) * 256);
+    const int ext = 1 << (log2_target - log2_src);
+    const size_t n = (size_t)1 << log2_target;
+    hipLaunchKernelGGL(k_dpv_setup, dim3(1), dim3(64), 0, st, dc, (const DomainConsts*)csrc, (const DomainConsts*)cext, (int)log2_src, ext, (int)roots_cut);
+    hipLaunchKernelGGL(k_dpv_apply, dim3(grid_for((n + PV_E - 1) / PV_E, 256)), dim3(256), 0, st, (Fr*)d_evals, n, dc, (const DomainConsts*)ctgt, ext - 1,
+                       (int)roots_cut);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+} // namespace bbg

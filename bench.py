@@ -32,6 +32,23 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MAD_PEAK_TOPS = 28.0           # measured v_mad_u64_u32 issue rate, bench_micro/mulbench.hip (profiles/r01_mulbench.txt)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_pmc_v2.txt: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command; KiB per dispatch).  MI355X_MICROARCH.md's gfx950
+    correction (FETCH_SIZE x2) applies to wide coalesced streams; k_accumulate's traffic is 64-byte gathers, for which the
+    counter is uncalibrated, so the raw sum is reported.  None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_v2.txt")
+    try:
+        tot = 0.0
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 4 and f[0].endswith(kernel) and f[-3] in ("FETCH_SIZE", "WRITE_SIZE"):
+                tot += float(f[-1]) * 1024.0
+        return round(tot) if tot else None
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,8 +150,9 @@ def main():
     alg_bytes_msm = 96.0 * n                      # 32-B scalar + 64-B base per term, one launch covers all n terms
     achieved = alg_bytes_msm / (acc_ms * 1e-3) / 1e9
     roofline = {"kernel": "k_accumulate (MSM bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_ms": round(acc_ms, 4),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("k_accumulate"),
+                "traffic_source": "profiles/r01_pmc_v2.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
+                "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
     pass_ms = avg("ntt_pass")
     ntt_alg = 64.0 * n

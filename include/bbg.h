@@ -132,6 +132,19 @@ int bbg_fr_pow(bbg_ctx* ctx, const uint64_t base[4], uint64_t e, uint64_t out[4]
  * all-to-all exchange. */
 int bbg_cross_dft_device(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse);
 
+/* ---- polynomial helpers between the NTTs and the MSMs, on device-resident Montgomery Fr arrays ----
+ * polynomial_arithmetic::add / sub / mul (polynomials/polynomial_arithmetic.cpp:486-505): r[i] = a[i] (op) b[i], op = 0 add,
+ * 1 sub, 2 mul; r may alias a or b. */
+int bbg_poly_op_device(bbg_ctx* ctx, int op, const void* d_a, const void* d_b, void* d_r, size_t n);
+/* polynomial_arithmetic::evaluate (:507-538): out = sum_i coeffs[i] z^i (canonical Montgomery).  Synchronous. */
+int bbg_poly_evaluate_device(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
+/* polynomial_arithmetic::compute_kate_opening_coefficients (:727-750): dest = coefficients of (F(X) - F(z)) / (X - z),
+ * f_out = F(z).  dest must not alias src.  Synchronous. */
+int bbg_kate_opening_device(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t z[4], uint64_t f_out[4]);
+/* polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial (:628-725): in place on the 2^log2_target coset evaluations;
+ * src domain 2^log2_src, num_roots_cut roots cut out of the vanishing polynomial (the reference default is 4). */
+int bbg_divide_by_pseudo_vanishing_device(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t num_roots_cut);
+
 /* ---- device memory helpers for hosts that do not link HIP (bbmalloc/bbfree analogue, c_bind.cpp:11-15) ---- */
 int bbg_dev_alloc(bbg_ctx* ctx, size_t bytes, void** d_ptr);
 int bbg_dev_free(bbg_ctx* ctx, void* d_ptr);

@@ -904,6 +904,65 @@ void oracle_poly_eval(const uint64_t* coeffs, size_t n, const uint64_t* z_mont, 
     memcpy(out, acc.d, 32);
 }
 
+/* r = a (op) b pointwise, op 0 add / 1 sub / 2 mul (polynomial_arithmetic.cpp:486-505) */
+void oracle_poly_binop(int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        fe x, y; memcpy(x.d, a + 4 * i, 32); memcpy(y.d, b + 4 * i, 32);
+        x = fe_canon(&FR, x); y = fe_canon(&FR, y);
+        fe z = op == 0 ? fe_add(&FR, x, y) : op == 1 ? fe_sub(&FR, x, y) : fe_mul(&FR, x, y);
+        memcpy(r + 4 * i, z.d, 32);
+    }
+}
+/* compute_kate_opening_coefficients (polynomial_arithmetic.cpp:727-750), the reference's own recurrence:
+ * f = F(z); dest[0] = (src[0] - f) * (-1/z); dest[i] = (src[i] - dest[i-1]) * (-1/z).  Returns f in f_out. */
+void oracle_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint64_t* z_mont, uint64_t* f_out)
+{
+    fe z; memcpy(z.d, z_mont, 32); z = fe_canon(&FR, z);
+    fe f; oracle_poly_eval(src, n, z_mont, f.d);
+    fe divisor = fe_neg(&FR, fe_inv(&FR, z));
+    fe prev = f;
+    for (size_t i = 0; i < n; i++) {
+        fe c; memcpy(c.d, src + 4 * i, 32); c = fe_canon(&FR, c);
+        prev = fe_mul(&FR, fe_sub(&FR, c, prev), divisor);
+        memcpy(dest + 4 * i, prev.d, 32);
+    }
+    memcpy(f_out, f.d, 32);
+}
+/* divide_by_pseudo_vanishing_polynomial (polynomial_arithmetic.cpp:628-725) with compute_multiplicative_subgroup (:119-138):
+ * evals[i] *= 1/((g w_ext^(i mod ext))^n - 1) * prod_{k < cut} (g w_T^i - w_src^-(k+1)),  n = 2^log2_src, T = 2^log2_target */
+int oracle_divide_by_pseudo_vanishing(uint64_t* evals, unsigned log2_src, unsigned log2_target, size_t cut)
+{
+    if (log2_target < log2_src || log2_target > 28) return -1;
+    unsigned lext = log2_target - log2_src;
+    size_t ext = (size_t)1 << lext, T = (size_t)1 << log2_target;
+    fe* sub = (fe*)malloc(ext * sizeof(fe));
+    fe g = fr_coset_generator();
+    fe acc = g;
+    for (unsigned i = 0; i < log2_src; i++) acc = fe_sqr(&FR, acc);
+    fe subroot = fr_root_of_unity(lext);
+    sub[0] = acc;
+    for (size_t j = 1; j < ext; j++) sub[j] = fe_mul(&FR, sub[j - 1], subroot);
+    for (size_t j = 0; j < ext; j++) sub[j] = fe_inv(&FR, fe_sub(&FR, sub[j], fe_one(&FR)));
+    fe root_inv = fe_inv(&FR, fr_root_of_unity(log2_src));
+    fe* numer = (fe*)malloc((cut ? cut : 1) * sizeof(fe));
+    if (cut) {
+        numer[0] = fe_neg(&FR, root_inv);
+        for (size_t k = 1; k < cut; k++) numer[k] = fe_mul(&FR, numer[k - 1], root_inv);
+    }
+    fe wT = fr_root_of_unity(log2_target);
+    fe work = g;
+    for (size_t i = 0; i < T; i++) {
+        fe v; memcpy(v.d, evals + 4 * i, 32); v = fe_canon(&FR, v);
+        v = fe_mul(&FR, v, sub[i & (ext - 1)]);
+        for (size_t k = 0; k < cut; k++) v = fe_mul(&FR, v, fe_add(&FR, work, numer[k]));
+        memcpy(evals + 4 * i, v.d, 32);
+        work = fe_mul(&FR, work, wT);
+    }
+    free(sub); free(numer);
+    return 0;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

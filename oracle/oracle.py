@@ -57,6 +57,9 @@ class Oracle:
         L.oracle_ntt.argtypes = [vp, cu, cint, sz, vp]; L.oracle_ntt.restype = cint
         L.oracle_coset_fft_split.argtypes = [vp, cu, sz]; L.oracle_coset_fft_split.restype = cint
         L.oracle_num_threads.argtypes = []; L.oracle_num_threads.restype = cint
+        L.oracle_poly_binop.argtypes = [cint, vp, vp, vp, sz]; L.oracle_poly_binop.restype = None
+        L.oracle_kate_opening.argtypes = [vp, vp, sz, vp, vp]; L.oracle_kate_opening.restype = None
+        L.oracle_divide_by_pseudo_vanishing.argtypes = [vp, cu, cu, sz]; L.oracle_divide_by_pseudo_vanishing.restype = cint
 
     # ---- fields (which: 0 Fr, 1 Fq)
     def _bin(self, fn, which, a, b):
@@ -207,6 +210,24 @@ class Oracle:
 
     def num_threads(self): return int(self.lib.oracle_num_threads())
 
+    def poly_binop(self, op, a, b):
+        a, b = _arr(a, 4), _arr(b, 4)
+        r = np.empty_like(a)
+        self.lib.oracle_poly_binop(op, a.ctypes.data, b.ctypes.data, r.ctypes.data, a.shape[0])
+        return r
+
+    def kate_opening(self, src, z):
+        a, z = _arr(src, 4), np.ascontiguousarray(z, dtype=np.uint64)
+        dest, f = np.empty_like(a), np.empty(4, dtype=np.uint64)
+        self.lib.oracle_kate_opening(a.ctypes.data, dest.ctypes.data, a.shape[0], z.ctypes.data, f.ctypes.data)
+        return dest, f
+
+    def divide_by_pseudo_vanishing(self, evals, log2_src, cut=4):
+        a = _arr(evals, 4).copy()
+        rc = self.lib.oracle_divide_by_pseudo_vanishing(a.ctypes.data, log2_src, a.shape[0].bit_length() - 1, cut)
+        assert rc == 0
+        return a
+
 
 def ref_available():
     if not os.path.exists(REF_SO):
@@ -249,6 +270,9 @@ class Ref:
         L.ref_ntt_run.argtypes = [vp, vp, cint, vp]; L.ref_ntt_run.restype = ctypes.c_double
         L.ref_coset_fft_split.argtypes = [vp, cu, sz]
         L.ref_poly_eval.argtypes = [vp, sz, vp, vp]
+        L.ref_poly_binop.argtypes = [cint, vp, vp, vp, cu]
+        L.ref_kate_opening.argtypes = [vp, vp, sz, vp, vp]
+        L.ref_divide_by_pseudo_vanishing.argtypes = [vp, cu, cu, sz]
 
     def num_threads(self): return int(self.lib.ref_num_threads())
 
@@ -399,3 +423,20 @@ class Ref:
         r = np.empty(4, dtype=np.uint64)
         self.lib.ref_poly_eval(a.ctypes.data, a.shape[0], z.ctypes.data, r.ctypes.data)
         return r
+
+    def poly_binop(self, op, a, b):
+        a, b = _arr(a, 4), _arr(b, 4)
+        r = np.empty_like(a)
+        self.lib.ref_poly_binop(op, a.ctypes.data, b.ctypes.data, r.ctypes.data, a.shape[0].bit_length() - 1)
+        return r
+
+    def kate_opening(self, src, z):
+        a, z = _arr(src, 4), np.ascontiguousarray(z, dtype=np.uint64)
+        dest, f = np.empty_like(a), np.empty(4, dtype=np.uint64)
+        self.lib.ref_kate_opening(a.ctypes.data, dest.ctypes.data, a.shape[0], z.ctypes.data, f.ctypes.data)
+        return dest, f
+
+    def divide_by_pseudo_vanishing(self, evals, log2_src, cut=4):
+        a = _arr(evals, 4).copy()
+        self.lib.ref_divide_by_pseudo_vanishing(a.ctypes.data, log2_src, a.shape[0].bit_length() - 1, cut)
+        return a

@@ -293,4 +293,33 @@ void ref_poly_eval(const uint64_t* coeffs, size_t n, const uint64_t* z_mont, uin
     for (size_t i = 0; i < n; i++) a[i] = load<fr>(coeffs + 4 * i);
     store<fr>(out, polynomial_arithmetic::evaluate(a.data(), load<fr>(z_mont), n));
 }
+// pointwise add / sub / mul over a domain (polynomial_arithmetic.cpp:486-505); op 0 add, 1 sub, 2 mul
+void ref_poly_binop(int op, const uint64_t* a, const uint64_t* b, uint64_t* r, unsigned log2n)
+{
+    const size_t n = (size_t)1 << log2n;
+    evaluation_domain d(n);
+    std::vector<fr> x(n), y(n), z(n);
+    for (size_t i = 0; i < n; i++) { x[i] = load<fr>(a + 4 * i); y[i] = load<fr>(b + 4 * i); }
+    if (op == 0) polynomial_arithmetic::add(x.data(), y.data(), z.data(), d);
+    else if (op == 1) polynomial_arithmetic::sub(x.data(), y.data(), z.data(), d);
+    else polynomial_arithmetic::mul(x.data(), y.data(), z.data(), d);
+    for (size_t i = 0; i < n; i++) store<fr>(r + 4 * i, z[i]);
+}
+void ref_kate_opening(const uint64_t* src, uint64_t* dest, size_t n, const uint64_t* z_mont, uint64_t* f_out)
+{
+    std::vector<fr> a(n), w(n);
+    for (size_t i = 0; i < n; i++) a[i] = load<fr>(src + 4 * i);
+    fr f = polynomial_arithmetic::compute_kate_opening_coefficients(a.data(), w.data(), load<fr>(z_mont), n);
+    for (size_t i = 0; i < n; i++) store<fr>(dest + 4 * i, w[i]);
+    store<fr>(f_out, f);
+}
+void ref_divide_by_pseudo_vanishing(uint64_t* evals, unsigned log2_src, unsigned log2_target, size_t cut)
+{
+    const size_t T = (size_t)1 << log2_target;
+    evaluation_domain src((size_t)1 << log2_src), tgt(T);
+    std::vector<fr> a(T);
+    for (size_t i = 0; i < T; i++) a[i] = load<fr>(evals + 4 * i);
+    polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial(a.data(), src, tgt, cut);
+    for (size_t i = 0; i < T; i++) store<fr>(evals + 4 * i, a[i]);
+}
 } // extern "C"

@@ -41,6 +41,23 @@ if "field" in stages:
         check(f"field{which} from_mont", B.field_op(which, 4, a), O.from_mont(which, a))
         check(f"field{which} to_mont", B.field_op(which, 5, a), O.to_mont(which, a))
 
+if "coarse" in stages:
+    P = [np.array([0x43E1F593F0000001, 0x2833E84879B97091, 0xB85045B68181585D, 0x30644E72E131A029], dtype=np.uint64),
+         np.array([0x3C208C16D87CFD47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029], dtype=np.uint64)]
+    def addp(x, p):
+        out = x.copy(); carry = np.zeros(len(x), dtype=object)
+        for j in range(4):
+            t = x[:, j].astype(object) + int(p[j]) + carry
+            out[:, j] = np.array([int(v) & 0xFFFFFFFFFFFFFFFF for v in t], dtype=np.uint64)
+            carry = np.array([int(v) >> 64 for v in t], dtype=object)
+        return out
+    for which in (0, 1):
+        a = O.canon(which, inp.synthetic_scalars(31, 2000)); b = O.canon(which, inp.synthetic_scalars(32, 2000))
+        ap, bp = addp(a, P[which]), addp(b, P[which])
+        want = O.fe_mul(which, a, b)
+        for name, x, y in (("a,b", a, b), ("a+p,b", ap, b), ("a,b+p", a, bp), ("a+p,b+p", ap, bp)):
+            check(f"field{which} raw mul {name}", B.field_op(which, 6, x, y), want)
+            check(f"field{which} raw cios {name}", B.field_op(which, 7, x, y), want)
 if "ntt" in stages:
     k = inp.synthetic_scalars(77, 1)[0]
     for lg in (0, 1, 2, 3, 5, 8, 11, 12, 13, 14, 16):

@@ -214,3 +214,19 @@ def test_live_against_reference(pkg, oracle, ref):
             want, _ = d.run(c, op)
             assert np.array_equal(oracle.ntt(c, op), want), (lg, op)
         d.free()
+
+
+def test_poly_helpers_golden(pkg, oracle, golden):
+    """add/sub/mul, compute_kate_opening_coefficients, divide_by_pseudo_vanishing_polynomial vs the compiled reference."""
+    kc = unhex(golden["ntt_constant"])[0]
+    for rec in golden["poly"]["binop"]:
+        a = pkg.synthetic_scalars(rec["seed_a"], 1 << rec["log2n"])
+        b = pkg.synthetic_scalars(rec["seed_b"], 1 << rec["log2n"])
+        assert sha(oracle.poly_binop(rec["op"], a, b)) == rec["sha256"], rec
+    for rec in golden["poly"]["kate"]:
+        a = pkg.synthetic_scalars(rec["seed"], rec["n"])
+        dest, f = oracle.kate_opening(a, kc)
+        assert np.array_equal(f, unhex(rec["f"])[0]) and sha(dest) == rec["dest_sha256"], rec
+    for rec in golden["poly"]["dpv"]:
+        e = pkg.synthetic_scalars(rec["seed"], 1 << rec["log2_target"])
+        assert sha(oracle.divide_by_pseudo_vanishing(e, rec["log2_src"], rec["cut"])) == rec["sha256"], rec
