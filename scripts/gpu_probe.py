@@ -179,6 +179,29 @@ if "nttprof" in stages:
         for _ in range(5):
             B.ntt_device(t.data_ptr(), lg, 0)
         B.sync()
+if "polytime" in stages:
+    import torch
+    for lg in (22, 24):
+        n = 1 << lg
+        a = torch.from_numpy(inp.synthetic_scalars(1, n).view(np.int64).reshape(-1)).cuda()
+        b = torch.from_numpy(inp.synthetic_scalars(2, n).view(np.int64).reshape(-1)).cuda()
+        r = torch.empty_like(a)
+        z = inp.synthetic_scalars(3, 1)[0]
+        def timeit(fn, reps=10):
+            fn(); B.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps): fn()
+            B.sync()
+            return (time.perf_counter() - t0) / reps
+        for op, name in ((0, "add"), (1, "sub"), (2, "mul")):
+            dt = timeit(lambda: B.poly_op_device(op, a.data_ptr(), b.data_ptr(), r.data_ptr(), n))
+            print(f"poly {name} 2^{lg}: {dt*1e3:.3f} ms  {96*n/dt/1e9:.0f} GB/s algorithmic (96 B/elem) = {96*n/dt/8e12*100:.1f}% of 8 TB/s", flush=True)
+        dt = timeit(lambda: B.poly_evaluate_device(a.data_ptr(), n, z), 5)
+        print(f"evaluate 2^{lg}: {dt*1e3:.3f} ms  {32*n/dt/1e9:.0f} GB/s (32 B/elem)", flush=True)
+        dt = timeit(lambda: B.kate_opening_device(a.data_ptr(), r.data_ptr(), n, z), 5)
+        print(f"kate opening 2^{lg}: {dt*1e3:.3f} ms  {64*n/dt/1e9:.0f} GB/s (64 B/elem)", flush=True)
+        dt = timeit(lambda: B.divide_by_pseudo_vanishing_device(a.data_ptr(), lg - 2, lg, 4))
+        print(f"divide_by_pseudo_vanishing 2^{lg}: {dt*1e3:.3f} ms  {64*n/dt/1e9:.0f} GB/s (64 B/elem)", flush=True)
 if "tune8" in stages:
     import torch
     for lg in (18, 20, 22, 24):
