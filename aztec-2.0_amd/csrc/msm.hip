@@ -324,6 +324,66 @@ k_combine(const uint32_t* __restrict__ offsets, uint32_t total, const Xyzz* __re
 
 __device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads);
 
+__device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
+{
+    Xyzz r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.x.v[i] = __shfl_xor(v.x.v[i], mask);
+        r.y.v[i] = __shfl_xor(v.y.v[i], mask);
+        r.zz.v[i] = __shfl_xor(v.zz.v[i], mask);
+        r.zzz.v[i] = __shfl_xor(v.zzz.v[i], mask);
+    }
+    return r;
+}
+
+// Latency-oriented variant of k_combine: 8 adjacent lanes share a bucket, each sums every 8th piece, then a 3-level
+// butterfly over the lane group (a bucket of ~512 entries has ~9 pieces: the serial chain drops from 8 additions to 4).
+constexpr int MSM_COMBINE_LANES = 8;
+__global__ void __launch_bounds__(256, 1)
+k_combine8(const uint32_t* __restrict__ offsets, uint32_t total, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = gid / MSM_COMBINE_LANES + 1;
+    const uint32_t r = gid % MSM_COMBINE_LANES;
+    if (b > MSM_BUCKETS) return; // whole lane groups drop out together (grid is a multiple of 8)
+    const uint32_t base = offsets[1];
+    const uint32_t sb = offsets[b], eb = offsets[b + 1];
+    bool store = true, reduce = false;
+    Xyzz acc = xyzz_inf();
+    if (sb != eb) {
+        const uint32_t l0 = (sb - base) / MSM_SEG, l1 = (eb - 1 - base) / MSM_SEG;
+        const bool at_start = (sb == base + l0 * MSM_SEG);
+        if (l0 == l1) {
+            uint32_t seg_end = base + (l0 + 1) * MSM_SEG;
+            if (seg_end > total || seg_end < base) seg_end = total;
+            if (at_start) acc = xyzz_load(head + l0);
+            else if (eb == seg_end) acc = xyzz_load(tail + l0);
+            else store = false; // complete run, already written by k_accumulate
+        } else if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
+            if (r == 0) {
+                const uint32_t slot = atomicAdd(long_count, 1u);
+                long_list[slot] = b;
+            }
+            store = false;
+        } else {
+            reduce = true;
+            for (uint32_t l = l0 + r; l <= l1; l += MSM_COMBINE_LANES) acc = xyzz_add(acc, bucket_piece(head, tail, l, l0, at_start));
+        }
+    }
+    // the butterfly is executed by all lanes of the wave (shuffles need every lane); groups that do not reduce carry infinities
+    if (!reduce && !(sb != eb && store)) acc = xyzz_inf();
+    const unsigned long long any = __ballot(reduce);
+    if (any) {
+        Xyzz part = reduce ? acc : xyzz_inf();
+        for (int m = MSM_COMBINE_LANES >> 1; m >= 1; m >>= 1) part = xyzz_add(part, xyzz_shfl_xor(part, m));
+        if (reduce) acc = part;
+    }
+    if (store && r == 0) xyzz_store(buckets + (b - 1), acc);
+}
+
+
 // one block per queued long bucket (grid-stride over the queue)
 __global__ void __launch_bounds__(256, 1)
 k_combine_long(const uint32_t* __restrict__ offsets, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
@@ -377,42 +437,32 @@ __global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* __restrict__ buck
     }
 }
 
-__device__ Xyzz xyzz_mul_small(const Xyzz& p, uint32_t k)
+// sum_b b*B_b = 256 * sum_hi hi*Row_hi + sum_lo (lo+1)*Col_lo = sum_t 2^t H_t with the bit planes
+//   H_t = sum_{lo : bit t of (lo+1)} Col_lo  +  sum_{hi : bit (t-8) of hi} Row_hi          (t = 0 .. 14).
+// One block per bit plane: tree-sum the selected rows/columns, then t doublings by one lane -- the 15 planes run side
+// by side, so the serial depth is 9 additions + 14 doublings instead of a 9-bit double-and-add on top of an 8-level tree
+// plus 8 more doublings.  k_final_sum adds the 15 planes and converts to the reference's Jacobian layout.
+constexpr int MSM_PLANES = 15;
+__global__ void __launch_bounds__(256, 1) k_final_planes(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Xyzz* planes)
 {
-    Xyzz acc = xyzz_inf();
-    for (int i = 31 - __clz(k | 1); i >= 0; i--) {
-        acc = xyzz_dbl(acc);
-        if ((k >> i) & 1) acc = xyzz_add(acc, p);
-    }
-    return k ? acc : xyzz_inf();
-}
-
-// one block of 512 threads: threads 0..127 weigh rows by hi, 256..511 weigh columns by lo+1; result =
-// 256 * sum(rows) + sum(cols), optionally added to `accumulate_into`, written as the reference's Jacobian.
-__global__ void __launch_bounds__(512, 1) k_final(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Jacobian* out)
-{
-    __shared__ Xyzz sm[256];
-    __shared__ Xyzz rowsum;
-    const int tid = threadIdx.x;
+    __shared__ Xyzz sm[128];
+    const int t = blockIdx.x, tid = threadIdx.x;
     Xyzz v = xyzz_inf();
-    if (tid < 128) v = xyzz_mul_small(xyzz_load(rows + tid), (uint32_t)tid);
-    else if (tid >= 256) v = xyzz_mul_small(xyzz_load(cols + (tid - 256)), (uint32_t)(tid - 256 + 1));
-    // reduce the two halves separately: lanes [0,256) and [256,512)
-    const int half = tid >> 8, l = tid & 255;
-    for (int stride = 128; stride >= 1; stride >>= 1) {
-        // two independent trees sharing the barrier; each half uses its own 128-entry region of sm
-        if (l >= stride && l < 2 * stride) sm[half * 128 + (l - stride)] = v;
-        __syncthreads();
-        if (l < stride) v = xyzz_add(v, sm[half * 128 + l]);
-        __syncthreads();
+    if (((tid + 1) >> t) & 1) v = xyzz_load(cols + tid);
+    if (t >= 8 && tid < 128 && ((tid >> (t - 8)) & 1)) v = xyzz_add(v, xyzz_load(rows + tid));
+    v = block_reduce(v, sm, 256);
+    if (tid == 0) {
+        for (int k = 0; k < t; k++) v = xyzz_dbl(v);
+        xyzz_store(planes + t, v);
     }
-    if (tid == 0) rowsum = v;
-    __syncthreads();
-    if (tid == 256) {
-        Xyzz r = rowsum;
-        for (int k = 0; k < 8; k++) r = xyzz_dbl(r);
-        r = xyzz_add(r, v);
-        Jacobian j = xyzz_to_jacobian(r);
+}
+__global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ planes, Jacobian* out)
+{
+    __shared__ Xyzz sm[8];
+    Xyzz v = threadIdx.x < MSM_PLANES ? xyzz_load(planes + threadIdx.x) : xyzz_inf();
+    v = block_reduce(v, sm, 16);
+    if (threadIdx.x == 0) {
+        Jacobian j = xyzz_to_jacobian(v);
         fe_store<FqP>(&out->x, j.x);
         fe_store<FqP>(&out->y, j.y);
         fe_store<FqP>(&out->z, j.z);
@@ -494,7 +544,7 @@ static int msm_layout(size_t n, MsmLayout& L)
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
         L.off_tail[k] = take(L.lanes * sizeof(Xyzz));
         L.off_buckets[k] = take((size_t)MSM_BUCKETS * sizeof(Xyzz));
-        L.off_rows[k] = take(128 * sizeof(Xyzz));
+        L.off_rows[k] = take((128 + 16) * sizeof(Xyzz)); // 128 row sums + 15 bit planes
         L.off_cols[k] = take(256 * sizeof(Xyzz));
         L.off_long[k] = take((MSM_BUCKETS + 1) * 4);
     }
@@ -570,6 +620,7 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     Xyzz* buckets = (Xyzz*)(base + L.off_buckets[slot]);
     Xyzz* rows = (Xyzz*)(base + L.off_rows[slot]);
     Xyzz* cols = (Xyzz*)(base + L.off_cols[slot]);
+    Xyzz* planes = rows + 128;
     uint32_t* long_count = (uint32_t*)(base + L.off_long[slot]);
     uint32_t* long_list = long_count + 1;
     const bool overlap = ctx->msm_async_reduce;
@@ -606,11 +657,12 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     }
     {
         ProfScope ps(ctx, "msm_reduce", rst);
-        hipLaunchKernelGGL(k_combine, dim3(grid_for(MSM_BUCKETS, 256)), dim3(256), 0, rst, offsets, (uint32_t)L.entries, head, tail,
-                           buckets, long_count, long_list);
+        hipLaunchKernelGGL(k_combine8, dim3(grid_for((size_t)MSM_BUCKETS * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
+                           (uint32_t)L.entries, head, tail, buckets, long_count, long_list);
         hipLaunchKernelGGL(k_combine_long, dim3(256), dim3(256), 0, rst, offsets, head, tail, buckets, long_count, long_list);
         hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, rst, buckets, rows, cols);
-        hipLaunchKernelGGL(k_final, dim3(1), dim3(512), 0, rst, rows, cols, (Jacobian*)d_out_jac);
+        hipLaunchKernelGGL(k_final_planes, dim3(MSM_PLANES), dim3(256), 0, rst, rows, cols, planes);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (Jacobian*)d_out_jac);
     }
     if (overlap) {
         BBG_HIP(hipEventRecord(ctx->ev_done[slot], rst));
