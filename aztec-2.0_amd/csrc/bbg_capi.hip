@@ -178,6 +178,12 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_async_reduce = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "msm_sort")) {
+        if (value != 0 && value != 1) { set_error("msm_sort must be 0 or 1"); return BBG_E_INVALID; }
+        BBG_HIP(hipDeviceSynchronize());
+        ctx->msm_sort = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_debug_idx_mask")) return msm_debug_idx_mask((uint32_t)value);
     if (!strcmp(key, "ntt_tile_log")) {
         if (value < 9 || value > 12) { set_error("ntt_tile_log must be 9..12"); return BBG_E_INVALID; }

@@ -83,6 +83,7 @@ struct bbg_ctx {
     bool ev_done_valid[2] = { false, false };
     unsigned long msm_seq = 0;
     bool msm_async_reduce = false;
+    int msm_sort = 1; // 1 = fused recode + MSD partition sort (msm.hip), 0 = k_recode + rocPRIM radix sort + k_offsets
     int ntt_tile_log = 10; // log2(elements per LDS tile); 10/7 measured best on MI355X (profiles/r01_ntt_plan_sweep.txt)
     int ntt_max_logr = 7;
     int ntt_kernel = 2;      // 2 = k_ntt_pass8 where applicable (n >= 2^11), 1 = k_ntt_pass only

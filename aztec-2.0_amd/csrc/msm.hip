@@ -196,6 +196,222 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, 
     // top window: k < 2^254 so the last digit is < 2^14 + 1 and never produces a carry
 }
 
+// ---------------------------------------------------------------------------------- fused recode + two-level partition sort
+// Replaces k_recode + the 2-pass library radix sort + k_offsets (0.42 ms at 2^20) with an MSD partition that exploits what
+// the accumulation needs: runs per bucket in ANY order.  Bucket id mag in [0, 2^15] splits into hi = mag >> 7 (257
+// partitions) and lo = mag & 127.
+//   k_sortA_count   : digits of 1024 scalars per block, LDS histogram of hi, one global add per (block, partition)
+//   k_sortA_scan    : exclusive scan of the 257 partition sizes
+//   k_sortA_scatter : digits again; each block reserves a contiguous range in every partition with ONE global atomic and
+//                     ranks its entries with LDS atomics; entry = (lo << 32) | value
+//   k_sortB         : one block per partition: LDS histogram of lo, writes the bucket offsets of its 128 buckets and
+//                     scatters the 32-bit values to their final position
+// Digits are recomputed instead of stored (one Montgomery product per scalar is cheaper than 2 x 34 MiB of traffic).
+constexpr int SORT_PARTS = 257;          // hi in [0, 256]
+constexpr int SORT_LO_BITS = 7;
+constexpr int SORT_BLOCK = 1024;         // scalars per block in the A kernels
+
+// LDS counter bump that stays fast when a whole wave hits one counter (all-equal scalars): one atomic per wave then.
+// Inactive lanes are masked off (no traffic); returns the lane's rank within the counter.
+__device__ __forceinline__ uint32_t lds_take(uint32_t* ctr, uint32_t key, bool active)
+{
+    uint32_t r = 0;
+    if (active) {
+        const uint64_t act = __ballot(1);
+        const uint32_t k0 = __builtin_amdgcn_readfirstlane(key);
+        if (__ballot(key == k0) == act) {
+            const int lane = threadIdx.x & 63;
+            const uint32_t below = (uint32_t)__popcll(act & ((1ull << lane) - 1));
+            uint32_t b = 0;
+            if (below == 0) b = atomicAdd(&ctr[k0], (uint32_t)__popcll(act));
+            r = __builtin_amdgcn_readfirstlane(b) + below;
+        } else {
+            r = atomicAdd(&ctr[key], 1u);
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, size_t i, uint32_t (&mag)[MSM_WINDOWS], uint32_t& signs)
+{
+    const Fr k = fe_from_mont(fe_load<FrP>(scalars + i));
+    uint32_t carry = 0;
+    signs = 0;
+#pragma unroll
+    for (int w = 0; w < MSM_WINDOWS; w++) {
+        const uint32_t limb = k.v[w >> 1];
+        const uint32_t d = ((w & 1) ? (limb >> 16) : (limb & 0xffffu)) + carry;
+        const uint32_t neg = d > 0x8000u;
+        mag[w] = neg ? (0x10000u - d) : d;
+        carry = neg;
+        signs |= neg << w;
+    }
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
+{
+    __shared__ uint32_t hist[SORT_PARTS + 3];
+    const int tid = threadIdx.x;
+    for (int h = tid; h < SORT_PARTS; h += SORT_BLOCK) hist[h] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
+    uint32_t mag[MSM_WINDOWS], signs;
+    if (i < n) recode_digits(scalars, i, mag, signs);
+#pragma unroll
+    for (int w = 0; w < MSM_WINDOWS; w++) {
+        const bool on = i < n && mag[w] != 0; // zero digits contribute nothing: never sorted
+        lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
+    }
+    __syncthreads();
+    for (int h = tid; h < SORT_PARTS; h += SORT_BLOCK)
+        if (hist[h]) atomicAdd(&part_count[h], hist[h]);
+}
+// part_base[h] = sum_{h' < h} count[h'] ; cursor[h] = part_base[h] ; offsets[MSM_BUCKETS + 1] = total
+__global__ void __launch_bounds__(512) k_sortA_scan(const uint32_t* __restrict__ part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets)
+{
+    __shared__ uint32_t sm[512];
+    const int tid = threadIdx.x;
+    const uint32_t c = tid < SORT_PARTS ? part_count[tid] : 0u;
+    sm[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < 512; d <<= 1) { // Hillis-Steele inclusive scan
+        const uint32_t t = tid >= d ? sm[tid - d] : 0u;
+        __syncthreads();
+        sm[tid] += t;
+        __syncthreads();
+    }
+    const uint32_t excl = sm[tid] - c;
+    if (tid <= SORT_PARTS) part_base[tid] = excl; // part_base[SORT_PARTS] = total
+    if (tid < SORT_PARTS) cursor[tid] = excl;
+    if (tid == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl;
+}
+// The block's <= 16 Ki entries are first grouped by partition in LDS (values + 16-bit bucket ids, 96 KiB) and then written
+// out with consecutive threads on consecutive addresses: every (block, partition) chunk is one contiguous burst instead
+// of ~60 independent 8-byte stores issued at random times.
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* cursor, uint64_t* entries)
+{
+    constexpr int CAP = SORT_BLOCK * MSM_WINDOWS;
+    __shared__ uint32_t hist[512];   // per-partition count, then rank counter
+    __shared__ uint32_t lstart[512]; // first LDS slot of each partition
+    __shared__ uint32_t gbase[512];  // this block's first global slot in each partition, minus lstart
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t st_val[CAP];
+    __shared__ uint16_t st_mag[CAP];
+    const int tid = threadIdx.x;
+    if (tid < 512) hist[tid] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
+    uint32_t mag[MSM_WINDOWS], signs = 0;
+    if (i < n) recode_digits(scalars, i, mag, signs);
+#pragma unroll
+    for (int w = 0; w < MSM_WINDOWS; w++) {
+        const bool on = i < n && mag[w] != 0;
+        lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
+    }
+    __syncthreads();
+    // exclusive scan of the 257 (padded to 512) counters: 8 waves of 64
+    uint32_t c = 0, incl = 0;
+    if (tid < 512) {
+        c = hist[tid];
+        incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if ((tid & 63) >= d) incl += t;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < 512) {
+        uint32_t before = 0;
+        for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
+        const uint32_t excl = before + incl - c;
+        lstart[tid] = excl;
+        gbase[tid] = (c ? atomicAdd(&cursor[tid], c) : 0u) - excl; // one global reservation per (block, partition)
+        hist[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < MSM_WINDOWS; w++) {
+        const bool on = i < n && mag[w] != 0;
+        const uint32_t h = on ? mag[w] >> SORT_LO_BITS : 0u;
+        const uint32_t rank = lds_take(hist, h, on);
+        if (on) {
+            const uint32_t slot = lstart[h] + rank;
+            st_val[slot] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
+            st_mag[slot] = (uint16_t)mag[w];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = lstart[SORT_PARTS - 1] + hist[SORT_PARTS - 1];
+    for (uint32_t slot = tid; slot < total; slot += SORT_BLOCK) {
+        const uint32_t m = st_mag[slot];
+        entries[gbase[m >> SORT_LO_BITS] + slot] = ((uint64_t)(m & ((1u << SORT_LO_BITS) - 1)) << 32) | st_val[slot];
+    }
+}
+
+constexpr int SORTB_UNROLL = 8; // independent 8-byte loads in flight per thread (the loop is latency-bound otherwise)
+__global__ void __launch_bounds__(1024)
+k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_base, uint32_t* offsets, uint32_t* svals)
+{
+    __shared__ uint32_t hist[1 << SORT_LO_BITS];
+    __shared__ uint32_t off[1 << SORT_LO_BITS];
+    const int tid = threadIdx.x;
+    const uint32_t h = blockIdx.x;
+    const uint32_t pb = part_base[h], pe = part_base[h + 1];
+    const uint32_t len = pe - pb;
+    if (tid < (1 << SORT_LO_BITS)) hist[tid] = 0;
+    __syncthreads();
+    constexpr uint32_t CHUNK = 1024 * SORTB_UNROLL;
+    const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loop (lds_take is wave-cooperative)
+    for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
+        uint32_t key[SORTB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SORTB_UNROLL; u++) {
+            const uint32_t q = q0 + u * 1024 + tid;
+            const uint32_t k = (uint32_t)(entries[pb + (q < len ? q : 0u)] >> 32); // unconditional: the loads batch up
+            key[u] = q < len ? k : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < SORTB_UNROLL; u++) lds_take(hist, key[u] & 127u, key[u] != 0xffffffffu);
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive scan of the 128 counters by one wave: two counters per lane
+        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (tid >= d) incl += t;
+        }
+        const uint32_t excl = incl - (c0 + c1);
+        off[2 * tid] = excl;
+        off[2 * tid + 1] = excl + c0;
+    }
+    __syncthreads();
+    if (tid < (1 << SORT_LO_BITS)) {
+        const uint32_t bucket = (h << SORT_LO_BITS) + tid;
+        if (bucket <= MSM_BUCKETS) offsets[bucket] = pb + off[tid];
+    }
+    __syncthreads();
+    for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
+        uint64_t e[SORTB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SORTB_UNROLL; u++) {
+            const uint32_t q = q0 + u * 1024 + tid;
+            const uint64_t v = entries[pb + (q < len ? q : 0u)];
+            e[u] = q < len ? v : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < SORTB_UNROLL; u++) {
+            const bool on = e[u] != ~0ull;
+            const uint32_t pos = lds_take(off, (uint32_t)(e[u] >> 32) & 127u, on);
+            if (on) svals[pb + pos] = (uint32_t)e[u];
+        }
+    }
+}
+
 // offsets[b] = first sorted position with key >= b, for b = 0 .. MSM_BUCKETS + 1
 __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint32_t* offsets)
 {
@@ -237,8 +453,9 @@ __device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ ta
 
 __global__ void __launch_bounds__(256)
 k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-             size_t n_srs, uint32_t total, Xyzz* head, Xyzz* tail, Xyzz* buckets)
+             size_t n_srs, uint32_t, Xyzz* head, Xyzz* tail, Xyzz* buckets)
 {
+    const uint32_t total = offsets[MSM_BUCKETS + 1]; // the partition sort drops zero digits: the count lives on the device
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = offsets[1]; // entries with key 0 (zero digits) sort first and are skipped
     const uint64_t s64 = (uint64_t)base + (uint64_t)lane * MSM_SEG;
@@ -292,9 +509,10 @@ __device__ __forceinline__ Xyzz bucket_piece(const Xyzz* __restrict__ head, cons
 // buckets[b-1] = sum of the pieces of bucket b; complete ("middle") runs were already written by k_accumulate.
 // Buckets spanning more than MSM_LONG_SPAN lanes (skewed scalar distributions) are queued for k_combine_long.
 __global__ void __launch_bounds__(256, 1)
-k_combine(const uint32_t* __restrict__ offsets, uint32_t total, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+k_combine(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
+    const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (b > MSM_BUCKETS) return;
     const uint32_t base = offsets[1];
@@ -341,9 +559,10 @@ __device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
 // butterfly over the lane group (a bucket of ~512 entries has ~9 pieces: the serial chain drops from 8 additions to 4).
 constexpr int MSM_COMBINE_LANES = 8;
 __global__ void __launch_bounds__(256, 1)
-k_combine8(const uint32_t* __restrict__ offsets, uint32_t total, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+k_combine8(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
+    const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / MSM_COMBINE_LANES + 1;
     const uint32_t r = gid % MSM_COMBINE_LANES;
@@ -515,7 +734,7 @@ __global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ 
 // ---------------------------------------------------------------------------------- host side
 struct MsmLayout {
     size_t entries, lanes;
-    size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort;
+    size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort, off_parts;
     // reduce-phase working set, double buffered so that the reduce of MSM i (aux stream) overlaps MSM i+1
     size_t off_offsets[2], off_head[2], off_tail[2], off_buckets[2], off_rows[2], off_cols[2], off_long[2];
     size_t sort_bytes;
@@ -539,6 +758,7 @@ static int msm_layout(size_t n, MsmLayout& L)
     L.off_vals0 = take(L.entries * 4);
     L.off_vals1 = take(L.entries * 4);
     L.off_sort = take(L.sort_bytes);
+    L.off_parts = take(3 * 512 * 4);
     for (int k = 0; k < 2; k++) {
         L.off_offsets[k] = take((MSM_BUCKETS + 2) * 4);
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
@@ -628,22 +848,44 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
 
     // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM two calls ago
     if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[slot], 0));
-    {
-        ProfScope ps(ctx, "msm_recode", st);
-        hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
-    }
-    rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
-    {
-        ProfScope ps(ctx, "msm_sort", st);
-        size_t tmp = L.sort_bytes;
-        hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C, st);
-        if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
-    }
-    const uint32_t* skeys = dk.current();
-    const uint32_t* svals = dv.current();
-    {
-        ProfScope ps(ctx, "msm_offsets", st);
-        hipLaunchKernelGGL(k_offsets, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
+    const uint32_t* svals;
+    if (ctx->msm_sort == 1) {
+        // fused recode + MSD partition sort (keys0 area = 64-bit entries, vals0 = final values, keys1 head = partition tables)
+        uint64_t* entries = (uint64_t*)keys0; // keys0 and keys1 are adjacent: 2 x 4 x 16n bytes = 8 x 16n
+        uint32_t* part_count = (uint32_t*)(base + L.off_parts);
+        uint32_t* part_base = part_count + 512;
+        uint32_t* cursor = part_count + 1024;
+        const int nblk = grid_for(n, SORT_BLOCK);
+        {
+            ProfScope ps(ctx, "msm_recode", st);
+            BBG_HIP(hipMemsetAsync(part_count, 0, 512 * 4, st));
+            hipLaunchKernelGGL(k_sortA_count, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
+            hipLaunchKernelGGL(k_sortA_scan, dim3(1), dim3(512), 0, st, part_count, part_base, cursor, offsets);
+        }
+        {
+            ProfScope ps(ctx, "msm_sort", st);
+            hipLaunchKernelGGL(k_sortA_scatter, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, from, cursor, entries);
+            hipLaunchKernelGGL(k_sortB, dim3(SORT_PARTS), dim3(1024), 0, st, entries, part_base, offsets, vals0);
+        }
+        svals = vals0;
+    } else {
+        {
+            ProfScope ps(ctx, "msm_recode", st);
+            hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
+        }
+        rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
+        {
+            ProfScope ps(ctx, "msm_sort", st);
+            size_t tmp = L.sort_bytes;
+            hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C, st);
+            if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
+        }
+        const uint32_t* skeys = dk.current();
+        svals = dv.current();
+        {
+            ProfScope ps(ctx, "msm_offsets", st);
+            hipLaunchKernelGGL(k_offsets, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
+        }
     }
     {
         ProfScope ps(ctx, "msm_accumulate", st);
