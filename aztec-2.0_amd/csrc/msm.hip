@@ -442,7 +442,7 @@ __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint3
 //   buckets[b]  : runs that start and end strictly inside the segment (complete buckets)
 // and k_combine adds head/tail pieces per bucket.  Values address the window tables: point = table[w*n_srs + idx],
 // negated when bit 31 is set.
-constexpr int MSM_SEG = 64;
+constexpr int MSM_SEG_LOG_MIN = 3, MSM_SEG_LOG_DEFAULT = 6; // segment length is chosen per call (msm_seg_log)
 constexpr int MSM_LONG_SPAN = 48; // buckets spanning more lanes than this are summed by a whole block
 
 __device__ uint32_t g_debug_idx_mask = 0xffffffffu; // experiments only: confine the gathers to a cache-resident subset
@@ -453,15 +453,15 @@ __device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ ta
 
 __global__ void __launch_bounds__(256)
 k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-             size_t n_srs, uint32_t, Xyzz* head, Xyzz* tail, Xyzz* buckets)
+             size_t n_srs, uint32_t seg_log, Xyzz* head, Xyzz* tail, Xyzz* buckets)
 {
     const uint32_t total = offsets[MSM_BUCKETS + 1]; // the partition sort drops zero digits: the count lives on the device
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = offsets[1]; // entries with key 0 (zero digits) sort first and are skipped
-    const uint64_t s64 = (uint64_t)base + (uint64_t)lane * MSM_SEG;
+    const uint64_t s64 = (uint64_t)base + ((uint64_t)lane << seg_log);
     if (s64 >= total) return;
     const uint32_t s = (uint32_t)s64;
-    const uint32_t e = (total - s > (uint32_t)MSM_SEG) ? s + MSM_SEG : total;
+    const uint32_t e = (total - s > (1u << seg_log)) ? s + (1u << seg_log) : total;
     // bucket containing position s: largest b in [1, 2^15] with offsets[b] <= s
     uint32_t lo = 1, hi = MSM_BUCKETS;
     while (lo < hi) {
@@ -509,7 +509,7 @@ __device__ __forceinline__ Xyzz bucket_piece(const Xyzz* __restrict__ head, cons
 // buckets[b-1] = sum of the pieces of bucket b; complete ("middle") runs were already written by k_accumulate.
 // Buckets spanning more than MSM_LONG_SPAN lanes (skewed scalar distributions) are queued for k_combine_long.
 __global__ void __launch_bounds__(256, 1)
-k_combine(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+k_combine(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
     const uint32_t total = offsets[MSM_BUCKETS + 1];
@@ -521,10 +521,10 @@ k_combine(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restrict
         xyzz_store(buckets + (b - 1), xyzz_inf());
         return;
     }
-    const uint32_t l0 = (sb - base) / MSM_SEG, l1 = (eb - 1 - base) / MSM_SEG;
-    const bool at_start = (sb == base + l0 * MSM_SEG);
+    const uint32_t l0 = (sb - base) >> seg_log, l1 = (eb - 1 - base) >> seg_log;
+    const bool at_start = (sb == base + (l0 << seg_log));
     if (l0 == l1) {
-        uint32_t seg_end = base + (l0 + 1) * MSM_SEG;
+        uint32_t seg_end = base + ((l0 + 1) << seg_log);
         if (seg_end > total || seg_end < base) seg_end = total;
         if (at_start) xyzz_store(buckets + (b - 1), xyzz_load(head + l0));
         else if (eb == seg_end) xyzz_store(buckets + (b - 1), xyzz_load(tail + l0));
@@ -559,7 +559,7 @@ __device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
 // butterfly over the lane group (a bucket of ~512 entries has ~9 pieces: the serial chain drops from 8 additions to 4).
 constexpr int MSM_COMBINE_LANES = 8;
 __global__ void __launch_bounds__(256, 1)
-k_combine8(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
     const uint32_t total = offsets[MSM_BUCKETS + 1];
@@ -572,10 +572,10 @@ k_combine8(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restric
     bool store = true, reduce = false;
     Xyzz acc = xyzz_inf();
     if (sb != eb) {
-        const uint32_t l0 = (sb - base) / MSM_SEG, l1 = (eb - 1 - base) / MSM_SEG;
-        const bool at_start = (sb == base + l0 * MSM_SEG);
+        const uint32_t l0 = (sb - base) >> seg_log, l1 = (eb - 1 - base) >> seg_log;
+        const bool at_start = (sb == base + (l0 << seg_log));
         if (l0 == l1) {
-            uint32_t seg_end = base + (l0 + 1) * MSM_SEG;
+            uint32_t seg_end = base + ((l0 + 1) << seg_log);
             if (seg_end > total || seg_end < base) seg_end = total;
             if (at_start) acc = xyzz_load(head + l0);
             else if (eb == seg_end) acc = xyzz_load(tail + l0);
@@ -605,7 +605,7 @@ k_combine8(const uint32_t* __restrict__ offsets, uint32_t, const Xyzz* __restric
 
 // one block per queued long bucket (grid-stride over the queue)
 __global__ void __launch_bounds__(256, 1)
-k_combine_long(const uint32_t* __restrict__ offsets, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
+k_combine_long(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
                const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list)
 {
     __shared__ Xyzz sm[128];
@@ -614,8 +614,8 @@ k_combine_long(const uint32_t* __restrict__ offsets, const Xyzz* __restrict__ he
     for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
         const uint32_t b = long_list[i];
         const uint32_t sb = offsets[b], eb = offsets[b + 1];
-        const uint32_t l0 = (sb - base) / MSM_SEG, l1 = (eb - 1 - base) / MSM_SEG;
-        const bool at_start = (sb == base + l0 * MSM_SEG);
+        const uint32_t l0 = (sb - base) >> seg_log, l1 = (eb - 1 - base) >> seg_log;
+        const bool at_start = (sb == base + (l0 << seg_log));
         Xyzz acc = xyzz_inf();
         for (uint32_t l = l0 + threadIdx.x; l <= l1; l += 256) acc = xyzz_add(acc, bucket_piece(head, tail, l, l0, at_start));
         acc = block_reduce(acc, sm, 256);
@@ -735,6 +735,7 @@ __global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ 
 struct MsmLayout {
     size_t entries, lanes;
     size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort, off_parts;
+    uint32_t seg_log;
     // reduce-phase working set, double buffered so that the reduce of MSM i (aux stream) overlaps MSM i+1
     size_t off_offsets[2], off_head[2], off_tail[2], off_buckets[2], off_rows[2], off_cols[2], off_long[2];
     size_t sort_bytes;
@@ -742,10 +743,22 @@ struct MsmLayout {
 };
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Segment length (entries per accumulation lane).  64 at the headline size; shorter for small MSMs, whose run time is the
+// latency of one lane's serial chain of mixed additions (64 additions = 0.43 ms regardless of n), and longer for very
+// large ones so that a bucket spans <= ~32 lanes and k_combine8 (not the block-per-bucket fallback) sums its pieces.
+static uint32_t msm_seg_log(size_t entries)
+{
+    uint32_t lg = MSM_SEG_LOG_MIN;
+    while (lg < MSM_SEG_LOG_DEFAULT && (entries >> lg) > (size_t)262144) lg++;   // fill the chip once: 256 Ki lanes
+    while ((entries >> lg) > (size_t)MSM_BUCKETS * 32) lg++;                      // <= 32 pieces per average bucket
+    return lg;
+}
+
 static int msm_layout(size_t n, MsmLayout& L)
 {
     L.entries = n * MSM_WINDOWS;
-    L.lanes = (L.entries + MSM_SEG - 1) / MSM_SEG;
+    L.seg_log = msm_seg_log(L.entries);
+    L.lanes = (L.entries + (1u << L.seg_log) - 1) >> L.seg_log;
     size_t tmp = 0;
     rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C);
@@ -891,7 +904,7 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
         ProfScope ps(ctx, "msm_accumulate", st);
         BBG_HIP(hipMemsetAsync(long_count, 0, 4, st));
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, (const Affine*)srs.points,
-                           srs.n, (uint32_t)L.entries, head, tail, buckets);
+                           srs.n, L.seg_log, head, tail, buckets);
     }
     if (overlap) {
         BBG_HIP(hipEventRecord(ctx->ev_acc[slot], st));
@@ -900,8 +913,8 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     {
         ProfScope ps(ctx, "msm_reduce", rst);
         hipLaunchKernelGGL(k_combine8, dim3(grid_for((size_t)MSM_BUCKETS * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
-                           (uint32_t)L.entries, head, tail, buckets, long_count, long_list);
-        hipLaunchKernelGGL(k_combine_long, dim3(256), dim3(256), 0, rst, offsets, head, tail, buckets, long_count, long_list);
+                           L.seg_log, head, tail, buckets, long_count, long_list);
+        hipLaunchKernelGGL(k_combine_long, dim3(256), dim3(256), 0, rst, offsets, L.seg_log, head, tail, buckets, long_count, long_list);
         hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, rst, buckets, rows, cols);
         hipLaunchKernelGGL(k_final_planes, dim3(MSM_PLANES), dim3(256), 0, rst, rows, cols, planes);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (Jacobian*)d_out_jac);

@@ -134,6 +134,32 @@ if "time" in stages:
             got = O.jac_to_affine(out.cpu().numpy().view(np.uint64))
             check("msm 2^16 vs oracle", got, O.pippenger(sc, pts))
         srs.free()
+if "msmsweep" in stages:
+    import torch
+    for lg in (10, 12, 14, 16, 18, 20, 22, 24):
+        n = 1 << lg
+        srs = B.srs_synth_hashed(0xBB254, n)
+        sc = inp.synthetic_scalars(1234, n)
+        ts = torch.from_numpy(sc.view(np.int64)).cuda()
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        for mode in (0, 1):
+            B.set_option("msm_async_reduce", mode)
+            B.msm_device(srs, ts.data_ptr(), n, out.data_ptr()); B.join(); B.sync()
+            reps = 10 if lg <= 20 else 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+            B.join(); B.sync()
+            dt = (time.perf_counter() - t0) / reps
+            B.profile_enable(True)
+            for _ in range(3):
+                B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+            B.join(); B.sync()
+            ph = {k[4:]: round(B.profile_get(k)[0] / 3, 4) for k in ("msm_recode", "msm_sort", "msm_accumulate", "msm_reduce")}
+            B.profile_enable(False)
+            print(f"msm 2^{lg} async_reduce={mode}: {dt*1e3:.3f} ms  {n/dt/1e6:.2f} Mscalar-mul/s  phases {ph}", flush=True)
+        B.set_option("msm_async_reduce", 0)
+        srs.free()
 if "msmexp" in stages:
     import torch
     n = 1 << 20
