@@ -198,18 +198,21 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, 
 
 // ---------------------------------------------------------------------------------- fused recode + two-level partition sort
 // Replaces k_recode + the 2-pass library radix sort + k_offsets (0.42 ms at 2^20) with an MSD partition that exploits what
-// the accumulation needs: runs per bucket in ANY order.  Bucket id mag in [0, 2^15] splits into hi = mag >> 7 (257
-// partitions) and lo = mag & 127.
+// the accumulation needs: runs per bucket in ANY order.  Bucket id mag in [0, 2^15] splits into hi = mag >> 5 (1025
+// partitions) and lo = mag & 31.
 //   k_sortA_count   : digits of 1024 scalars per block, LDS histogram of hi, one global add per (block, partition)
-//   k_sortA_scan    : exclusive scan of the 257 partition sizes
-//   k_sortA_scatter : digits again; each block reserves a contiguous range in every partition with ONE global atomic and
-//                     ranks its entries with LDS atomics; entry = (lo << 32) | value
-//   k_sortB         : one block per partition: LDS histogram of lo, writes the bucket offsets of its 128 buckets and
-//                     scatters the 32-bit values to their final position
+//   k_sortA_scan    : exclusive scan of the partition sizes
+//   k_sortA_scatter : digits again; each block reserves a contiguous range in every partition with ONE global atomic,
+//                     groups its entries by partition in LDS and writes them out coalesced; entry = (lo << 32) | value
+//   k_sortB         : one block per partition: LDS histogram of lo, writes the bucket offsets of its 32 buckets and
+//                     moves the 32-bit values to their final position (through LDS when the partition fits)
 // Digits are recomputed instead of stored (one Montgomery product per scalar is cheaper than 2 x 34 MiB of traffic).
-constexpr int SORT_PARTS = 257;          // hi in [0, 256]
-constexpr int SORT_LO_BITS = 7;
-constexpr int SORT_BLOCK = 1024;         // scalars per block in the A kernels
+// Order inside a bucket is arbitrary (atomics), so the Jacobian REPRESENTATIVE of an MSM result may differ between runs;
+// the point it denotes does not (the reference's representative likewise depends on its thread count).
+constexpr int SORT_LO_BITS = 5;
+constexpr int SORT_PARTS = (MSM_BUCKETS >> SORT_LO_BITS) + 1; // 1025: hi in [0, 1024]
+constexpr int SORT_PAD = 2048;                                 // table size (power of two >= SORT_PARTS)
+constexpr int SORT_BLOCK = 1024;                               // scalars per block in the A kernels
 
 // LDS counter bump that stays fast when a whole wave hits one counter (all-equal scalars): one atomic per wave then.
 // Inactive lanes are masked off (no traffic); returns the lane's rank within the counter.
@@ -248,11 +251,32 @@ __device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, si
     }
 }
 
+// exclusive scan of tbl[0 .. SORT_PAD) by a 1024-thread block, two adjacent entries per thread; returns the pair's
+// exclusive prefixes.  wsum = 16 words of LDS scratch.
+__device__ __forceinline__ void block_scan_pairs(const uint32_t* tbl, uint32_t* wsum, uint32_t& excl0, uint32_t& c0, uint32_t& c1)
+{
+    const int tid = threadIdx.x;
+    c0 = tbl[2 * tid];
+    c1 = tbl[2 * tid + 1];
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if ((tid & 63) >= d) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
+    excl0 = before + incl - (c0 + c1);
+}
+
 __global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
 {
-    __shared__ uint32_t hist[SORT_PARTS + 3];
+    __shared__ uint32_t hist[SORT_PAD];
     const int tid = threadIdx.x;
-    for (int h = tid; h < SORT_PARTS; h += SORT_BLOCK) hist[h] = 0;
+    hist[tid] = 0;
+    hist[tid + 1024] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
     uint32_t mag[MSM_WINDOWS], signs;
@@ -267,39 +291,36 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict
         if (hist[h]) atomicAdd(&part_count[h], hist[h]);
 }
 // part_base[h] = sum_{h' < h} count[h'] ; cursor[h] = part_base[h] ; offsets[MSM_BUCKETS + 1] = total
-__global__ void __launch_bounds__(512) k_sortA_scan(const uint32_t* __restrict__ part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets)
+__global__ void __launch_bounds__(1024) k_sortA_scan(const uint32_t* __restrict__ part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets)
 {
-    __shared__ uint32_t sm[512];
+    __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x;
-    const uint32_t c = tid < SORT_PARTS ? part_count[tid] : 0u;
-    sm[tid] = c;
-    __syncthreads();
-    for (int d = 1; d < 512; d <<= 1) { // Hillis-Steele inclusive scan
-        const uint32_t t = tid >= d ? sm[tid - d] : 0u;
-        __syncthreads();
-        sm[tid] += t;
-        __syncthreads();
-    }
-    const uint32_t excl = sm[tid] - c;
-    if (tid <= SORT_PARTS) part_base[tid] = excl; // part_base[SORT_PARTS] = total
-    if (tid < SORT_PARTS) cursor[tid] = excl;
-    if (tid == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl;
+    uint32_t excl, c0, c1;
+    block_scan_pairs(part_count, wsum, excl, c0, c1); // part_count[SORT_PARTS ..) is zero
+    const int h0 = 2 * tid, h1 = 2 * tid + 1;
+    if (h0 <= SORT_PARTS) part_base[h0] = excl; // part_base[SORT_PARTS] = total
+    if (h1 <= SORT_PARTS) part_base[h1] = excl + c0;
+    if (h0 < SORT_PARTS) cursor[h0] = excl;
+    if (h1 < SORT_PARTS) cursor[h1] = excl + c0;
+    if (h0 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl;
+    if (h1 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl + c0;
 }
 // The block's <= 16 Ki entries are first grouped by partition in LDS (values + 16-bit bucket ids, 96 KiB) and then written
 // out with consecutive threads on consecutive addresses: every (block, partition) chunk is one contiguous burst instead
-// of ~60 independent 8-byte stores issued at random times.
+// of independent 8-byte stores issued at random times.
 __global__ void __launch_bounds__(SORT_BLOCK)
 k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* cursor, uint64_t* entries)
 {
     constexpr int CAP = SORT_BLOCK * MSM_WINDOWS;
-    __shared__ uint32_t hist[512];   // per-partition count, then rank counter
-    __shared__ uint32_t lstart[512]; // first LDS slot of each partition
-    __shared__ uint32_t gbase[512];  // this block's first global slot in each partition, minus lstart
+    __shared__ uint32_t hist[SORT_PAD];   // per-partition count, then rank counter
+    __shared__ uint32_t lstart[SORT_PAD]; // first LDS slot of each partition
+    __shared__ uint32_t gbase[SORT_PAD];  // this block's first global slot in each partition, minus lstart
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t st_val[CAP];
     __shared__ uint16_t st_mag[CAP];
     const int tid = threadIdx.x;
-    if (tid < 512) hist[tid] = 0;
+    hist[tid] = 0;
+    hist[tid + 1024] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
     uint32_t mag[MSM_WINDOWS], signs = 0;
@@ -310,26 +331,17 @@ k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t*
         lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
     }
     __syncthreads();
-    // exclusive scan of the 257 (padded to 512) counters: 8 waves of 64
-    uint32_t c = 0, incl = 0;
-    if (tid < 512) {
-        c = hist[tid];
-        incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if ((tid & 63) >= d) incl += t;
-        }
-        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    }
+    uint32_t excl, c0, c1;
+    block_scan_pairs(hist, wsum, excl, c0, c1);
     __syncthreads();
-    if (tid < 512) {
-        uint32_t before = 0;
-        for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
-        const uint32_t excl = before + incl - c;
-        lstart[tid] = excl;
-        gbase[tid] = (c ? atomicAdd(&cursor[tid], c) : 0u) - excl; // one global reservation per (block, partition)
-        hist[tid] = 0;
+    {
+        const int h0 = 2 * tid, h1 = 2 * tid + 1;
+        lstart[h0] = excl;
+        lstart[h1] = excl + c0;
+        gbase[h0] = (c0 ? atomicAdd(&cursor[h0], c0) : 0u) - excl; // one global reservation per (block, partition)
+        gbase[h1] = (c1 ? atomicAdd(&cursor[h1], c1) : 0u) - (excl + c0);
+        hist[h0] = 0;
+        hist[h1] = 0;
     }
     __syncthreads();
 #pragma unroll
@@ -351,63 +363,91 @@ k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t*
     }
 }
 
-constexpr int SORTB_UNROLL = 8; // independent 8-byte loads in flight per thread (the loop is latency-bound otherwise)
+// One block per partition.  Fast path (partition <= SORTB_CAP entries, the normal case up to n = 2^20): entries are
+// read once into registers, ranked with LDS counters, staged in LDS in bucket order and written out coalesced.  Larger
+// partitions (bigger n, skewed digits) take two passes over global memory with scattered 4-byte stores.
+constexpr int SORTB_PER_THREAD = 19;
+constexpr int SORTB_CAP = SORTB_PER_THREAD * 1024; // 76 KiB of staging: two blocks per CU
+constexpr int SORTB_UNROLL = 8;
+constexpr uint32_t SORT_LO_MASK = (1u << SORT_LO_BITS) - 1;
 __global__ void __launch_bounds__(1024)
 k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_base, uint32_t* offsets, uint32_t* svals)
 {
     __shared__ uint32_t hist[1 << SORT_LO_BITS];
     __shared__ uint32_t off[1 << SORT_LO_BITS];
+    __shared__ uint32_t stage[SORTB_CAP];
     const int tid = threadIdx.x;
     const uint32_t h = blockIdx.x;
     const uint32_t pb = part_base[h], pe = part_base[h + 1];
     const uint32_t len = pe - pb;
+    const bool fast = len <= (uint32_t)SORTB_CAP;
     if (tid < (1 << SORT_LO_BITS)) hist[tid] = 0;
     __syncthreads();
+    uint64_t e[SORTB_PER_THREAD];
     constexpr uint32_t CHUNK = 1024 * SORTB_UNROLL;
-    const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loop (lds_take is wave-cooperative)
-    for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
-        uint32_t key[SORTB_UNROLL];
+    const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loops (lds_take is wave-cooperative)
+    if (fast) {
 #pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) {
-            const uint32_t q = q0 + u * 1024 + tid;
-            const uint32_t k = (uint32_t)(entries[pb + (q < len ? q : 0u)] >> 32); // unconditional: the loads batch up
-            key[u] = q < len ? k : 0xffffffffu;
+        for (int u = 0; u < SORTB_PER_THREAD; u++) {
+            const uint32_t q = u * 1024 + tid;
+            const uint64_t v = entries[pb + (q < len ? q : 0u)]; // unconditional: the loads batch up
+            e[u] = q < len ? v : ~0ull;
         }
 #pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) lds_take(hist, key[u] & 127u, key[u] != 0xffffffffu);
+        for (int u = 0; u < SORTB_PER_THREAD; u++) lds_take(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
+    } else {
+        for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
+            uint32_t key[SORTB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) {
+                const uint32_t q = q0 + u * 1024 + tid;
+                const uint32_t k = (uint32_t)(entries[pb + (q < len ? q : 0u)] >> 32);
+                key[u] = q < len ? k : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) lds_take(hist, key[u] & SORT_LO_MASK, key[u] != 0xffffffffu);
+        }
     }
     __syncthreads();
-    if (tid < 64) { // exclusive scan of the 128 counters by one wave: two counters per lane
-        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
-        uint32_t incl = c0 + c1;
+    if (tid < 64) { // exclusive scan of the counters by one wave
+        const uint32_t c = tid < (1 << SORT_LO_BITS) ? hist[tid] : 0u;
+        uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(incl, d);
             if (tid >= d) incl += t;
         }
-        const uint32_t excl = incl - (c0 + c1);
-        off[2 * tid] = excl;
-        off[2 * tid + 1] = excl + c0;
-    }
-    __syncthreads();
-    if (tid < (1 << SORT_LO_BITS)) {
-        const uint32_t bucket = (h << SORT_LO_BITS) + tid;
-        if (bucket <= MSM_BUCKETS) offsets[bucket] = pb + off[tid];
-    }
-    __syncthreads();
-    for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
-        uint64_t e[SORTB_UNROLL];
-#pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) {
-            const uint32_t q = q0 + u * 1024 + tid;
-            const uint64_t v = entries[pb + (q < len ? q : 0u)];
-            e[u] = q < len ? v : ~0ull;
+        if (tid < (1 << SORT_LO_BITS)) {
+            off[tid] = incl - c;
+            const uint32_t bucket = (h << SORT_LO_BITS) + tid;
+            if (bucket <= MSM_BUCKETS) offsets[bucket] = pb + incl - c;
         }
+    }
+    __syncthreads();
+    if (fast) {
 #pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) {
+        for (int u = 0; u < SORTB_PER_THREAD; u++) {
             const bool on = e[u] != ~0ull;
-            const uint32_t pos = lds_take(off, (uint32_t)(e[u] >> 32) & 127u, on);
-            if (on) svals[pb + pos] = (uint32_t)e[u];
+            const uint32_t pos = lds_take(off, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, on);
+            if (on) stage[pos] = (uint32_t)e[u];
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < len; q += 1024) svals[pb + q] = stage[q];
+    } else {
+        for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
+            uint64_t x[SORTB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) {
+                const uint32_t q = q0 + u * 1024 + tid;
+                const uint64_t v = entries[pb + (q < len ? q : 0u)];
+                x[u] = q < len ? v : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) {
+                const bool on = x[u] != ~0ull;
+                const uint32_t pos = lds_take(off, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, on);
+                if (on) svals[pb + pos] = (uint32_t)x[u];
+            }
         }
     }
 }
@@ -771,7 +811,7 @@ static int msm_layout(size_t n, MsmLayout& L)
     L.off_vals0 = take(L.entries * 4);
     L.off_vals1 = take(L.entries * 4);
     L.off_sort = take(L.sort_bytes);
-    L.off_parts = take(3 * 512 * 4);
+    L.off_parts = take(3 * SORT_PAD * 4);
     for (int k = 0; k < 2; k++) {
         L.off_offsets[k] = take((MSM_BUCKETS + 2) * 4);
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
@@ -866,14 +906,14 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
         // fused recode + MSD partition sort (keys0 area = 64-bit entries, vals0 = final values, keys1 head = partition tables)
         uint64_t* entries = (uint64_t*)keys0; // keys0 and keys1 are adjacent: 2 x 4 x 16n bytes = 8 x 16n
         uint32_t* part_count = (uint32_t*)(base + L.off_parts);
-        uint32_t* part_base = part_count + 512;
-        uint32_t* cursor = part_count + 1024;
+        uint32_t* part_base = part_count + SORT_PAD;
+        uint32_t* cursor = part_count + 2 * SORT_PAD;
         const int nblk = grid_for(n, SORT_BLOCK);
         {
             ProfScope ps(ctx, "msm_recode", st);
-            BBG_HIP(hipMemsetAsync(part_count, 0, 512 * 4, st));
+            BBG_HIP(hipMemsetAsync(part_count, 0, SORT_PAD * 4, st));
             hipLaunchKernelGGL(k_sortA_count, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
-            hipLaunchKernelGGL(k_sortA_scan, dim3(1), dim3(512), 0, st, part_count, part_base, cursor, offsets);
+            hipLaunchKernelGGL(k_sortA_scan, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets);
         }
         {
             ProfScope ps(ctx, "msm_sort", st);
