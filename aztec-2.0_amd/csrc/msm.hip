@@ -595,9 +595,11 @@ __device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
     return r;
 }
 
-// Latency-oriented variant of k_combine: 8 adjacent lanes share a bucket, each sums every 8th piece, then a 3-level
-// butterfly over the lane group (a bucket of ~512 entries has ~9 pieces: the serial chain drops from 8 additions to 4).
-constexpr int MSM_COMBINE_LANES = 8;
+// Latency-oriented variant of k_combine: MSM_COMBINE_LANES adjacent lanes share a bucket, each sums every 4th piece, then
+// a butterfly over the lane group (a bucket of ~512 entries has ~9 pieces: the serial chain drops from 8 additions to
+// 5).  4 lanes, not 8: the butterfly runs in lock-step on every lane, and with 8 the reduce phase (which shares the chip
+// with the next MSM's accumulation) cost 40 lane-additions per bucket instead of 17 -- 5 % of the pipelined step time.
+constexpr int MSM_COMBINE_LANES = 4;
 __global__ void __launch_bounds__(256, 1)
 k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
