@@ -95,7 +95,7 @@ __device__ __forceinline__ Xyzz xyzz_dbl_affine(const Affine& p)
     Fq M = fe_add(fe_dbl(xx), xx);
     Xyzz r;
     r.x = fe_sub(fe_sqr(M), fe_dbl(S));
-    r.y = fe_sub(fe_mul(M, fe_sub(S, r.x)), fe_mul(W, p.y));
+    r.y = fe_mul_sub2(M, fe_sub(S, r.x), W, p.y);
     r.zz = V;
     r.zzz = W;
     return r;
@@ -112,7 +112,7 @@ __device__ __forceinline__ Xyzz xyzz_dbl(const Xyzz& p)
     Fq M = fe_add(fe_dbl(xx), xx);
     Xyzz r;
     r.x = fe_sub(fe_sqr(M), fe_dbl(S));
-    r.y = fe_sub(fe_mul(M, fe_sub(S, r.x)), fe_mul(W, p.y));
+    r.y = fe_mul_sub2(M, fe_sub(S, r.x), W, p.y);
     r.zz = fe_mul(V, p.zz);
     r.zzz = fe_mul(W, p.zzz);
     return r;
@@ -136,7 +136,7 @@ __device__ __forceinline__ Xyzz xyzz_madd(const Xyzz& a, const Affine& p)
     Fq Q = fe_mul(a.x, PP);
     Xyzz r;
     r.x = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    r.y = fe_sub(fe_mul(R, fe_sub(Q, r.x)), fe_mul(a.y, PPP));
+    r.y = fe_mul_sub2(R, fe_sub(Q, r.x), a.y, PPP);
     r.zz = fe_mul(a.zz, PP);
     r.zzz = fe_mul(a.zzz, PPP);
     return r;
@@ -161,7 +161,7 @@ __device__ __forceinline__ Xyzz xyzz_add(const Xyzz& a, const Xyzz& b)
     Fq Q = fe_mul(U1, PP);
     Xyzz r;
     r.x = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    r.y = fe_sub(fe_mul(R, fe_sub(Q, r.x)), fe_mul(S1, PPP));
+    r.y = fe_mul_sub2(R, fe_sub(Q, r.x), S1, PPP);
     r.zz = fe_mul(fe_mul(a.zz, b.zz), PP);
     r.zzz = fe_mul(fe_mul(a.zzz, b.zzz), PPP);
     return r;

@@ -264,6 +264,60 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul(const Fe<P>& a, const
     return r;
 }
 
+// a*b - c*d with ONE Montgomery reduction (the Y3 = R(Q - X3) - Y1*PPP shape of every XYZZ group law): both products
+// are accumulated column by column before the m*p terms, saving the 64 + 8 multiply-adds of a second reduction.
+// c is negated first (2p - c <= 2p), so T = a*b + (2p - c)*d <= 8p^2 and (T + m*p)/R < p*(8p/R + 1) = 2.52p < 2^256:
+// one conditional subtraction of 2p restores the coarse range [0,2p).
+template <class P, int K> __device__ __forceinline__ void fips2_low_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b,
+                                                                          const uint32_t* c, const uint32_t* d, uint32_t* m)
+{
+    mac_col_v<K + 1>(acc, c2, a, b + K);
+    mac_col_v<K + 1>(acc, c2, c, d + K);
+    if constexpr (K > 0) mac_col_mod<P, K, K>(acc, c2, m);
+    m[K] = (uint32_t)acc * P::INV;
+    mac1_s(acc, c2, m[K], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+    c2 = 0;
+}
+template <class P, int K> __device__ __forceinline__ void fips2_high_column(uint64_t& acc, uint32_t& c2, const uint32_t* a, const uint32_t* b,
+                                                                           const uint32_t* c, const uint32_t* d, const uint32_t* m, uint32_t* r)
+{
+    if constexpr (K < 15) {
+        mac_col_v<15 - K>(acc, c2, a + (K - 7), b + 7);
+        mac_col_v<15 - K>(acc, c2, c + (K - 7), d + 7);
+        mac_col_mod<P, 15 - K, 7>(acc, c2, m + (K - 7));
+    }
+    r[K - 8] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+    c2 = 0;
+}
+template <class P> __device__ __forceinline__ Fe<P> fe_mul_sub2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d)
+{
+    const Fe<P> nc = fe_neg(c);
+    uint64_t acc = 0;
+    uint32_t c2 = 0;
+    uint32_t m[8];
+    Fe<P> r;
+    fips2_low_column<P, 0>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 1>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 2>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 3>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 4>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 5>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 6>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_low_column<P, 7>(acc, c2, a.v, b.v, nc.v, d.v, m);
+    fips2_high_column<P, 8>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 9>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 10>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 11>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 12>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 13>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 14>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    fips2_high_column<P, 15>(acc, c2, a.v, b.v, nc.v, d.v, m, r.v);
+    asm_reduce_once<BBG_K8(P::NEG2P)>(r.v); // r - 2p if r >= 2p
+    return r;
+}
+
 // Reference formulation kept for cross-checking the asm path in tests (CIOS over 32-bit limbs;
 // running value T < 3p < 2^256 after each row, so 9 words suffice).
 template <class P> __device__ __forceinline__ Fe<P> fe_mul_cios(const Fe<P>& a, const Fe<P>& b)

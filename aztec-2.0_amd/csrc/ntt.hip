@@ -794,6 +794,8 @@ template <class P> __global__ void k_field_op(int op, const Fe<P>* a, const Fe<P
     case 3: z = fe_mul_cios(x, y); break;
     case 4: z = fe_from_mont(x); break;
     case 5: z = fe_to_mont(x); break;
+    case 8: z = fe_mul_sub2(x, x, y, y); break;                       // x^2 - y^2, single reduction
+    case 9: z = fe_mul_sub2(fe_neg(x), fe_neg(y), x, fe_neg(y)); break; // extreme operands (2p - x ...): = 2xy
     default: z = x; break;
     }
     fe_store<P>(out + i, fe_reduce_once(z));

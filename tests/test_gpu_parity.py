@@ -30,6 +30,11 @@ def test_field_ops(pkg, oracle, bbg, which):
     assert np.array_equal(bbg.field_op(which, 2, a, b), oracle.fe_sub(which, a, b))
     assert np.array_equal(bbg.field_op(which, 4, a), oracle.from_mont(which, a))
     assert np.array_equal(bbg.field_op(which, 5, a), oracle.to_mont(which, a))
+    # fused two-product multiplier a*b - c*d (one Montgomery reduction; used by every XYZZ group law)
+    sq = oracle.fe_sub(which, oracle.fe_mul(which, a, a), oracle.fe_mul(which, b, b))
+    assert np.array_equal(bbg.field_op(which, 8, a, b), sq)
+    ab = oracle.fe_mul(which, a, b)
+    assert np.array_equal(bbg.field_op(which, 9, a, b), oracle.fe_add(which, ab, ab))
 
 
 def test_field_reference_kats(bbg, oracle, kats):
