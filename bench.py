@@ -32,12 +32,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MAD_PEAK_TOPS = 28.0           # measured v_mad_u64_u32 issue rate, bench_micro/mulbench.hip (profiles/r01_mulbench.txt)
 
 
+def _latest_pmc_profile():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_v*.txt")))
+    return files[-1] if files else os.path.join(ROOT, "profiles", "r01_pmc_v2.txt")
+
+
+PMC_PROFILE = _latest_pmc_profile()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_pmc_v2.txt: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command; KiB per dispatch).  MI355X_MICROARCH.md's gfx950
     correction (FETCH_SIZE x2) applies to wide coalesced streams; k_accumulate's traffic is 64-byte gathers, for which the
     counter is uncalibrated, so the raw sum is reported.  None when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_v2.txt")
+    path = PMC_PROFILE
     try:
         tot = 0.0
         for line in open(path):
@@ -151,7 +160,7 @@ def main():
     achieved = alg_bytes_msm / (acc_ms * 1e-3) / 1e9
     roofline = {"kernel": "k_accumulate (MSM bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("k_accumulate"),
-                "traffic_source": "profiles/r01_pmc_v2.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
+                "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
     pass_ms = avg("ntt_pass")

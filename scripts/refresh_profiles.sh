@@ -1,0 +1,35 @@
+#!/bin/bash
+# Regenerates the rocprofv3 summaries committed under profiles/ (run on the GPU box through gpurun; writes gpurun_out/).
+#   gpurun --timeout 900 -- 'bash scripts/refresh_profiles.sh v3'
+# Pass 1: --kernel-trace of the default bench command.  Passes 2-4: PMC counters, one group per run, never combined with
+# other trace domains (MI355X_MICROARCH.md HBM section; gpurun refuses combined runs).
+set -u
+TAG=${1:-v3}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace -d /tmp/prof_kt -o bench -- $BENCH > /tmp/bench_kt.log 2>&1
+{
+  echo "# rocprofv3 --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, round 1, build $TAG)"
+  echo "# durations include overlap: the MSM reduce kernels (k_combine8 .. k_final_sum) run on an auxiliary stream beside the next step"
+  echo "# bench line of this run:"
+  grep "^{\"metric\"" /tmp/bench_kt.log | tail -1
+  echo
+  python $ROOT/scripts/rocpd_summary.py kernels $(find /tmp/prof_kt -name "*_results.db" | head -1)
+} > $OUT/r01_kernel_stats_$TAG.txt
+PMCBENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+DBS=""
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_ANY"; do
+  d=/tmp/prof_pmc_$(echo $grp | cut -d' ' -f1)
+  rm -rf $d && rocprofv3 --pmc $grp -d $d -o bench -- $PMCBENCH > $d.log 2>&1
+  DBS="$DBS $(find $d -name '*_results.db' | head -1)"
+done
+{
+  echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (build $TAG)"
+  echo "# FETCH_SIZE/WRITE_SIZE in KiB per dispatch as reported (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced streams 2x on gfx950; uncalibrated for 64-B gathers)"
+  python $ROOT/scripts/rocpd_summary.py pmc $DBS
+} > $OUT/r01_pmc_$TAG.txt
+head -25 $OUT/r01_kernel_stats_$TAG.txt | cut -c1-200
+grep -c . $OUT/r01_pmc_$TAG.txt
