@@ -32,7 +32,9 @@ int ensure_buffer(void** buf, size_t* have, size_t need)
     *have = need;
     return BBG_OK;
 }
-int srs_build_tables(const void* d_points, size_t n, void* d_table, hipStream_t st);
+int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st);
+int msm_pick_window(const bbg_ctx* ctx, size_t n);
+int msm_windows_for(int c);
 int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st);
 
 static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs** out)
@@ -42,19 +44,24 @@ static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs*
     s->s.n = n;
     s->s.device = ctx->device;
     if (n) {
-        hipError_t e = hipMalloc(&s->s.points, n * 16 * 64);
+        // window tables of the width a full-size MSM over this SRS will use; the other width is built on demand (msm_run)
+        const int c = msm_pick_window(ctx, n);
+        void* table = nullptr;
+        hipError_t e = hipMalloc(&table, n * (size_t)msm_windows_for(c) * 64);
         if (e != hipSuccess) {
             delete s;
             return hip_fail(e, "hipMalloc(SRS window tables)", __FILE__, __LINE__);
         }
-        int rc = srs_build_tables(d_plain_points, n, s->s.points, ctx->stream);
+        int rc = srs_build_tables(d_plain_points, n, table, c, ctx->stream);
         if (rc == BBG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = hip_fail(hipGetLastError(), "SRS table build", __FILE__, __LINE__);
         if (rc) {
-            (void)hipFree(s->s.points);
+            (void)hipFree(table);
             delete s;
             return rc;
         }
+        s->s.points = table; // window 0 = the plain points
+        (c == 20 ? s->s.table20 : s->s.table16) = table;
     }
     *out = s;
     return BBG_OK;
@@ -176,6 +183,11 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     if (!strcmp(key, "msm_async_reduce")) {
         BBG_HIP(hipDeviceSynchronize());
         ctx->msm_async_reduce = value != 0;
+        return BBG_OK;
+    }
+    if (!strcmp(key, "msm_window")) {
+        if (value != 0 && value != 16 && value != 20) { set_error("msm_window must be 0 (automatic), 16 or 20"); return BBG_E_INVALID; }
+        ctx->msm_window = (int)value;
         return BBG_OK;
     }
     if (!strcmp(key, "msm_sort")) {
@@ -393,7 +405,8 @@ void bbg_srs_free(bbg_srs* srs)
     if (!srs) return;
     (void)hipSetDevice(srs->ctx->device);
     (void)hipDeviceSynchronize();
-    if (srs->s.points) (void)hipFree(srs->s.points);
+    if (srs->s.table16) (void)hipFree(srs->s.table16);
+    if (srs->s.table20) (void)hipFree(srs->s.table20);
     delete srs;
 }
 

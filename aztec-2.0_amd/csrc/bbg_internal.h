@@ -43,7 +43,9 @@ struct NttDomain {
 // ---------------------------------------------------------------------------------------------- MSM
 struct Srs {
     size_t n = 0;          // number of (plain) points
-    void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical
+    void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical (= window 0 of a table below)
+    void* table16 = nullptr; // window tables T[w][i] = 2^(16 w) P_i, 16 x n points (msm.hip); built on first use
+    void* table20 = nullptr; // window tables T[w][i] = 2^(20 w) P_i, 13 x n points
     int device = 0;
 };
 
@@ -83,6 +85,7 @@ struct bbg_ctx {
     bool ev_done_valid[2] = { false, false };
     unsigned long msm_seq = 0;
     bool msm_async_reduce = false;
+    int msm_window = 0; // 0 = automatic (20 from n = 2^22, else 16), or 16 / 20
     int msm_sort = 1; // 1 = fused recode + MSD partition sort (msm.hip), 0 = k_recode + rocPRIM radix sort + k_offsets
     int ntt_tile_log = 10; // log2(elements per LDS tile); 10/7 measured best on MI355X (profiles/r01_ntt_plan_sweep.txt)
     int ntt_max_logr = 7;
@@ -132,7 +135,7 @@ int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t
 int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hipStream_t stream);
 int ntt_cross_dft(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse, hipStream_t stream);
 int field_op_device(int which, int op, const void* a, const void* b, void* out, size_t n, hipStream_t stream);
-int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
+int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
             hipStream_t stream);
 int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
 int msm_join(bbg_ctx* ctx, hipStream_t stream);

@@ -32,18 +32,30 @@
 
 namespace bbg {
 
-constexpr int MSM_WINDOWS = 16;     // 16-bit windows over a 254-bit scalar
-constexpr int MSM_C = 16;
-constexpr int MSM_BUCKETS = 1 << 15; // |digit| in [1, 2^15]
+// Window width C is a per-call choice between two compiled configurations (msm_pick_window): C = 16 (16 windows, 2^15
+// buckets) and C = 20 (13 windows, 2^19 buckets).  Wider windows trade 19 % of the mixed additions for a 16x larger
+// bucket reduction, which pays from n = 2^22 upwards.  Each width has its own window tables T[w][i] = 2^(C w) P_i.
+template <int C> struct MsmCfg {
+    static constexpr int c = C;
+    static constexpr int windows = (254 + C) / C;      // C * windows >= 255: 254 scalar bits + the recoding carry
+    static constexpr int buckets = 1 << (C - 1);       // |digit| in [1, 2^(C-1)]
+    static constexpr int lo_bits = C - 11;             // sort partitions = buckets >> lo_bits (+1) = 1025
+    static constexpr int parts = (buckets >> lo_bits) + 1;
+    static constexpr int log_cols = C / 2;             // bucket index (0-based) = hi * cols + lo
+    static constexpr int log_rows = C - 1 - log_cols;
+    static constexpr int planes = C - 1;               // bit planes of the weight idx + 1 <= 2^(C-1)
+};
+constexpr int MSM_MAX_WINDOWS = 16;
 constexpr int MSM_IDX_BITS = 26;     // point index bits in an entry value (n <= 2^26 per call)
 
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
 // ---------------------------------------------------------------------------------- SRS precomputation
-// table[w * n + i] = 2^(16 w) * P_i (affine, canonical).  One thread per point: 15 x 16 doublings in XYZZ,
-// then one shared inversion (Montgomery's trick over the 15 Z-products) to normalise.
-__global__ void __launch_bounds__(128) k_precompute_tables(const Affine* __restrict__ points, Affine* table, size_t n)
+// table[w * n + i] = 2^(C w) * P_i (affine, canonical).  One thread per point: (windows - 1) x C doublings in XYZZ,
+// then one shared inversion (Montgomery's trick over the Z-products) to normalise.
+template <int C> __global__ void __launch_bounds__(128) k_precompute_tables(const Affine* __restrict__ points, Affine* table, size_t n)
 {
+    constexpr int MSM_WINDOWS = MsmCfg<C>::windows, MSM_C = C;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine p = aff_load(points + i);
@@ -173,27 +185,40 @@ __global__ void __launch_bounds__(128) k_srs_hashed(Affine* out, size_t n, uint6
 // Replaces compute_wnaf_states + fixed_wnaf_with_counts (scalar_multiplication.cpp:188-252, wnaf.hpp:230-283):
 // same idea (signed windows halve the bucket count), but plain signed digits with carry instead of the
 // odd-digit + skew form, and zero digits produce no work.
-__global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* keys,
-                                                uint32_t* vals)
+// from_montgomery = Montgomery product with the integer 1: (s + m*r) / 2^256 <= r for ANY 256-bit s, so one conditional
+// subtraction canonicalises (from_montgomery_form, field_impl.hpp:245-255).  Top window: k < 2^254, so the last digit
+// is < 2^14 + 1 and never produces a carry.
+template <int C>
+__device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, size_t i, uint32_t (&mag)[MSM_MAX_WINDOWS], uint32_t& signs)
+{
+    const Fr k = fe_from_mont(fe_load<FrP>(scalars + i)); // canonical integer < r < 2^254
+    uint32_t carry = 0;
+    signs = 0;
+#pragma unroll
+    for (int w = 0; w < MsmCfg<C>::windows; w++) {
+        constexpr uint32_t FULL = 1u << C, HALF = 1u << (C - 1);
+        const int bit = w * C, limb = bit >> 5, sh = bit & 31;
+        uint64_t two = k.v[limb];
+        if (limb + 1 < 8) two |= (uint64_t)k.v[limb + 1] << 32;
+        const uint32_t d = ((uint32_t)(two >> sh) & (FULL - 1)) + carry; // 0 .. 2^C
+        const uint32_t neg = d > HALF;
+        mag[w] = neg ? (FULL - d) : d; // |digit| in [0, 2^(C-1)]
+        carry = neg;
+        signs |= neg << w;
+    }
+}
+template <int C>
+__global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* keys, uint32_t* vals)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr s = fe_load<FrP>(scalars + i);
-    // from_montgomery = Montgomery product with the integer 1: (s + m*r) / 2^256 <= r for ANY 256-bit s, so one
-    // conditional subtraction canonicalises (from_montgomery_form, field_impl.hpp:245-255)
-    Fr k = fe_from_mont(s); // canonical integer < r < 2^254
-    uint32_t carry = 0;
+    uint32_t mag[MSM_MAX_WINDOWS], signs;
+    recode_digits<C>(scalars, i, mag, signs);
 #pragma unroll
-    for (int w = 0; w < MSM_WINDOWS; w++) {
-        uint32_t limb = k.v[w >> 1];
-        uint32_t d = ((w & 1) ? (limb >> 16) : (limb & 0xffffu)) + carry; // 0 .. 2^16
-        uint32_t neg = d > 0x8000u;
-        uint32_t mag = neg ? (0x10000u - d) : d; // |digit| in [0, 2^15]
-        carry = neg;
-        keys[(size_t)w * n + i] = mag;
-        vals[(size_t)w * n + i] = (neg << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
+    for (int w = 0; w < MsmCfg<C>::windows; w++) {
+        keys[(size_t)w * n + i] = mag[w];
+        vals[(size_t)w * n + i] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
     }
-    // top window: k < 2^254 so the last digit is < 2^14 + 1 and never produces a carry
 }
 
 // ---------------------------------------------------------------------------------- fused recode + two-level partition sort
@@ -209,10 +234,8 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, 
 // Digits are recomputed instead of stored (one Montgomery product per scalar is cheaper than 2 x 34 MiB of traffic).
 // Order inside a bucket is arbitrary (atomics), so the Jacobian REPRESENTATIVE of an MSM result may differ between runs;
 // the point it denotes does not (the reference's representative likewise depends on its thread count).
-constexpr int SORT_LO_BITS = 5;
-constexpr int SORT_PARTS = (MSM_BUCKETS >> SORT_LO_BITS) + 1; // 1025: hi in [0, 1024]
-constexpr int SORT_PAD = 2048;                                 // table size (power of two >= SORT_PARTS)
-constexpr int SORT_BLOCK = 1024;                               // scalars per block in the A kernels
+constexpr int SORT_PAD = 2048;   // partition table size (power of two >= MsmCfg::parts = 1025)
+constexpr int SORT_BLOCK = 1024; // scalars per block in the A kernels
 
 // LDS counter bump that stays fast when a whole wave hits one counter (all-equal scalars): one atomic per wave then.
 // Inactive lanes are masked off (no traffic); returns the lane's rank within the counter.
@@ -235,22 +258,6 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* ctr, uint32_t key, bool a
     return r;
 }
 
-__device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, size_t i, uint32_t (&mag)[MSM_WINDOWS], uint32_t& signs)
-{
-    const Fr k = fe_from_mont(fe_load<FrP>(scalars + i));
-    uint32_t carry = 0;
-    signs = 0;
-#pragma unroll
-    for (int w = 0; w < MSM_WINDOWS; w++) {
-        const uint32_t limb = k.v[w >> 1];
-        const uint32_t d = ((w & 1) ? (limb >> 16) : (limb & 0xffffu)) + carry;
-        const uint32_t neg = d > 0x8000u;
-        mag[w] = neg ? (0x10000u - d) : d;
-        carry = neg;
-        signs |= neg << w;
-    }
-}
-
 // exclusive scan of tbl[0 .. SORT_PAD) by a 1024-thread block, two adjacent entries per thread; returns the pair's
 // exclusive prefixes.  wsum = 16 words of LDS scratch.
 __device__ __forceinline__ void block_scan_pairs(const uint32_t* tbl, uint32_t* wsum, uint32_t& excl0, uint32_t& c0, uint32_t& c1)
@@ -271,16 +278,17 @@ __device__ __forceinline__ void block_scan_pairs(const uint32_t* tbl, uint32_t* 
     excl0 = before + incl - (c0 + c1);
 }
 
-__global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
+template <int C> __global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
 {
+    constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
     __shared__ uint32_t hist[SORT_PAD];
     const int tid = threadIdx.x;
     hist[tid] = 0;
     hist[tid + 1024] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
-    uint32_t mag[MSM_WINDOWS], signs;
-    if (i < n) recode_digits(scalars, i, mag, signs);
+    uint32_t mag[MSM_MAX_WINDOWS], signs;
+    if (i < n) recode_digits<C>(scalars, i, mag, signs);
 #pragma unroll
     for (int w = 0; w < MSM_WINDOWS; w++) {
         const bool on = i < n && mag[w] != 0; // zero digits contribute nothing: never sorted
@@ -291,8 +299,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict
         if (hist[h]) atomicAdd(&part_count[h], hist[h]);
 }
 // part_base[h] = sum_{h' < h} count[h'] ; cursor[h] = part_base[h] ; offsets[MSM_BUCKETS + 1] = total
+template <int C>
 __global__ void __launch_bounds__(1024) k_sortA_scan(const uint32_t* __restrict__ part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets)
 {
+    constexpr int SORT_PARTS = MsmCfg<C>::parts, MSM_BUCKETS = MsmCfg<C>::buckets;
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x;
     uint32_t excl, c0, c1;
@@ -305,26 +315,27 @@ __global__ void __launch_bounds__(1024) k_sortA_scan(const uint32_t* __restrict_
     if (h0 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl;
     if (h1 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl + c0;
 }
-// The block's <= 16 Ki entries are first grouped by partition in LDS (values + 16-bit bucket ids, 96 KiB) and then written
+// The block's <= 16 Ki entries are first grouped by partition in LDS (values + bucket ids, 128 KiB) and then written
 // out with consecutive threads on consecutive addresses: every (block, partition) chunk is one contiguous burst instead
 // of independent 8-byte stores issued at random times.
-__global__ void __launch_bounds__(SORT_BLOCK)
+template <int C> __global__ void __launch_bounds__(SORT_BLOCK)
 k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* cursor, uint64_t* entries)
 {
+    constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
     constexpr int CAP = SORT_BLOCK * MSM_WINDOWS;
     __shared__ uint32_t hist[SORT_PAD];   // per-partition count, then rank counter
     __shared__ uint32_t lstart[SORT_PAD]; // first LDS slot of each partition
     __shared__ uint32_t gbase[SORT_PAD];  // this block's first global slot in each partition, minus lstart
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t st_val[CAP];
-    __shared__ uint16_t st_mag[CAP];
+    __shared__ uint32_t st_mag[CAP];
     const int tid = threadIdx.x;
     hist[tid] = 0;
     hist[tid + 1024] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
-    uint32_t mag[MSM_WINDOWS], signs = 0;
-    if (i < n) recode_digits(scalars, i, mag, signs);
+    uint32_t mag[MSM_MAX_WINDOWS], signs = 0;
+    if (i < n) recode_digits<C>(scalars, i, mag, signs);
 #pragma unroll
     for (int w = 0; w < MSM_WINDOWS; w++) {
         const bool on = i < n && mag[w] != 0;
@@ -352,7 +363,7 @@ k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t*
         if (on) {
             const uint32_t slot = lstart[h] + rank;
             st_val[slot] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
-            st_mag[slot] = (uint16_t)mag[w];
+            st_mag[slot] = mag[w];
         }
     }
     __syncthreads();
@@ -366,22 +377,25 @@ k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t*
 // One block per partition.  Fast path (partition <= SORTB_CAP entries, the normal case up to n = 2^20): entries are
 // read once into registers, ranked with LDS counters, staged in LDS in bucket order and written out coalesced.  Larger
 // partitions (bigger n, skewed digits) take two passes over global memory with scattered 4-byte stores.
-constexpr int SORTB_PER_THREAD = 19;
-constexpr int SORTB_CAP = SORTB_PER_THREAD * 1024; // 76 KiB of staging: two blocks per CU
+constexpr int SORTB_PER_THREAD = 18;
+constexpr int SORTB_CAP = SORTB_PER_THREAD * 1024; // 72 KiB of staging (+ up to 4 KiB of counters): two blocks per CU
 constexpr int SORTB_UNROLL = 8;
-constexpr uint32_t SORT_LO_MASK = (1u << SORT_LO_BITS) - 1;
-__global__ void __launch_bounds__(1024)
+template <int C> __global__ void __launch_bounds__(1024)
 k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_base, uint32_t* offsets, uint32_t* svals)
 {
-    __shared__ uint32_t hist[1 << SORT_LO_BITS];
-    __shared__ uint32_t off[1 << SORT_LO_BITS];
+    constexpr int SORT_LO_BITS = MsmCfg<C>::lo_bits, MSM_BUCKETS = MsmCfg<C>::buckets, BINS = 1 << SORT_LO_BITS;
+    constexpr uint32_t SORT_LO_MASK = BINS - 1;
+    static_assert(BINS <= 1024, "one thread per bin");
+    __shared__ uint32_t hist[BINS];
+    __shared__ uint32_t off[BINS];
+    __shared__ uint32_t wsum[16];
     __shared__ uint32_t stage[SORTB_CAP];
     const int tid = threadIdx.x;
     const uint32_t h = blockIdx.x;
     const uint32_t pb = part_base[h], pe = part_base[h + 1];
     const uint32_t len = pe - pb;
     const bool fast = len <= (uint32_t)SORTB_CAP;
-    if (tid < (1 << SORT_LO_BITS)) hist[tid] = 0;
+    if (tid < BINS) hist[tid] = 0;
     __syncthreads();
     uint64_t e[SORTB_PER_THREAD];
     constexpr uint32_t CHUNK = 1024 * SORTB_UNROLL;
@@ -409,18 +423,23 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
         }
     }
     __syncthreads();
-    if (tid < 64) { // exclusive scan of the counters by one wave
-        const uint32_t c = tid < (1 << SORT_LO_BITS) ? hist[tid] : 0u;
+    { // exclusive scan of the BINS counters (one per thread, wave scans + 16 wave totals)
+        const uint32_t c = tid < BINS ? hist[tid] : 0u;
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(incl, d);
-            if (tid >= d) incl += t;
+            if ((tid & 63) >= d) incl += t;
         }
-        if (tid < (1 << SORT_LO_BITS)) {
-            off[tid] = incl - c;
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
+        if (tid < BINS) {
+            const uint32_t excl = before + incl - c;
+            off[tid] = excl;
             const uint32_t bucket = (h << SORT_LO_BITS) + tid;
-            if (bucket <= MSM_BUCKETS) offsets[bucket] = pb + incl - c;
+            if (bucket <= (uint32_t)MSM_BUCKETS) offsets[bucket] = pb + excl;
         }
     }
     __syncthreads();
@@ -453,8 +472,9 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
 }
 
 // offsets[b] = first sorted position with key >= b, for b = 0 .. MSM_BUCKETS + 1
-__global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint32_t* offsets)
+template <int C> __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint32_t* offsets)
 {
+    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e > total) return;
     if (e == total) {
@@ -482,7 +502,7 @@ __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint3
 //   buckets[b]  : runs that start and end strictly inside the segment (complete buckets)
 // and k_combine adds head/tail pieces per bucket.  Values address the window tables: point = table[w*n_srs + idx],
 // negated when bit 31 is set.
-constexpr int MSM_SEG_LOG_MIN = 3, MSM_SEG_LOG_DEFAULT = 6; // segment length is chosen per call (msm_seg_log)
+constexpr uint32_t MSM_SEG_MIN = 8, MSM_SEG_DEFAULT = 64; // segment length is chosen per call (msm_seg_len)
 constexpr int MSM_LONG_SPAN = 48; // buckets spanning more lanes than this are summed by a whole block
 
 __device__ uint32_t g_debug_idx_mask = 0xffffffffu; // experiments only: confine the gathers to a cache-resident subset
@@ -491,17 +511,18 @@ __device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ ta
     return aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1) & g_debug_idx_mask));
 }
 
-__global__ void __launch_bounds__(256)
+template <int C> __global__ void __launch_bounds__(256)
 k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-             size_t n_srs, uint32_t seg_log, Xyzz* head, Xyzz* tail, Xyzz* buckets)
+             size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets)
 {
+    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
     const uint32_t total = offsets[MSM_BUCKETS + 1]; // the partition sort drops zero digits: the count lives on the device
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = offsets[1]; // entries with key 0 (zero digits) sort first and are skipped
-    const uint64_t s64 = (uint64_t)base + ((uint64_t)lane << seg_log);
+    const uint64_t s64 = (uint64_t)base + (uint64_t)lane * seg;
     if (s64 >= total) return;
     const uint32_t s = (uint32_t)s64;
-    const uint32_t e = (total - s > (1u << seg_log)) ? s + (1u << seg_log) : total;
+    const uint32_t e = (total - s > seg) ? s + seg : total;
     // bucket containing position s: largest b in [1, 2^15] with offsets[b] <= s
     uint32_t lo = 1, hi = MSM_BUCKETS;
     while (lo < hi) {
@@ -548,10 +569,11 @@ __device__ __forceinline__ Xyzz bucket_piece(const Xyzz* __restrict__ head, cons
 
 // buckets[b-1] = sum of the pieces of bucket b; complete ("middle") runs were already written by k_accumulate.
 // Buckets spanning more than MSM_LONG_SPAN lanes (skewed scalar distributions) are queued for k_combine_long.
-__global__ void __launch_bounds__(256, 1)
-k_combine(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+template <int C> __global__ void __launch_bounds__(256, 1)
+k_combine(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
+    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (b > MSM_BUCKETS) return;
@@ -561,10 +583,10 @@ k_combine(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __
         xyzz_store(buckets + (b - 1), xyzz_inf());
         return;
     }
-    const uint32_t l0 = (sb - base) >> seg_log, l1 = (eb - 1 - base) >> seg_log;
-    const bool at_start = (sb == base + (l0 << seg_log));
+    const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
+    const bool at_start = (sb == base + l0 * seg);
     if (l0 == l1) {
-        uint32_t seg_end = base + ((l0 + 1) << seg_log);
+        uint32_t seg_end = base + (l0 + 1) * seg;
         if (seg_end > total || seg_end < base) seg_end = total;
         if (at_start) xyzz_store(buckets + (b - 1), xyzz_load(head + l0));
         else if (eb == seg_end) xyzz_store(buckets + (b - 1), xyzz_load(tail + l0));
@@ -600,10 +622,11 @@ __device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
 // 5).  4 lanes, not 8: the butterfly runs in lock-step on every lane, and with 8 the reduce phase (which shares the chip
 // with the next MSM's accumulation) cost 40 lane-additions per bucket instead of 17 -- 5 % of the pipelined step time.
 constexpr int MSM_COMBINE_LANES = 4;
-__global__ void __launch_bounds__(256, 1)
-k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+template <int C> __global__ void __launch_bounds__(256, 1)
+k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
+    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / MSM_COMBINE_LANES + 1;
@@ -614,10 +637,10 @@ k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* _
     bool store = true, reduce = false;
     Xyzz acc = xyzz_inf();
     if (sb != eb) {
-        const uint32_t l0 = (sb - base) >> seg_log, l1 = (eb - 1 - base) >> seg_log;
-        const bool at_start = (sb == base + (l0 << seg_log));
+        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
+        const bool at_start = (sb == base + l0 * seg);
         if (l0 == l1) {
-            uint32_t seg_end = base + ((l0 + 1) << seg_log);
+            uint32_t seg_end = base + (l0 + 1) * seg;
             if (seg_end > total || seg_end < base) seg_end = total;
             if (at_start) acc = xyzz_load(head + l0);
             else if (eb == seg_end) acc = xyzz_load(tail + l0);
@@ -646,8 +669,8 @@ k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* _
 
 
 // one block per queued long bucket (grid-stride over the queue)
-__global__ void __launch_bounds__(256, 1)
-k_combine_long(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
+template <int C> __global__ void __launch_bounds__(256, 1)
+k_combine_long(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
                const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list)
 {
     __shared__ Xyzz sm[128];
@@ -656,8 +679,8 @@ k_combine_long(const uint32_t* __restrict__ offsets, uint32_t seg_log, const Xyz
     for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
         const uint32_t b = long_list[i];
         const uint32_t sb = offsets[b], eb = offsets[b + 1];
-        const uint32_t l0 = (sb - base) >> seg_log, l1 = (eb - 1 - base) >> seg_log;
-        const bool at_start = (sb == base + (l0 << seg_log));
+        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
+        const bool at_start = (sb == base + l0 * seg);
         Xyzz acc = xyzz_inf();
         for (uint32_t l = l0 + threadIdx.x; l <= l1; l += 256) acc = xyzz_add(acc, bucket_piece(head, tail, l, l0, at_start));
         acc = block_reduce(acc, sm, 256);
@@ -679,49 +702,57 @@ __device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads)
     return v;
 }
 
-// weight of bucket index idx (0-based) is idx + 1 = hi*256 + lo + 1.
-// blocks 0..127: Row_hi = sum_lo B[hi][lo] ; blocks 128..383: Col_lo = sum_hi B[hi][lo].
-__global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
+// weight of bucket index idx (0-based) is idx + 1 = hi*COLS + lo + 1  (COLS = 2^log_cols, ROWS = 2^log_rows).
+// blocks 0..ROWS-1: Row_hi = sum_lo B[hi][lo] ; blocks ROWS..ROWS+COLS-1: Col_lo = sum_hi B[hi][lo].
+template <int C> __global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
 {
+    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[128];
     const int tid = threadIdx.x;
-    if (blockIdx.x < 128) {
+    if (blockIdx.x < ROWS) {
         const int hi = blockIdx.x;
-        Xyzz v = xyzz_load(buckets + hi * 256 + tid);
+        Xyzz v = xyzz_load(buckets + (size_t)hi * COLS + tid);
+        for (int lo = tid + 256; lo < COLS; lo += 256) v = xyzz_add(v, xyzz_load(buckets + (size_t)hi * COLS + lo));
         v = block_reduce(v, sm, 256);
         if (tid == 0) xyzz_store(rows + hi, v);
     } else {
-        const int lo = blockIdx.x - 128;
-        Xyzz v = tid < 128 ? xyzz_load(buckets + tid * 256 + lo) : xyzz_inf();
+        const int lo = blockIdx.x - ROWS;
+        Xyzz v = xyzz_inf();
+        for (int hi = tid; hi < ROWS; hi += 256) v = xyzz_add(v, xyzz_load(buckets + (size_t)hi * COLS + lo));
         v = block_reduce(v, sm, 256);
         if (tid == 0) xyzz_store(cols + lo, v);
     }
 }
 
-// sum_b b*B_b = 256 * sum_hi hi*Row_hi + sum_lo (lo+1)*Col_lo = sum_t 2^t H_t with the bit planes
-//   H_t = sum_{lo : bit t of (lo+1)} Col_lo  +  sum_{hi : bit (t-8) of hi} Row_hi          (t = 0 .. 14).
-// One block per bit plane: tree-sum the selected rows/columns, then t doublings by one lane -- the 15 planes run side
-// by side, so the serial depth is 9 additions + 14 doublings instead of a 9-bit double-and-add on top of an 8-level tree
-// plus 8 more doublings.  k_final_sum adds the 15 planes and converts to the reference's Jacobian layout.
-constexpr int MSM_PLANES = 15;
-__global__ void __launch_bounds__(256, 1) k_final_planes(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Xyzz* planes)
+// sum_b b*B_b = COLS * sum_hi hi*Row_hi + sum_lo (lo+1)*Col_lo = sum_t 2^t H_t with the bit planes
+//   H_t = sum_{lo : bit t of (lo+1)} Col_lo  +  sum_{hi : bit (t - log_cols) of hi} Row_hi        (t = 0 .. C-2).
+// One block per bit plane: tree-sum the selected rows/columns, then t doublings by one lane -- the planes run side by
+// side, so the serial depth is ~9 additions + t doublings instead of a double-and-add on top of a tree plus log_cols more
+// doublings.  k_final_sum adds the planes and converts to the reference's Jacobian layout.
+template <int C> __global__ void __launch_bounds__(256, 1) k_final_planes(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Xyzz* planes)
 {
+    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols, LOGC = MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[128];
     const int t = blockIdx.x, tid = threadIdx.x;
     Xyzz v = xyzz_inf();
-    if (((tid + 1) >> t) & 1) v = xyzz_load(cols + tid);
-    if (t >= 8 && tid < 128 && ((tid >> (t - 8)) & 1)) v = xyzz_add(v, xyzz_load(rows + tid));
+    if (t <= LOGC)
+        for (int lo = tid; lo < COLS; lo += 256)
+            if (((lo + 1) >> t) & 1) v = xyzz_add(v, xyzz_load(cols + lo));
+    if (t >= LOGC)
+        for (int hi = tid; hi < ROWS; hi += 256)
+            if ((hi >> (t - LOGC)) & 1) v = xyzz_add(v, xyzz_load(rows + hi));
     v = block_reduce(v, sm, 256);
     if (tid == 0) {
         for (int k = 0; k < t; k++) v = xyzz_dbl(v);
         xyzz_store(planes + t, v);
     }
 }
-__global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ planes, Jacobian* out)
+constexpr int MSM_MAX_PLANES = 32;
+__global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ planes, int nplanes, Jacobian* out)
 {
-    __shared__ Xyzz sm[8];
-    Xyzz v = threadIdx.x < MSM_PLANES ? xyzz_load(planes + threadIdx.x) : xyzz_inf();
-    v = block_reduce(v, sm, 16);
+    __shared__ Xyzz sm[16];
+    Xyzz v = (int)threadIdx.x < nplanes ? xyzz_load(planes + threadIdx.x) : xyzz_inf();
+    v = block_reduce(v, sm, MSM_MAX_PLANES);
     if (threadIdx.x == 0) {
         Jacobian j = xyzz_to_jacobian(v);
         fe_store<FqP>(&out->x, j.x);
@@ -777,7 +808,7 @@ __global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ 
 struct MsmLayout {
     size_t entries, lanes;
     size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort, off_parts;
-    uint32_t seg_log;
+    uint32_t seg;
     // reduce-phase working set, double buffered so that the reduce of MSM i (aux stream) overlaps MSM i+1
     size_t off_offsets[2], off_head[2], off_tail[2], off_buckets[2], off_rows[2], off_cols[2], off_long[2];
     size_t sort_bytes;
@@ -785,25 +816,33 @@ struct MsmLayout {
 };
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Segment length (entries per accumulation lane).  64 at the headline size; shorter for small MSMs, whose run time is the
-// latency of one lane's serial chain of mixed additions (64 additions = 0.43 ms regardless of n), and longer for very
-// large ones so that a bucket spans <= ~32 lanes and k_combine8 (not the block-per-bucket fallback) sums its pieces.
-static uint32_t msm_seg_log(size_t entries)
+// Segment length (entries per accumulation lane).  Around 64 at the headline size; shorter for small MSMs, whose run time
+// is the latency of one lane's serial chain of mixed additions (64 additions = 0.43 ms regardless of n), and longer for
+// very large ones so that a bucket spans <= ~32 lanes and the lane-group combine (not the block-per-bucket fallback) sums
+// its pieces.  When one round of waves covers the whole job the lane count is made a multiple of the chip's 65536 SIMD
+// lanes: with 3.25 waves per SIMD the kernel takes as long as with 4, because the busiest SIMD sets the time.
+static uint32_t msm_seg_len(size_t entries, size_t buckets)
 {
-    uint32_t lg = MSM_SEG_LOG_MIN;
-    while (lg < MSM_SEG_LOG_DEFAULT && (entries >> lg) > (size_t)262144) lg++;   // fill the chip once: 256 Ki lanes
-    while ((entries >> lg) > (size_t)MSM_BUCKETS * 32) lg++;                      // <= 32 pieces per average bucket
-    return lg;
+    constexpr size_t CHIP_LANES = 65536; // 256 CUs x 4 SIMDs x 64
+    if (entries <= MSM_SEG_MIN * 4 * CHIP_LANES) return MSM_SEG_MIN;      // small: at most 4 waves per SIMD of 8 entries
+    if (entries <= MSM_SEG_DEFAULT * 5 * CHIP_LANES) {                     // one round: k full waves per SIMD, k = 4 or 5
+        const size_t k = entries <= MSM_SEG_DEFAULT * 4 * CHIP_LANES ? 4 : 5;
+        return (uint32_t)((entries + k * CHIP_LANES - 1) / (k * CHIP_LANES));
+    }
+    size_t seg = MSM_SEG_DEFAULT;
+    while (entries / seg > buckets * 32 && entries / seg > (size_t)1048576) seg *= 2; // <= 32 pieces per average bucket
+    return (uint32_t)seg;
 }
 
-static int msm_layout(size_t n, MsmLayout& L)
+template <int C> static int msm_layout(size_t n, MsmLayout& L)
 {
-    L.entries = n * MSM_WINDOWS;
-    L.seg_log = msm_seg_log(L.entries);
-    L.lanes = (L.entries + (1u << L.seg_log) - 1) >> L.seg_log;
+    using K = MsmCfg<C>;
+    L.entries = n * K::windows;
+    L.seg = msm_seg_len(L.entries, K::buckets);
+    L.lanes = (L.entries + L.seg - 1) / L.seg;
     size_t tmp = 0;
     rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C);
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)C);
     if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs(size query)", __FILE__, __LINE__);
     L.sort_bytes = tmp;
     size_t o = 0;
@@ -815,23 +854,36 @@ static int msm_layout(size_t n, MsmLayout& L)
     L.off_sort = take(L.sort_bytes);
     L.off_parts = take(3 * SORT_PAD * 4);
     for (int k = 0; k < 2; k++) {
-        L.off_offsets[k] = take((MSM_BUCKETS + 2) * 4);
+        L.off_offsets[k] = take(((size_t)K::buckets + 2) * 4);
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
         L.off_tail[k] = take(L.lanes * sizeof(Xyzz));
-        L.off_buckets[k] = take((size_t)MSM_BUCKETS * sizeof(Xyzz));
-        L.off_rows[k] = take((128 + 16) * sizeof(Xyzz)); // 128 row sums + 15 bit planes
-        L.off_cols[k] = take(256 * sizeof(Xyzz));
-        L.off_long[k] = take((MSM_BUCKETS + 1) * 4);
+        L.off_buckets[k] = take((size_t)K::buckets * sizeof(Xyzz));
+        L.off_rows[k] = take(((size_t)(1 << K::log_rows) + MSM_MAX_PLANES) * sizeof(Xyzz)); // row sums + bit planes
+        L.off_cols[k] = take((size_t)(1 << K::log_cols) * sizeof(Xyzz));
+        L.off_long[k] = take(((size_t)K::buckets + 1) * 4);
     }
     L.total = o;
     return BBG_OK;
 }
 
-int srs_build_tables(const void* d_points, size_t n, void* d_table, hipStream_t st)
+int msm_windows_for(int c) { return c == 20 ? MsmCfg<20>::windows : MsmCfg<16>::windows; }
+
+// Window width for an n-term MSM (0 = automatic).  2^19 buckets cost ~0.25 ms of extra reduction and sort work against
+// 19 % fewer mixed additions: measured break-even at n = 2^20..2^21 (1.68 vs 1.69 ms, 3.32 vs 3.32 ms pipelined), 7 %
+// ahead at 2^22 (6.13 vs 6.57 ms) -- profiles/r01_msm_size_sweep.txt.
+int msm_pick_window(const bbg_ctx* ctx, size_t n)
+{
+    if (ctx->msm_window == 16 || ctx->msm_window == 20) return ctx->msm_window;
+    return n >= ((size_t)1 << 22) ? 20 : 16;
+}
+
+int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st)
 {
     if (n == 0) return BBG_OK;
-    hipLaunchKernelGGL(k_precompute_tables, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Affine*)d_points,
-                       (Affine*)d_table, n);
+    if (c == 20)
+        hipLaunchKernelGGL(k_precompute_tables<20>, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Affine*)d_points, (Affine*)d_table, n);
+    else
+        hipLaunchKernelGGL(k_precompute_tables<16>, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Affine*)d_points, (Affine*)d_table, n);
     BBG_HIP(hipGetLastError());
     return BBG_OK;
 }
@@ -854,25 +906,13 @@ int srs_synth_hashed(bbg_ctx*, uint64_t seed, size_t n, void* d_points, hipStrea
     return BBG_OK;
 }
 
-int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st)
+template <int C>
+static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
+                     hipStream_t st)
 {
-    if (from > srs.n || n > srs.n - from) {
-        set_error("bbg_msm: range [from, from+n) exceeds the registered SRS");
-        return BBG_E_INVALID;
-    }
-    if (srs.n > ((size_t)1 << MSM_IDX_BITS)) {
-        set_error("bbg_msm: SRS larger than 2^26 points per device is not supported (shard it across devices)");
-        return BBG_E_INVALID;
-    }
-    if (n == 0) {
-        // pippenger(): n == 0 -> point at infinity (scalar_multiplication.cpp:868-872)
-        uint64_t inf[12] = { 0, 0, 0, 1ULL << 63, 0, 0, 0, 0, 0, 0, 0, 0 };
-        BBG_HIP(hipMemcpyAsync(d_out_jac, inf, 96, hipMemcpyHostToDevice, st));
-        BBG_HIP(hipStreamSynchronize(st));
-        return BBG_OK;
-    }
+    using K = MsmCfg<C>;
     MsmLayout L;
-    int rc = msm_layout(n, L);
+    int rc = msm_layout<C>(n, L);
     if (rc) return rc;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
@@ -895,7 +935,7 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     Xyzz* buckets = (Xyzz*)(base + L.off_buckets[slot]);
     Xyzz* rows = (Xyzz*)(base + L.off_rows[slot]);
     Xyzz* cols = (Xyzz*)(base + L.off_cols[slot]);
-    Xyzz* planes = rows + 128;
+    Xyzz* planes = rows + (1 << K::log_rows);
     uint32_t* long_count = (uint32_t*)(base + L.off_long[slot]);
     uint32_t* long_list = long_count + 1;
     const bool overlap = ctx->msm_async_reduce;
@@ -914,39 +954,39 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
         {
             ProfScope ps(ctx, "msm_recode", st);
             BBG_HIP(hipMemsetAsync(part_count, 0, SORT_PAD * 4, st));
-            hipLaunchKernelGGL(k_sortA_count, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
-            hipLaunchKernelGGL(k_sortA_scan, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets);
+            hipLaunchKernelGGL(k_sortA_count<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
+            hipLaunchKernelGGL(k_sortA_scan<C>, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets);
         }
         {
             ProfScope ps(ctx, "msm_sort", st);
-            hipLaunchKernelGGL(k_sortA_scatter, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, from, cursor, entries);
-            hipLaunchKernelGGL(k_sortB, dim3(SORT_PARTS), dim3(1024), 0, st, entries, part_base, offsets, vals0);
+            hipLaunchKernelGGL(k_sortA_scatter<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, from, cursor, entries);
+            hipLaunchKernelGGL(k_sortB<C>, dim3(K::parts), dim3(1024), 0, st, entries, part_base, offsets, vals0);
         }
         svals = vals0;
     } else {
         {
             ProfScope ps(ctx, "msm_recode", st);
-            hipLaunchKernelGGL(k_recode, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
+            hipLaunchKernelGGL(k_recode<C>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
         }
         rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
         {
             ProfScope ps(ctx, "msm_sort", st);
             size_t tmp = L.sort_bytes;
-            hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)MSM_C, st);
+            hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)C, st);
             if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
         }
         const uint32_t* skeys = dk.current();
         svals = dv.current();
         {
             ProfScope ps(ctx, "msm_offsets", st);
-            hipLaunchKernelGGL(k_offsets, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
+            hipLaunchKernelGGL(k_offsets<C>, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
         }
     }
     {
         ProfScope ps(ctx, "msm_accumulate", st);
         BBG_HIP(hipMemsetAsync(long_count, 0, 4, st));
-        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, (const Affine*)srs.points,
-                           srs.n, L.seg_log, head, tail, buckets);
+        hipLaunchKernelGGL(k_accumulate<C>, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, table,
+                           srs.n, L.seg, head, tail, buckets);
     }
     if (overlap) {
         BBG_HIP(hipEventRecord(ctx->ev_acc[slot], st));
@@ -954,12 +994,16 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     }
     {
         ProfScope ps(ctx, "msm_reduce", rst);
-        hipLaunchKernelGGL(k_combine8, dim3(grid_for((size_t)MSM_BUCKETS * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
-                           L.seg_log, head, tail, buckets, long_count, long_list);
-        hipLaunchKernelGGL(k_combine_long, dim3(256), dim3(256), 0, rst, offsets, L.seg_log, head, tail, buckets, long_count, long_list);
-        hipLaunchKernelGGL(k_rowcol, dim3(384), dim3(256), 0, rst, buckets, rows, cols);
-        hipLaunchKernelGGL(k_final_planes, dim3(MSM_PLANES), dim3(256), 0, rst, rows, cols, planes);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (Jacobian*)d_out_jac);
+        if (L.lanes > (size_t)2 * K::buckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
+            hipLaunchKernelGGL(k_combine8<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
+                               L.seg, head, tail, buckets, long_count, long_list);
+        else
+            hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
+                               buckets, long_count, long_list);
+        hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
+        hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
+        hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (int)K::planes, (Jacobian*)d_out_jac);
     }
     if (overlap) {
         BBG_HIP(hipEventRecord(ctx->ev_done[slot], rst));
@@ -967,6 +1011,39 @@ int msm_run(bbg_ctx* ctx, const Srs& srs, const void* d_scalars, size_t from, si
     }
     BBG_HIP(hipGetLastError());
     return BBG_OK;
+}
+
+
+int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st)
+{
+    if (from > srs.n || n > srs.n - from) {
+        set_error("bbg_msm: range [from, from+n) exceeds the registered SRS");
+        return BBG_E_INVALID;
+    }
+    if (srs.n > ((size_t)1 << MSM_IDX_BITS)) {
+        set_error("bbg_msm: SRS larger than 2^26 points per device is not supported (shard it across devices)");
+        return BBG_E_INVALID;
+    }
+    if (n == 0) {
+        // pippenger(): n == 0 -> point at infinity (scalar_multiplication.cpp:868-872)
+        uint64_t inf[12] = { 0, 0, 0, 1ULL << 63, 0, 0, 0, 0, 0, 0, 0, 0 };
+        BBG_HIP(hipMemcpyAsync(d_out_jac, inf, 96, hipMemcpyHostToDevice, st));
+        BBG_HIP(hipStreamSynchronize(st));
+        return BBG_OK;
+    }
+    const int c = msm_pick_window(ctx, n);
+    void*& table = c == 20 ? srs.table20 : srs.table16;
+    if (!table) { // first MSM of this width on this SRS: build its window tables from the plain points (one-off)
+        hipError_t e = hipMalloc(&table, srs.n * (size_t)msm_windows_for(c) * sizeof(Affine));
+        if (e != hipSuccess) {
+            table = nullptr;
+            return hip_fail(e, "hipMalloc(SRS window tables)", __FILE__, __LINE__);
+        }
+        int rc = srs_build_tables(srs.points, srs.n, table, c, st);
+        if (rc) return rc;
+    }
+    if (c == 20) return msm_run_c<20>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st);
+    return msm_run_c<16>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st);
 }
 
 // makes the context stream wait for every reduce phase queued on the auxiliary stream (no host sync)

@@ -160,6 +160,27 @@ if "msmsweep" in stages:
             print(f"msm 2^{lg} async_reduce={mode}: {dt*1e3:.3f} ms  {n/dt/1e6:.2f} Mscalar-mul/s  phases {ph}", flush=True)
         B.set_option("msm_async_reduce", 0)
         srs.free()
+if "msmwin" in stages:
+    import torch
+    for lg in (19, 20, 21, 22):
+        n = 1 << lg
+        srs = B.srs_synth_hashed(0xBB254, n)
+        ts = torch.from_numpy(inp.synthetic_scalars(1234, n).view(np.int64)).cuda()
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        B.set_option("msm_async_reduce", 1)
+        for win in (16, 20):
+            B.set_option("msm_window", win)
+            B.msm_device(srs, ts.data_ptr(), n, out.data_ptr()); B.join(); B.sync()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+            B.join(); B.sync()
+            dt = (time.perf_counter() - t0) / reps
+            print(f"msm 2^{lg} window={win} pipelined: {dt*1e3:.3f} ms  {n/dt/1e6:.2f} Mscalar-mul/s", flush=True)
+        B.set_option("msm_window", 0)
+        B.set_option("msm_async_reduce", 0)
+        srs.free()
 if "msmexp" in stages:
     import torch
     n = 1 << 20

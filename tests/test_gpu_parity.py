@@ -330,14 +330,42 @@ def test_msm_sort_paths_agree(pkg, oracle, bbg, srs16):
     pts = srs16.read(0, 3)
     try:
         for name, sc in cases.items():
-            bbg.set_option("msm_sort", 1)
-            a = oracle.jac_to_affine(bbg.msm(srs16, sc))
-            bbg.set_option("msm_sort", 0)
-            b = oracle.jac_to_affine(bbg.msm(srs16, sc))
-            assert np.array_equal(a, b), name
-        assert np.array_equal(a, oracle.pippenger(cases["tiny"], pts))
+            got = []
+            for window in (16, 20):  # both compiled window widths (the second one builds its tables on first use)
+                bbg.set_option("msm_window", window)
+                for sort in (1, 0):
+                    bbg.set_option("msm_sort", sort)
+                    got.append(oracle.jac_to_affine(bbg.msm(srs16, sc)))
+            for g in got[1:]:
+                assert np.array_equal(got[0], g), name
+        assert np.array_equal(got[0], oracle.pippenger(cases["tiny"], pts))
     finally:
         bbg.set_option("msm_sort", 1)
+        bbg.set_option("msm_window", 0)
+
+
+def test_msm_window20_vs_oracle(pkg, oracle, bbg, golden, srs16):
+    """The 20-bit-window configuration (automatic from n = 2^20) forced at small sizes: oracle parity, `from` offsets,
+    the reference's golden results and the mixed-width scalar distribution."""
+    bbg.set_option("msm_window", 20)
+    try:
+        pts = srs16.read(0, 5000)
+        sc = pkg.synthetic_scalars(0xBB254 + 3, 5000)
+        for n in (1, 2, 17, 65, 1000, 5000):
+            assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs16, sc[:n])), oracle.pippenger(sc[:n], pts[:n])), n
+        got = oracle.jac_to_affine(bbg.msm(srs16, sc[:1000], start=300))
+        assert np.array_equal(got, oracle.pippenger(sc[:1000], srs16.read(300, 1000)))
+        for rec in golden["msm"]:
+            if rec["srs"] != "hashed" or rec["from"] + rec["n"] > (1 << 16):
+                continue
+            if rec.get("scalar_kind") == "mixed":
+                s_ = pkg.inputs.mixed_scalars(rec["scalar_seed"], rec["n"], lambda p: oracle.to_mont(0, p))
+            else:
+                s_ = pkg.synthetic_scalars(rec["scalar_seed"], rec["n"])
+            got = oracle.jac_to_affine(bbg.msm(srs16, s_, start=rec["from"]))
+            assert np.array_equal(got, unhex(rec["result"], 8)[0]), rec
+    finally:
+        bbg.set_option("msm_window", 0)
 
 
 def test_g1_sum_and_normalize(pkg, oracle, bbg, srs16):
