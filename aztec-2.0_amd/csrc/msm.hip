@@ -34,7 +34,7 @@ namespace bbg {
 
 // Window width C is a per-call choice between two compiled configurations (msm_pick_window): C = 16 (16 windows, 2^15
 // buckets) and C = 20 (13 windows, 2^19 buckets).  Wider windows trade 19 % of the mixed additions for a 16x larger
-// bucket reduction, which pays from n = 2^22 upwards.  Each width has its own window tables T[w][i] = 2^(C w) P_i.
+// bucket reduction, which pays from n = 2^21 upwards.  Each width has its own window tables T[w][i] = 2^(C w) P_i.
 template <int C> struct MsmCfg {
     static constexpr int c = C;
     static constexpr int windows = (254 + C) / C;      // C * windows >= 255: 254 scalar bits + the recoding carry
@@ -824,12 +824,19 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static uint32_t msm_seg_len(size_t entries, size_t buckets)
 {
     constexpr size_t CHIP_LANES = 65536; // 256 CUs x 4 SIMDs x 64
-    if (entries <= MSM_SEG_MIN * 4 * CHIP_LANES) return MSM_SEG_MIN;      // small: at most 4 waves per SIMD of 8 entries
-    if (entries <= MSM_SEG_DEFAULT * 5 * CHIP_LANES) {                     // one round: k full waves per SIMD, k = 4 or 5
-        const size_t k = entries <= MSM_SEG_DEFAULT * 4 * CHIP_LANES ? 4 : 5;
-        return (uint32_t)((entries + k * CHIP_LANES - 1) / (k * CHIP_LANES));
+    constexpr size_t MAX_WAVES = 6;      // resident waves per SIMD of k_accumulate (84 VGPRs)
+    if (entries <= MSM_SEG_MIN * 4 * CHIP_LANES) return MSM_SEG_MIN; // small: at most 4 waves per SIMD of 8 entries
+    size_t seg;
+    if (entries <= MSM_SEG_DEFAULT * MAX_WAVES * CHIP_LANES) { // one round of k = 4..6 full waves per SIMD, <= 64 entries each
+        size_t k = (entries + MSM_SEG_DEFAULT * CHIP_LANES - 1) / (MSM_SEG_DEFAULT * CHIP_LANES);
+        if (k < 4) k = 4;
+        seg = (entries + k * CHIP_LANES - 1) / (k * CHIP_LANES);
+    } else { // whole rounds of MAX_WAVES waves per SIMD, ~64 entries each
+        const size_t per_round = MSM_SEG_DEFAULT * MAX_WAVES * CHIP_LANES;
+        size_t rounds = (entries + per_round / 2) / per_round;
+        if (rounds < 1) rounds = 1;
+        seg = (entries + rounds * MAX_WAVES * CHIP_LANES - 1) / (rounds * MAX_WAVES * CHIP_LANES);
     }
-    size_t seg = MSM_SEG_DEFAULT;
     while (entries / seg > buckets * 32 && entries / seg > (size_t)1048576) seg *= 2; // <= 32 pieces per average bucket
     return (uint32_t)seg;
 }
@@ -869,12 +876,13 @@ template <int C> static int msm_layout(size_t n, MsmLayout& L)
 int msm_windows_for(int c) { return c == 20 ? MsmCfg<20>::windows : MsmCfg<16>::windows; }
 
 // Window width for an n-term MSM (0 = automatic).  2^19 buckets cost ~0.25 ms of extra reduction and sort work against
-// 19 % fewer mixed additions: measured break-even at n = 2^20..2^21 (1.68 vs 1.69 ms, 3.32 vs 3.32 ms pipelined), 7 %
-// ahead at 2^22 (6.13 vs 6.57 ms) -- profiles/r01_msm_size_sweep.txt.
+// 19 % fewer mixed additions.  Measured (interleaved A/B, pipelined, profiles/r01_msm_size_sweep.txt): n = 2^20 1.70 vs
+// 1.75 ms MSM-only but 1.85 vs 1.80 ms for the MSM + NTT bench step (the longer reduce phase competes with the NTT);
+// n = 2^21 3.03 vs 3.22 ms; n = 2^22 6.0 vs 6.5 ms.  Hence 20 bits from 2^21 terms.
 int msm_pick_window(const bbg_ctx* ctx, size_t n)
 {
     if (ctx->msm_window == 16 || ctx->msm_window == 20) return ctx->msm_window;
-    return n >= ((size_t)1 << 22) ? 20 : 16;
+    return n >= ((size_t)1 << 21) ? 20 : 16;
 }
 
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st)

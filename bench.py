@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, 16 or 20 (A/B runs)")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +98,8 @@ def main():
     bbg = pkg.Bbg(local_rank)
     bbg.set_stream(torch.cuda.current_stream().cuda_stream)
     bbg.set_option("msm_async_reduce", 1)  # bucket reduction of MSM i overlaps sort/accumulate of step i+1
+    if args.msm_window:
+        bbg.set_option("msm_window", args.msm_window)
 
     # ---- setup (untimed): SRS shard resident in HBM, scalars / coefficients resident, twiddles built
     start = rank * n  # weak scaling: every rank owns n points of a world*n-point SRS

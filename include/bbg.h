@@ -153,7 +153,7 @@ int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
- * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (bucket window width: 0 = automatic [20 bits from n = 2^22 terms,
+ * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (bucket window width: 0 = automatic [20 bits from n = 2^21 terms,
  * else 16], 16 or 20; a width's window tables are built the first time it is used on an SRS), "msm_sort" (1 = fused recode + two-level partition sort, default;
  * 0 = recode + rocPRIM radix sort + offsets kernels; both feed the same accumulation and give identical results). */
 int bbg_set_option(bbg_ctx* ctx, const char* key, long value);

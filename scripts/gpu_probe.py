@@ -181,6 +181,32 @@ if "msmwin" in stages:
         B.set_option("msm_window", 0)
         B.set_option("msm_async_reduce", 0)
         srs.free()
+if "msmab" in stages:
+    import torch
+    for lg in (20, 21):
+        n = 1 << lg
+        srs = B.srs_synth_hashed(0xBB254, n)
+        ts = torch.from_numpy(inp.synthetic_scalars(1234, n).view(np.int64)).cuda()
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        B.set_option("msm_async_reduce", 1)
+        res = {16: [], 20: []}
+        for rnd in range(6):
+            for win in (16, 20):
+                B.set_option("msm_window", win)
+                for _ in range(3):
+                    B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+                B.join(); B.sync()
+                reps = 20
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
+                B.join(); B.sync()
+                res[win].append((time.perf_counter() - t0) / reps * 1e3)
+        for win in (16, 20):
+            print(f"msm 2^{lg} window={win} pipelined, 6 interleaved rounds x 20: " + " ".join(f"{x:.3f}" for x in res[win]) + f"  min {min(res[win]):.3f} ms", flush=True)
+        B.set_option("msm_window", 0)
+        B.set_option("msm_async_reduce", 0)
+        srs.free()
 if "msmexp" in stages:
     import torch
     n = 1 << 20
