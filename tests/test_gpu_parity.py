@@ -403,6 +403,37 @@ def test_msm_2_20_golden_and_properties(pkg, oracle, bbg, golden):
     srs.free()
 
 
+def test_msm_2_22_properties_wide_windows(pkg, oracle, bbg, golden):
+    """n = 2^22 takes the 20-bit-window configuration automatically (13 windows, 2^19 buckets).  No CPU oracle finishes at
+    this size in seconds, so: (a) the first 2^20 points and scalars reproduce the reference's recorded 2^20 result through
+    BOTH widths, (b) whole == sum of four point-range shards (each shard is a 2^20 MSM = 16-bit windows: the two
+    configurations must agree on the same data), (c) linearity, (d) MSM(-s) = -MSM(s)."""
+    n = 1 << 22
+    srs = bbg.srs_synth_hashed(0xBB254, n)
+    rec = [r for r in golden["msm"] if r["n"] == (1 << 20)][0]
+    sc20 = pkg.synthetic_scalars(rec["scalar_seed"], 1 << 20)
+    want = unhex(rec["result"], 8)[0]
+    try:
+        for window in (16, 20):
+            bbg.set_option("msm_window", window)
+            assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs, sc20)), want), window
+    finally:
+        bbg.set_option("msm_window", 0)
+    sc = pkg.synthetic_scalars(777, n)
+    whole = oracle.jac_to_affine(bbg.msm(srs, sc))
+    q = n // 4
+    parts = np.stack([bbg.msm(srs, sc[i * q:(i + 1) * q], start=i * q) for i in range(4)])
+    assert np.array_equal(oracle.jac_to_affine(bbg.g1_sum(parts)), whole)
+    sc2 = pkg.synthetic_scalars(778, n)
+    r2 = oracle.jac_to_affine(bbg.msm(srs, sc2))
+    rsum = oracle.jac_to_affine(bbg.msm(srs, oracle.fe_add(0, sc, sc2)))
+    assert np.array_equal(oracle.g1_add(whole, r2), rsum)
+    neg = oracle.jac_to_affine(bbg.msm(srs, oracle.fe_sub(0, np.zeros_like(sc), sc)))
+    assert np.array_equal(neg[:4], whole[:4])
+    assert np.array_equal(neg[4:], oracle.fe_sub(1, np.zeros((1, 4), dtype=np.uint64), whole[4:])[0])
+    srs.free()
+
+
 # ---------------------------------------------------------------------------------------------- the C++ drop-in shim
 def test_shim_reference_api_on_gpu():
     """oracle/_ref/shim_check: barretenberg's own TUs + shim/bbg_barretenberg_shim.cpp, MSM/FFT entry points wrapped at
