@@ -207,6 +207,31 @@ if "msmab" in stages:
         B.set_option("msm_window", 0)
         B.set_option("msm_async_reduce", 0)
         srs.free()
+if "hostpath" in stages:
+    import torch, ctypes
+    for lg in (18, 20, 22):
+        n = 1 << lg
+        srs = B.srs_synth_hashed(0xBB254, n)
+        sc = inp.synthetic_scalars(1234, n)
+        pinned = torch.from_numpy(sc.view(np.int64).copy()).pin_memory()
+        out = np.zeros(12, dtype=np.uint64)
+        def run(ptr):
+            B._ck(B.lib.bbg_msm(B.ctx, srs.handle, ctypes.c_void_p(ptr), 0, n, out.ctypes.data))
+        for name, ptr in (("pageable", sc.ctypes.data), ("pinned", pinned.data_ptr())):
+            run(ptr)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); run(ptr); ts.append(time.perf_counter() - t0)
+            print(f"bbg_msm host path 2^{lg} ({name} scalars): best {min(ts)*1e3:.3f} ms  median {sorted(ts)[2]*1e3:.3f} ms", flush=True)
+        c = inp.synthetic_scalars(5, n)
+        pc = torch.from_numpy(c.view(np.int64).copy()).pin_memory()
+        for name, ptr in (("pageable", c.ctypes.data), ("pinned", pc.data_ptr())):
+            B._ck(B.lib.bbg_ntt(B.ctx, ctypes.c_void_p(ptr), lg, 0, 0, None))
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); B._ck(B.lib.bbg_ntt(B.ctx, ctypes.c_void_p(ptr), lg, 0, 0, None)); ts.append(time.perf_counter() - t0)
+            print(f"bbg_ntt host path 2^{lg} ({name} coeffs, in place): best {min(ts)*1e3:.3f} ms  median {sorted(ts)[2]*1e3:.3f} ms", flush=True)
+        srs.free()
 if "msmexp" in stages:
     import torch
     n = 1 << 20
