@@ -71,6 +71,7 @@ def load_library():
         "bbg_g1_sum_device": (cint, [vp, vp, sz, vp]),
         "bbg_g1_normalize": (cint, [vp, vp, sz, vp]),
         "bbg_ntt": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
+        "bbg_coset_fft_extend": (cint, [vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
         "bbg_ntt_device": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
         "bbg_ntt_prepare": (cint, [vp, ctypes.c_uint]),
         "bbg_coset_fft_split": (cint, [vp, vp, ctypes.c_uint, sz]),
@@ -103,7 +104,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
-    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device",
+    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
@@ -237,6 +238,17 @@ class Bbg:
         c = None if constant is None else np.ascontiguousarray(constant, dtype=np.uint64)
         self._ck(self.lib.bbg_ntt(self.ctx, a.ctypes.data, log2n, op, generator_size, None if c is None else c.ctypes.data))
         return a
+
+    def coset_fft_extend(self, coeffs, log2_domain):
+        """The prover's FFT work item (work_queue.hpp:252-264): n coefficients -> 2^log2_domain + 4 coset evaluations."""
+        a = _u64(coeffs, 4)
+        n = a.shape[0]
+        log2n = n.bit_length() - 1
+        if n == 0 or (1 << log2n) != n:
+            raise ValueError("coefficient count must be a power of two")
+        out = np.empty(((1 << log2_domain) + 4, 4), dtype=np.uint64)
+        self._ck(self.lib.bbg_coset_fft_extend(self.ctx, a.ctypes.data, log2n, log2_domain, out.ctypes.data))
+        return out
 
     def ntt_device(self, d_coeffs, log2n, op=FFT, generator_size=0, constant=None):
         c = None if constant is None else np.ascontiguousarray(constant, dtype=np.uint64)

@@ -543,6 +543,28 @@ int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, siz
     return ntt_coset_split(ctx, d_coeffs, log2n, ext, ctx->stream);
 }
 
+int bbg_coset_fft_extend(bbg_ctx* ctx, const uint64_t* coeffs, unsigned log2n, unsigned log2_domain, uint64_t* out)
+{
+    CHECK_CTX(ctx);
+    if (!coeffs || !out) { set_error("bbg_coset_fft_extend: null argument"); return BBG_E_INVALID; }
+    if (log2_domain > 28 || log2_domain < 2 || log2n > log2_domain) {
+        set_error("bbg_coset_fft_extend: need log2n <= log2_domain and 2 <= log2_domain <= 28");
+        return BBG_E_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t n = (size_t)1 << log2n, m = (size_t)1 << log2_domain;
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, m * 32);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(ctx->staging, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (m > n) BBG_HIP(hipMemsetAsync((char*)ctx->staging + n * 32, 0, (m - n) * 32, ctx->stream));
+    rc = ntt_run(ctx, ctx->staging, log2_domain, BBG_COSET_FFT, n, nullptr, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(out, ctx->staging, m * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out + m * 4, out, 4 * 32); // add_lagrange_base_coefficient(out[0..3])
+    return BBG_OK;
+}
+
 int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t ext)
 {
     CHECK_CTX(ctx);

@@ -120,6 +120,11 @@ int bbg_ntt_prepare(bbg_ctx* ctx, unsigned log2n);
  * ext * 2^log2n elements; result interleaves ext size-n coset FFTs at index ext*i + k. */
 int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t ext);
 int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext);
+/* The prover's FFT work item as ONE call (work_queue.hpp:252-264, WorkType::FFT): copy the 2^log2n coefficients of a wire
+ * into a zeroed domain of 2^log2_domain elements, coset_fft over that domain with generator_size = 2^log2n, and append
+ * the first four results (polynomial::add_lagrange_base_coefficient x4).  coeffs: 2^log2n elements (read only);
+ * out: 2^log2_domain + 4 elements.  Uploads n elements instead of 4n and spares the host the 4n copy / zero fill. */
+int bbg_coset_fft_extend(bbg_ctx* ctx, const uint64_t* coeffs, unsigned log2n, unsigned log2_domain, uint64_t* out);
 
 /* ---- building blocks of an NTT sharded across GPUs by residue class (aztec-2.0_amd/parallel.py::ntt_sharded; the
  *      reference's precedent is the 4-way coset split, work_queue.hpp:166-199, polynomial_arithmetic.cpp:401-456) ---- */

@@ -440,3 +440,140 @@ class Ref:
         a = _arr(evals, 4).copy()
         self.lib.ref_divide_by_pseudo_vanishing(a.ctypes.data, log2_src, a.shape[0].bit_length() - 1, cut)
         return a
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's whole TurboPLONK prover with its MSM / FFT work items delegated to callbacks (ref_prover_driver.cpp)
+PROVER_SO = os.path.join(_HERE, "_ref", "libbbprover.so")
+
+
+def prover_available():
+    if not os.path.exists(PROVER_SO):
+        return False
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return all(f in flags for f in (" adx", " bmi2", " avx2"))
+
+
+class RefProver:
+    """One TurboComposer circuit + TurboProver of the reference.  `engine` supplies the three hot-path operations:
+         engine.msm(scalars[n,4]) -> jacobian[12]        (over the monomials returned by .monomials())
+         engine.coset_fft(coeffs[4n,4], generator_size)  -> coeffs[4n,4]
+         engine.ifft(coeffs[n,4])                        -> coeffs[n,4]
+       prove(engine=None) uses the reference's own CPU process_queue."""
+
+    MSM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p)
+    FFT_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p)
+    IFFT_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    FFT_ITEM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+    def __init__(self, num_gates, circuit_seed, points, x_mont):
+        if not prover_available():
+            raise RuntimeError("oracle/_ref/libbbprover.so not available on this machine")
+        L = self.lib = ctypes.CDLL(PROVER_SO, mode=os.RTLD_NOW)
+        L.refp_new.argtypes = [sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new.restype = vp
+        L.refp_circuit_size.argtypes = [vp]; L.refp_circuit_size.restype = sz
+        L.refp_get_monomials.argtypes = [vp, vp, sz]
+        L.refp_execute_round.argtypes = [vp, cint]; L.refp_execute_round.restype = sz
+        L.refp_process_queue_reference.argtypes = [vp]
+        L.refp_process_queue_with2.argtypes = [vp, self.MSM_CB, self.FFT_CB, self.FFT_ITEM_CB, self.IFFT_CB, vp, cint, vp]
+        L.refp_process_queue_with2.restype = cint
+        L.refp_export_proof.argtypes = [vp, vp, sz]; L.refp_export_proof.restype = sz
+        L.refp_verify.argtypes = [vp]; L.refp_verify.restype = cint
+        L.refp_delete.argtypes = [vp]
+        L.refp_set_threads.argtypes = [cint]
+        L.refp_max_threads.restype = cint
+        # small circuits: cap the reference's OpenMP team (see refp_set_threads in ref_prover_driver.cpp)
+        self.threads = min(os.cpu_count() or 1, 16 if num_gates < (1 << 17) else 64)
+        L.refp_set_threads(self.threads)
+        pts = _arr(points, 8)
+        x = np.ascontiguousarray(x_mont, dtype=np.uint64)
+        self.h = L.refp_new(num_gates, circuit_seed, pts.ctypes.data, pts.shape[0], x.ctypes.data)
+        if not self.h:
+            raise RuntimeError("refp_new failed (circuit larger than the SRS?)")
+        self.n = int(L.refp_circuit_size(self.h))
+        self.counts = [0, 0, 0]
+        self.mismatches = 0
+
+    def monomials(self, count=None):
+        count = self.n + 1 if count is None else count
+        out = np.empty((count, 8), dtype=np.uint64)
+        self.lib.refp_get_monomials(self.h, out.ctypes.data, count)
+        return out
+
+    def prove(self, engine=None, check=True):
+        """Runs all rounds (prover.cpp:420-436 construct_proof); returns the proof bytes."""
+        cbs = None
+        if engine is not None and getattr(engine, "raw", False):
+            # raw engine: gets the prover's own buffers (addresses) and works in place -- what a C++ binding does
+            item = None
+            if hasattr(engine, "fft_item_raw"):  # the whole FFT work item (n coefficients -> 4n + 4 values) in one call
+                item = self.FFT_ITEM_CB(lambda w, lgn, wf, lgd, _u: engine.fft_item_raw(w, lgn, wf, lgd))
+            cbs = (self.MSM_CB(lambda scalars, n, out, _u: engine.msm_raw(scalars, n, out)),
+                   self.FFT_CB(lambda coeffs, lg, gs, _u: engine.coset_fft_raw(coeffs, lg, gs)),
+                   self.IFFT_CB(lambda coeffs, lg, _u: engine.ifft_raw(coeffs, lg)), item)
+        elif engine is not None:
+            def msm_cb(scalars, n, out, _user):
+                s = np.ctypeslib.as_array(ctypes.cast(scalars, ctypes.POINTER(ctypes.c_uint64)), shape=(n, 4))
+                r = np.ascontiguousarray(engine.msm(s), dtype=np.uint64)
+                ctypes.memmove(out, r.ctypes.data, 96)
+
+            def fft_cb(coeffs, log2_domain, generator_size, _user):
+                m = 1 << log2_domain
+                a = np.ctypeslib.as_array(ctypes.cast(coeffs, ctypes.POINTER(ctypes.c_uint64)), shape=(m, 4))
+                r = np.ascontiguousarray(engine.coset_fft(a, generator_size), dtype=np.uint64)
+                ctypes.memmove(coeffs, r.ctypes.data, m * 32)
+
+            def ifft_cb(coeffs, log2n, _user):
+                m = 1 << log2n
+                a = np.ctypeslib.as_array(ctypes.cast(coeffs, ctypes.POINTER(ctypes.c_uint64)), shape=(m, 4))
+                r = np.ascontiguousarray(engine.ifft(a), dtype=np.uint64)
+                ctypes.memmove(coeffs, r.ctypes.data, m * 32)
+
+            item = None
+            if hasattr(engine, "fft_item"):
+                def item_cb(wire, log2n, wire_fft, log2_domain, _user):
+                    a = np.ctypeslib.as_array(ctypes.cast(wire, ctypes.POINTER(ctypes.c_uint64)), shape=(1 << log2n, 4))
+                    r = np.ascontiguousarray(engine.fft_item(a, log2_domain), dtype=np.uint64)
+                    assert r.shape == ((1 << log2_domain) + 4, 4)
+                    ctypes.memmove(wire_fft, r.ctypes.data, r.nbytes)
+                item = self.FFT_ITEM_CB(item_cb)
+            cbs = (self.MSM_CB(msm_cb), self.FFT_CB(fft_cb), self.IFFT_CB(ifft_cb), item)
+        self.counts = [0, 0, 0]
+        self.mismatches = 0
+        self.t_rounds = self.t_queue = 0.0  # seconds in the prover's own round logic / in the MSM+FFT work items
+        import time
+        for k in range(7):
+            t0 = time.perf_counter()
+            self.lib.refp_execute_round(self.h, k)
+            t1 = time.perf_counter()
+            self.t_rounds += t1 - t0
+            if k == 5:
+                continue  # construct_proof() runs rounds 5 and 6 back to back
+            if cbs is None:
+                self.lib.refp_process_queue_reference(self.h)
+                self.t_queue += time.perf_counter() - t1
+            else:
+                c = (ctypes.c_uint32 * 3)()
+                item = cbs[3] if cbs[3] is not None else ctypes.cast(None, self.FFT_ITEM_CB)
+                rc = self.lib.refp_process_queue_with2(self.h, cbs[0], cbs[1], item, cbs[2], None, 1 if check else 0, c)
+                if rc < 0:
+                    raise RuntimeError(f"refp_process_queue_with failed ({rc}) in round {k}")
+                self.mismatches += rc
+                for i in range(3):
+                    self.counts[i] += c[i]
+                self.t_queue += time.perf_counter() - t1
+        size = self.lib.refp_export_proof(self.h, None, 0)
+        buf = (ctypes.c_uint8 * size)()
+        self.lib.refp_export_proof(self.h, buf, size)
+        return bytes(buf)
+
+    def verify(self):
+        return int(self.lib.refp_verify(self.h))
+
+    def free(self):
+        if self.h:
+            self.lib.refp_delete(self.h)
+            self.h = None

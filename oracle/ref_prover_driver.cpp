@@ -1,0 +1,318 @@
+// oracle/ref_prover_driver.cpp -- TEST INFRASTRUCTURE, never shipped and never on the product path.
+//
+// Drives the REAL reference TurboPLONK prover (waffle::TurboComposer / TurboProver / TurboVerifier, compiled by
+// oracle/Makefile from the reference's own translation units where they lie under /root/reference) with its MSM / FFT
+// work items delegated to caller-supplied callbacks.  It is the native equivalent of the reference's own offload
+// protocol (plonk/proof_system/prover/c_bind.cpp:9-121: execute_*_round -> get work item data -> put results), i.e. the
+// exact seam a barretenberg maintainer would bind this repo's C ABI to:
+//
+//     work_queue::process_queue (work_queue.hpp:208-282)
+//        SCALAR_MULTIPLICATION -> pippenger_unsafe(scalars, monomials, n [+1])      ==> msm callback
+//        FFT                   -> copy n coeffs into the 4n+4 buffer, coset_fft      ==> coset_fft callback
+//        IFFT                  -> wire.ifft(small_domain)                            ==> ifft callback
+//
+// The tests run the prover twice over the same circuit: once with the reference's own CPU process_queue, once with the
+// callbacks (the GPU library); both proofs must verify under the reference verifier, and every work item's result is also
+// compared bit-exactly (canonical form) against the reference CPU result computed from the same inputs.
+//
+// Nothing here is reference source: only calls into its public classes.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <omp.h>
+#include <string>
+#include <vector>
+
+#include <ecc/curves/bn254/g1.hpp>
+#include <ecc/curves/bn254/g2.hpp>
+#include <ecc/curves/bn254/pairing.hpp>
+#include <ecc/curves/bn254/scalar_multiplication/pippenger.hpp>
+#include <ecc/curves/bn254/scalar_multiplication/scalar_multiplication.hpp>
+#include <plonk/composer/turbo_composer.hpp>
+#include <plonk/proof_system/prover/prover.hpp>
+#include <plonk/proof_system/verifier/verifier.hpp>
+#include <plonk/reference_string/reference_string.hpp>
+#include <polynomials/polynomial_arithmetic.hpp>
+
+using namespace barretenberg;
+
+namespace {
+
+// SRS handed in by the test as raw Montgomery affine points (the same 64-byte layout bbg_srs_register takes) plus the
+// secret x of the synthetic powers-of-x string, from which [x]_2 is derived for the verifier.
+class DriverProverCrs : public waffle::ProverReferenceString {
+  public:
+    DriverProverCrs(const uint64_t* points, size_t num_points)
+    {
+        table_ = scalar_multiplication::point_table_alloc<g1::affine_element>(num_points);
+        std::memcpy((void*)table_, points, num_points * sizeof(g1::affine_element));
+        scalar_multiplication::generate_pippenger_point_table(table_, table_, num_points);
+    }
+    ~DriverProverCrs() override { aligned_free(table_); }
+    g1::affine_element* get_monomials() override { return table_; }
+
+  private:
+    g1::affine_element* table_;
+};
+
+class DriverVerifierCrs : public waffle::VerifierReferenceString {
+  public:
+    explicit DriverVerifierCrs(const fr& x)
+    {
+        g2_x_ = g2::affine_element(g2::element(g2::one) * x);
+        lines_ = (pairing::miller_lines*)aligned_alloc(64, sizeof(pairing::miller_lines) * 2);
+        pairing::precompute_miller_lines(g2::one, lines_[0]);
+        pairing::precompute_miller_lines(g2_x_, lines_[1]);
+    }
+    ~DriverVerifierCrs() override { aligned_free(lines_); }
+    g2::affine_element get_g2x() const override { return g2_x_; }
+    pairing::miller_lines const* get_precomputed_g2_lines() const override { return lines_; }
+
+  private:
+    g2::affine_element g2_x_;
+    pairing::miller_lines* lines_;
+};
+
+class DriverCrsFactory : public waffle::ReferenceStringFactory {
+  public:
+    DriverCrsFactory(const uint64_t* points, size_t num_points, const fr& x)
+        : points_(points, points + num_points * 8)
+        , num_points_(num_points)
+        , x_(x)
+    {}
+    std::shared_ptr<waffle::ProverReferenceString> get_prover_crs(size_t degree) override
+    {
+        if (degree > num_points_) return nullptr;
+        return std::make_shared<DriverProverCrs>(points_.data(), degree);
+    }
+    std::shared_ptr<waffle::VerifierReferenceString> get_verifier_crs() override
+    {
+        return std::make_shared<DriverVerifierCrs>(x_);
+    }
+
+  private:
+    std::vector<uint64_t> points_;
+    size_t num_points_;
+    fr x_;
+};
+
+struct Session {
+    std::unique_ptr<waffle::TurboComposer> composer;
+    std::unique_ptr<waffle::TurboProver> prover;
+    std::vector<uint8_t> proof;
+};
+
+// A satisfiable arithmetic circuit of ~num_gates gates: a chain x_{k+1} = x_k * y_k + x_k with fresh y_k, laid out as one
+// multiplication gate and one addition gate per step (TurboComposer::create_mul_gate / create_add_gate).
+void build_circuit(waffle::TurboComposer& c, size_t num_gates, uint64_t seed)
+{
+    auto next = [&seed]() {
+        seed += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    };
+    fr x = fr(next() | 1).to_montgomery_form();
+    uint32_t xi = c.add_variable(x);
+    const size_t steps = num_gates / 2;
+    for (size_t k = 0; k < steps; k++) {
+        fr y = fr{ next(), next(), next(), next() & 0x0fffffffffffffffULL }.to_montgomery_form();
+        uint32_t yi = c.add_variable(y);
+        fr m = x * y;
+        uint32_t mi = c.add_variable(m);
+        c.create_mul_gate({ xi, yi, mi, fr::one(), fr::neg_one(), fr::zero() });
+        fr s = m + x;
+        uint32_t si = c.add_variable(s);
+        c.create_add_gate({ mi, xi, si, fr::one(), fr::one(), fr::neg_one(), fr::zero() });
+        x = s;
+        xi = si;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+typedef void (*refp_msm_cb)(const uint64_t* scalars, size_t n, uint64_t* out_jacobian, void* user);
+typedef void (*refp_coset_fft_cb)(uint64_t* coeffs, size_t log2_domain, size_t generator_size, void* user);
+typedef void (*refp_ifft_cb)(uint64_t* coeffs, size_t log2n, void* user);
+// the whole FFT work item: n coefficients of the wire -> the 4n + 4 entries of wire_fft (coset FFT + 4 wrapped values)
+typedef void (*refp_fft_item_cb)(const uint64_t* wire, size_t log2n, uint64_t* wire_fft, size_t log2_domain, void* user);
+
+// points: num_points affine Montgomery points [x^i]G (64 B each); x_mont: the secret as a Montgomery Fr (4 limbs).
+void* refp_new(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const uint64_t* x_mont)
+{
+    try {
+        fr x{ x_mont[0], x_mont[1], x_mont[2], x_mont[3] };
+        auto factory = std::make_shared<DriverCrsFactory>(points, num_points, x);
+        auto* s = new Session;
+        s->composer = std::make_unique<waffle::TurboComposer>(std::static_pointer_cast<waffle::ReferenceStringFactory>(factory), num_gates);
+        build_circuit(*s->composer, num_gates, circuit_seed);
+        s->prover = std::make_unique<waffle::TurboProver>(s->composer->create_prover());
+        return s;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+size_t refp_circuit_size(void* h) { return ((Session*)h)->prover->get_circuit_size(); }
+
+// OpenMP team size for everything the reference runs on the host.  The reference's compute_wnaf_states mis-indexes its
+// per-thread scratch when the team is large relative to the input (observed: intermittent SIGSEGV with 128 threads at
+// n = 2^14 on the GPU box's host), so callers cap it for small circuits.
+void refp_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+int refp_max_threads(void) { return omp_get_max_threads(); }
+
+// the monomials the prover's MSMs run over: plain points 0 .. n (the interleaved endomorphism twins skipped), 64 B each
+void refp_get_monomials(void* h, uint64_t* out, size_t count)
+{
+    g1::affine_element* t = ((Session*)h)->prover->key->reference_string->get_monomials();
+    for (size_t i = 0; i < count; i++) std::memcpy(out + i * 8, (const void*)&t[2 * i], 64);
+}
+
+// round k = 0 (preamble) .. 6; returns the number of queued work items afterwards
+size_t refp_execute_round(void* h, int k)
+{
+    auto& p = *((Session*)h)->prover;
+    switch (k) {
+    case 0: p.execute_preamble_round(); break;
+    case 1: p.execute_first_round(); break;
+    case 2: p.execute_second_round(); break;
+    case 3: p.execute_third_round(); break;
+    case 4: p.execute_fourth_round(); break;
+    case 5: p.execute_fifth_round(); break;
+    case 6: p.execute_sixth_round(); break;
+    default: break;
+    }
+    return p.queue.get_queue().size();
+}
+
+// the reference's own CPU path for the queued items (work_queue::process_queue)
+void refp_process_queue_reference(void* h) { ((Session*)h)->prover->queue.process_queue(); }
+
+// Same items, same order, same data movement as work_queue::process_queue (work_queue.hpp:208-282), with the three
+// compute calls replaced by the callbacks.  When check != 0 every callback result is compared with the reference CPU
+// result on the same input (canonical values); returns the number of mismatching items (0 = all bit-exact), or -1 on
+// an exception.  counts[0..2] receive the number of MSM / FFT / IFFT items processed.
+int refp_process_queue_with2(void* h, refp_msm_cb msm, refp_coset_fft_cb coset_fft, refp_fft_item_cb fft_item, refp_ifft_cb ifft,
+                             void* user, int check, uint32_t* counts);
+int refp_process_queue_with(void* h, refp_msm_cb msm, refp_coset_fft_cb coset_fft, refp_ifft_cb ifft, void* user, int check,
+                            uint32_t* counts)
+{
+    return refp_process_queue_with2(h, msm, coset_fft, nullptr, ifft, user, check, counts);
+}
+// fft_item (optional) replaces the copy + coset_fft + 4 x add_lagrange_base_coefficient of an FFT item by one call
+int refp_process_queue_with2(void* h, refp_msm_cb msm, refp_coset_fft_cb coset_fft, refp_fft_item_cb fft_item, refp_ifft_cb ifft,
+                             void* user, int check, uint32_t* counts)
+{
+    try {
+        auto& p = *((Session*)h)->prover;
+        auto* key = p.key.get();
+        auto* witness = p.witness.get();
+        int mismatches = 0;
+        uint32_t n_msm = 0, n_fft = 0, n_ifft = 0;
+        for (const auto& item : p.queue.get_queue()) {
+            switch (item.work_type) {
+            case waffle::work_queue::WorkType::SCALAR_MULTIPLICATION: {
+                const size_t num = key->small_domain.size + ((item.constant == fr(1)) ? 1 : 0);
+                g1::element r;
+                msm((const uint64_t*)item.mul_scalars, num, (uint64_t*)&r, user);
+                g1::affine_element result(r);
+                if (check) {
+                    auto state = scalar_multiplication::pippenger_runtime_state(num);
+                    g1::affine_element want(scalar_multiplication::pippenger_unsafe(
+                        item.mul_scalars, key->reference_string->get_monomials(), num, state));
+                    if (!(want == result)) mismatches++;
+                }
+                p.transcript.add_element(item.tag, result.to_buffer());
+                n_msm++;
+                break;
+            }
+            case waffle::work_queue::WorkType::FFT: {
+                polynomial& wire = witness->wires.at(item.tag);
+                polynomial& wire_fft = key->wire_ffts.at(item.tag + "_fft");
+                const size_t m = 4 * key->n;
+                std::vector<fr> ref_out;
+                if (check) { // the reference's own sequence on a scratch polynomial of the same shape (proving_key.cpp:102)
+                    polynomial tmp(m + 4, m + 4);
+                    polynomial_arithmetic::copy_polynomial(&wire[0], &tmp[0], key->n, m + 4);
+                    tmp.coset_fft(key->large_domain);
+                    for (int k = 0; k < 4; k++) tmp.add_lagrange_base_coefficient(tmp[k]);
+                    ref_out.assign(&tmp[0], &tmp[0] + m + 4);
+                }
+                if (fft_item) {
+                    fft_item((const uint64_t*)&wire[0], key->small_domain.log2_size, (uint64_t*)&wire_fft[0],
+                             key->large_domain.log2_size, user);
+                } else {
+                    polynomial_arithmetic::copy_polynomial(&wire[0], &wire_fft[0], key->n, m + 4);
+                    coset_fft((uint64_t*)&wire_fft[0], key->large_domain.log2_size, key->large_domain.generator_size, user);
+                    wire_fft.resize_unsafe(m); // what polynomial::coset_fft leaves behind (polynomial.cpp:270-278) ...
+                    for (int k = 0; k < 4; k++) wire_fft.add_lagrange_base_coefficient(wire_fft[k]); // ... so these land at 4n..4n+3
+                }
+                if (check) {
+                    bool ok = wire_fft.get_size() == m + 4;
+                    for (size_t i = 0; i < m + 4 && ok; i++) ok = (ref_out[i] == wire_fft[i]);
+                    if (!ok) mismatches++;
+                }
+                n_fft++;
+                break;
+            }
+            case waffle::work_queue::WorkType::IFFT: {
+                polynomial& wire = witness->wires.at(item.tag);
+                std::vector<fr> ref_out;
+                if (check) {
+                    polynomial tmp(wire, key->n);
+                    tmp.ifft(key->small_domain);
+                    ref_out.assign(&tmp[0], &tmp[0] + key->n);
+                }
+                ifft((uint64_t*)&wire[0], key->small_domain.log2_size, user);
+                if (check) {
+                    bool ok = true;
+                    for (size_t i = 0; i < key->n && ok; i++) ok = (ref_out[i] == wire[i]);
+                    if (!ok) mismatches++;
+                }
+                n_ifft++;
+                break;
+            }
+            default:
+                return -2; // SMALL_FFT only exists in WASM builds
+            }
+        }
+        p.queue.flush_queue();
+        if (counts) {
+            counts[0] = n_msm;
+            counts[1] = n_fft;
+            counts[2] = n_ifft;
+        }
+        return mismatches;
+    } catch (...) {
+        return -1;
+    }
+}
+
+// export the proof; returns its size (bytes copied into out up to cap)
+size_t refp_export_proof(void* h, uint8_t* out, size_t cap)
+{
+    auto* s = (Session*)h;
+    s->proof = s->prover->export_proof().proof_data;
+    if (out) std::memcpy(out, s->proof.data(), s->proof.size() < cap ? s->proof.size() : cap);
+    return s->proof.size();
+}
+
+// TurboVerifier::verify_proof on the exported proof: 1 = accepted, 0 = rejected, -1 = exception
+int refp_verify(void* h)
+{
+    try {
+        auto* s = (Session*)h;
+        auto verifier = s->composer->create_verifier();
+        waffle::plonk_proof proof{ s->proof };
+        return verifier.verify_proof(proof) ? 1 : 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
+void refp_delete(void* h) { delete (Session*)h; }
+
+} // extern "C"

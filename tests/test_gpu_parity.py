@@ -434,6 +434,48 @@ def test_msm_2_22_properties_wide_windows(pkg, oracle, bbg, golden):
     srs.free()
 
 
+# ---------------------------------------------------------------------------------------------- the reference PROVER seam
+@pytest.mark.parametrize("log2_gates,fused_item", [(9, False), (13, False), (13, True)])
+def test_reference_prover_with_gpu_engine(pkg, oracle, bbg, log2_gates, fused_item):
+    """The reference's REAL TurboPLONK prover (oracle/ref_prover_driver.cpp: TurboComposer circuit, TurboProver rounds,
+    prebuilt from the reference's own sources) with every MSM / coset-FFT / iFFT item of work_queue::process_queue
+    (work_queue.hpp:208-282) computed by this library through its C ABI host entry points -- the seam a barretenberg build
+    binds to.  Every item must equal the reference CPU result bit for bit (canonical), and the reference's TurboVerifier must
+    accept the proof.  Sizes: n = 2^10 and 2^14 gates after padding (MSMs of n and n+1 terms, coset FFTs of 4n)."""
+    from oracle.oracle import RefProver, prover_available
+    if not prover_available():
+        pytest.skip("oracle/_ref/libbbprover.so absent on this machine")
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    pts = oracle.srs_powers(x, (2 << log2_gates) + 1)
+    P = RefProver(1 << log2_gates, 11, pts, x)
+    n = P.n
+    mon = P.monomials()
+    srs = bbg.srs_register(mon)  # what a Pippenger-constructor hook registers: the prover's own monomials
+
+    class Engine:
+        def msm(self, s):
+            return bbg.msm(srs, s)
+
+        def coset_fft(self, a, generator_size):
+            return bbg.ntt(a, pkg.binding.COSET_FFT, generator_size)
+
+        def ifft(self, a):
+            return bbg.ntt(a, pkg.binding.IFFT)
+
+    class FusedEngine(Engine):  # the FFT work item as one call (bbg_coset_fft_extend): n coefficients in, 4n + 4 values out
+        def fft_item(self, wire, log2_domain):
+            return bbg.coset_fft_extend(wire, log2_domain)
+
+    proof = P.prove(FusedEngine() if fused_item else Engine())
+    assert P.mismatches == 0
+    assert P.counts[0] >= 9 and P.counts[1] >= 4 and P.counts[2] >= 3, P.counts
+    assert len(proof) > 0 and P.verify() == 1
+    print(f"\nreference TurboProver, n = {n}: {P.counts[0]} MSM + {P.counts[1]} coset-FFT(4n) + {P.counts[2]} iFFT on the GPU "
+          f"(checked against the CPU per item); rounds {P.t_rounds*1e3:.1f} ms")
+    srs.free()
+    P.free()
+
+
 # ---------------------------------------------------------------------------------------------- the C++ drop-in shim
 def test_shim_reference_api_on_gpu():
     """oracle/_ref/shim_check: barretenberg's own TUs + shim/bbg_barretenberg_shim.cpp, MSM/FFT entry points wrapped at

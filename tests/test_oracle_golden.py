@@ -230,3 +230,60 @@ def test_poly_helpers_golden(pkg, oracle, golden):
     for rec in golden["poly"]["dpv"]:
         e = pkg.synthetic_scalars(rec["seed"], 1 << rec["log2_target"])
         assert sha(oracle.divide_by_pseudo_vanishing(e, rec["log2_src"], rec["cut"])) == rec["sha256"], rec
+
+
+# ---------------------------------------------------------------------------------------------- the reference PROVER seam
+def test_reference_prover_with_oracle_engine(oracle):
+    """The reference's real TurboPLONK prover (TurboComposer circuit -> TurboProver rounds, oracle/ref_prover_driver.cpp) with
+    every MSM / coset-FFT / iFFT work item of work_queue::process_queue (work_queue.hpp:208-282) computed by THIS repo's
+    CPU oracle instead: each item must equal the reference's CPU result bit for bit, and the reference's TurboVerifier must
+    accept the resulting proof.  Pins the oracle on the data a real proof produces (blinded wires, quotient parts, opening
+    polynomials), not only on synthetic vectors."""
+    from oracle.oracle import RefProver, prover_available
+    if not prover_available():
+        pytest.skip("oracle/_ref/libbbprover.so absent (built from /root/reference by `make -C oracle prover`)")
+    O = oracle
+    x = O.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    pts = O.srs_powers(x, (1 << 9) + 1)
+
+    class Engine:
+        def __init__(self, mon):
+            self.mon = mon
+
+        def msm(self, s):
+            j = np.zeros(12, dtype=np.uint64)
+            j[:8] = O.pippenger(s, self.mon[:s.shape[0]])
+            j[8:12] = O.to_mont(1, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+            return j
+
+        def coset_fft(self, a, generator_size):
+            return O.ntt(a, 2, generator_size)
+
+        def ifft(self, a):
+            return O.ntt(a, 1)
+
+    P = RefProver(1 << 8, 7, pts, x)
+    assert P.n == 1 << 9
+    assert len(P.prove()) > 0 and P.verify() == 1  # baseline: the reference on its own
+    P.free()
+    P = RefProver(1 << 8, 7, pts, x)
+    mon = P.monomials()
+    assert np.array_equal(mon, pts[: P.n + 1])
+    proof = P.prove(Engine(mon))
+    assert P.mismatches == 0
+    assert P.counts[0] >= 9 and P.counts[1] >= 4 and P.counts[2] >= 3, P.counts
+    assert len(proof) > 0 and P.verify() == 1
+    P.free()
+
+    class FusedEngine(Engine):  # the FFT work item as one call: n coefficients -> 4n + 4 values (copy, coset FFT, 4 wrapped)
+        def fft_item(self, wire, log2_domain):
+            m = 1 << log2_domain
+            a = np.zeros((m, 4), dtype=np.uint64)
+            a[: wire.shape[0]] = wire
+            r = O.ntt(a, 2, wire.shape[0])
+            return np.concatenate([r, r[:4]])
+
+    P = RefProver(1 << 8, 7, pts, x)
+    proof = P.prove(FusedEngine(P.monomials()))
+    assert P.mismatches == 0 and len(proof) > 0 and P.verify() == 1
+    P.free()
