@@ -445,6 +445,9 @@ class Ref:
 # ------------------------------------------------------------------------------------------------------------------
 # The reference's whole TurboPLONK prover with its MSM / FFT work items delegated to callbacks (ref_prover_driver.cpp)
 PROVER_SO = os.path.join(_HERE, "_ref", "libbbprover.so")
+# same objects + shim/bbg_barretenberg_shim.cpp + -Wl,--wrap flags + libbbg.so: the reference prover with its MSM / FFT
+# entry points wrapped onto the GPU library at link time.  Needs the HIP runtime: import torch first.
+PROVER_GPU_SO = os.path.join(_HERE, "_ref", "libbbprover_gpu.so")
 
 
 def prover_available():
@@ -469,10 +472,12 @@ class RefProver:
     IFFT_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
     FFT_ITEM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
-    def __init__(self, num_gates, circuit_seed, points, x_mont):
-        if not prover_available():
-            raise RuntimeError("oracle/_ref/libbbprover.so not available on this machine")
-        L = self.lib = ctypes.CDLL(PROVER_SO, mode=os.RTLD_NOW)
+    def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False):
+        if not prover_available() or (gpu_linked and not os.path.exists(PROVER_GPU_SO)):
+            raise RuntimeError("oracle/_ref/libbbprover[_gpu].so not available on this machine")
+        L = self.lib = ctypes.CDLL(PROVER_GPU_SO if gpu_linked else PROVER_SO, mode=os.RTLD_NOW)
+        L.refp_gpu_linked.restype = cint
+        assert bool(L.refp_gpu_linked()) == bool(gpu_linked)
         L.refp_new.argtypes = [sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new.restype = vp
         L.refp_circuit_size.argtypes = [vp]; L.refp_circuit_size.restype = sz
         L.refp_get_monomials.argtypes = [vp, vp, sz]
@@ -544,12 +549,14 @@ class RefProver:
         self.counts = [0, 0, 0]
         self.mismatches = 0
         self.t_rounds = self.t_queue = 0.0  # seconds in the prover's own round logic / in the MSM+FFT work items
+        self.t_round = [0.0] * 7           # per execute_*_round (0 = preamble)
         import time
         for k in range(7):
             t0 = time.perf_counter()
             self.lib.refp_execute_round(self.h, k)
             t1 = time.perf_counter()
             self.t_rounds += t1 - t0
+            self.t_round[k] = t1 - t0
             if k == 5:
                 continue  # construct_proof() runs rounds 5 and 6 back to back
             if cbs is None:

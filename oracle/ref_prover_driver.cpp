@@ -132,7 +132,14 @@ void build_circuit(waffle::TurboComposer& c, size_t num_gates, uint64_t seed)
 
 } // namespace
 
+// Present only in the variant of this library that is linked with the drop-in shim (libbbprover_gpu.so)
+extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num_points) __attribute__((weak));
+
 extern "C" {
+
+// 1 when this build has the reference's MSM / FFT entry points wrapped onto libbbg.so at link time (no callbacks needed:
+// refp_process_queue_reference and every inline polynomial::fft... call of the prover then run on the GPU)
+int refp_gpu_linked(void) { return bbg_shim_register_point_table ? 1 : 0; }
 
 typedef void (*refp_msm_cb)(const uint64_t* scalars, size_t n, uint64_t* out_jacobian, void* user);
 typedef void (*refp_coset_fft_cb)(uint64_t* coeffs, size_t log2_domain, size_t generator_size, void* user);
@@ -150,6 +157,8 @@ void* refp_new(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, 
         s->composer = std::make_unique<waffle::TurboComposer>(std::static_pointer_cast<waffle::ReferenceStringFactory>(factory), num_gates);
         build_circuit(*s->composer, num_gates, circuit_seed);
         s->prover = std::make_unique<waffle::TurboProver>(s->composer->create_prover());
+        if (bbg_shim_register_point_table) // the Pippenger-constructor hook of INTEGRATION.md: upload the SRS once, up front
+            bbg_shim_register_point_table(s->prover->key->reference_string->get_monomials(), s->prover->get_circuit_size() + 1);
         return s;
     } catch (...) {
         return nullptr;

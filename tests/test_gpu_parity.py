@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI (libbbg.so); results are compared
 bit-exactly, on canonical values, with the oracle on the same seeded inputs, with the golden vectors recorded from the
 compiled reference, and -- at BASELINE.json's full sizes -- through size-independent algebraic properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -473,6 +475,22 @@ def test_reference_prover_with_gpu_engine(pkg, oracle, bbg, log2_gates, fused_it
     print(f"\nreference TurboProver, n = {n}: {P.counts[0]} MSM + {P.counts[1]} coset-FFT(4n) + {P.counts[2]} iFFT on the GPU "
           f"(checked against the CPU per item); rounds {P.t_rounds*1e3:.1f} ms")
     srs.free()
+    P.free()
+
+
+def test_reference_prover_linked_against_shim(pkg, oracle, bbg):
+    """INTEGRATION.md 2a end to end: the reference's TurboPLONK prover, UNMODIFIED, linked with shim/bbg_barretenberg_shim.cpp
+    and -Wl,--wrap so that pippenger_unsafe / fft / ifft / coset_fft / coset_ifft ... resolve to libbbg.so.  No callbacks:
+    work_queue::process_queue and every inline polynomial::ifft / coset_ifft of the rounds run on the GPU.  The reference's
+    TurboVerifier must accept the proof."""
+    from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
+    if not prover_available() or not os.path.exists(PROVER_GPU_SO):
+        pytest.skip("oracle/_ref/libbbprover_gpu.so absent on this machine")
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    pts = oracle.srs_powers(x, (2 << 13) + 1)
+    P = RefProver(1 << 13, 12, pts, x, gpu_linked=True)
+    proof = P.prove()  # engine=None: the reference's own process_queue -> __wrap_* -> libbbg.so
+    assert len(proof) > 0 and P.verify() == 1
     P.free()
 
 
