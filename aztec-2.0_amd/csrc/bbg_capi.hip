@@ -34,6 +34,8 @@ int ensure_buffer(void** buf, size_t* have, size_t need)
 }
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st);
 int msm_pick_window(const bbg_ctx* ctx, size_t n);
+int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
+                    uint64_t* alpha_out, hipStream_t st);
 int msm_windows_for(int c);
 int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st);
 
@@ -125,6 +127,7 @@ void bbg_destroy(bbg_ctx* ctx)
         for (auto e : kv.second.stop) (void)hipEventDestroy(e);
     }
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
+    if (ctx->quot_setup) (void)hipFree(ctx->quot_setup);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
     if (ctx->poly_scratch) (void)hipFree(ctx->poly_scratch);
@@ -541,6 +544,14 @@ int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, siz
     if (!d_coeffs) { set_error("bbg_coset_fft_split: null coeffs"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ntt_coset_split(ctx, d_coeffs, log2n, ext, ctx->stream);
+}
+
+int bbg_quotient_widget_device(bbg_ctx* ctx, int widget, const void* const d_polys[BBG_QP_COUNT], unsigned log2_large_domain,
+                               const uint64_t* challenges, void* d_quotient, uint64_t* alpha_base_out)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return quotient_widget(ctx, widget, d_polys, log2_large_domain, challenges, d_quotient, alpha_base_out, ctx->stream);
 }
 
 int bbg_coset_fft_extend(bbg_ctx* ctx, const uint64_t* coeffs, unsigned log2n, unsigned log2_domain, uint64_t* out)

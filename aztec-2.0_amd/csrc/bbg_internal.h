@@ -85,6 +85,8 @@ struct bbg_ctx {
     bool ev_done_valid[2] = { false, false };
     unsigned long msm_seq = 0;
     bool msm_async_reduce = false;
+    void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
+    size_t quot_setup_bytes = 0;
     int msm_window = 0; // 0 = automatic (20 from n = 2^21, else 16), or 16 / 20
     int msm_sort = 1; // 1 = fused recode + MSD partition sort (msm.hip), 0 = k_recode + rocPRIM radix sort + k_offsets
     int ntt_tile_log = 10; // log2(elements per LDS tile); 10/7 measured best on MI355X (profiles/r01_ntt_plan_sweep.txt)

@@ -1,0 +1,326 @@
+// Quotient-polynomial pointwise kernels on the 4n coset domain: what a TurboPLONK prover's widgets do in
+// ProverBase::execute_fourth_round (reference plonk/proof_system/prover/prover.cpp:304-319) --
+//
+//   ProverPermutationWidget<4,false>::compute_quotient_contribution     widgets/random_widgets/permutation_widget_impl.hpp:316-420
+//   TransitionWidget<..., TurboArithmeticKernel / TurboFixedBaseKernel / TurboRangeKernel / TurboLogicKernel>
+//       ::compute_quotient_contribution                                  widgets/transition_widgets/transition_widget.hpp:262-290
+//       with the kernels of turbo_arithmetic_widget.hpp:17-139, turbo_fixed_base_widget.hpp, turbo_range_widget.hpp,
+//       turbo_logic_widget.hpp
+//
+// Each is a pure pointwise function of ~10 of the key's "*_fft" arrays (values on the 4n coset, index i and the shifted
+// index (i + 4) mod 4n = the next row of the circuit) and the transcript challenges; the permutation widget ASSIGNS the
+// quotient array, the transition widgets ACCUMULATE into it, exactly as the reference.  The identities are restated
+// here from the equations they implement (comments give the algebraic form); values stay coarsely reduced in [0, 2p).
+// One thread per domain point (the permutation kernel walks 4 consecutive points to amortise w^i).  All reads are
+// coalesced 32-byte elements: this is the one part of the prover that is genuinely HBM-streaming.
+#include "bbg_internal.h"
+#include "field.hip.h"
+#include "ntt_consts.hip.h"
+
+namespace bbg {
+
+enum { QP_W1 = 0, QP_W2, QP_W3, QP_W4, QP_Z, QP_S1, QP_S2, QP_S3, QP_S4, QP_Q1, QP_Q2, QP_Q3, QP_Q4, QP_Q5, QP_QM, QP_QC,
+       QP_QARITH, QP_QECC, QP_QRANGE, QP_QLOGIC, QP_L1, QP_COUNT };
+static_assert(QP_COUNT == BBG_QP_COUNT, "include/bbg.h and quotient.hip disagree on the polynomial table");
+
+struct QuotientSetup {
+    Fr ap[7];       // alpha_base * alpha^k
+    Fr alpha, beta, gamma, delta;
+    Fr alpha_base_sqr;
+    Fr beta_g;      // beta * g (g = the small domain's coset generator): beta*g*w^i is the identity-permutation term
+    Fr k1, k2, k3;  // coset generators of the wire columns 2..4 (fr::coset_generator(0..2))
+    Fr one, c2, c3, c6, c7, c17, c81, c83;
+    Fr alpha_out[5]; // per widget: the alpha_base the next widget starts from
+};
+struct QuotientArgs {
+    const Fr* p[QP_COUNT];
+    Fr* quotient;
+    uint32_t mask; // 4n - 1
+    const QuotientSetup* s;
+    const DomainConsts* dc; // large (4n) domain: root and its power-of-two table
+};
+
+__device__ __forceinline__ Fr fr_small(uint32_t k)
+{
+    Fr one = Fr::one(), acc = Fr::zero();
+    for (int b = 31; b >= 0; b--) {
+        acc = fe_add(acc, acc);
+        if ((k >> b) & 1) acc = fe_add(acc, one);
+    }
+    return acc;
+}
+// challenges arrive as Montgomery limbs from the host; everything derived from them is computed here (the product has no
+// CPU field arithmetic)
+__global__ void k_quotient_setup(QuotientSetup* s, const Fr* in /* alpha_base, alpha, beta, gamma, delta, g, k1, k2, k3 */)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Fr alpha_base = fe_load<FrP>(in + 0), alpha = fe_load<FrP>(in + 1);
+    s->alpha = alpha;
+    s->beta = fe_load<FrP>(in + 2);
+    s->gamma = fe_load<FrP>(in + 3);
+    s->delta = fe_load<FrP>(in + 4);
+    s->beta_g = fe_mul(s->beta, fe_load<FrP>(in + 5));
+    s->k1 = fe_load<FrP>(in + 6);
+    s->k2 = fe_load<FrP>(in + 7);
+    s->k3 = fe_load<FrP>(in + 8);
+    Fr a = alpha_base;
+    for (int k = 0; k < 7; k++) {
+        s->ap[k] = a;
+        a = fe_mul(a, alpha);
+    }
+    s->alpha_base_sqr = fe_sqr(alpha_base);
+    s->one = Fr::one();
+    s->c2 = fr_small(2);
+    s->c3 = fr_small(3);
+    s->c6 = fr_small(6);
+    s->c7 = fr_small(7);
+    s->c17 = fr_small(17);
+    s->c81 = fr_small(81);
+    s->c83 = fr_small(83);
+    // update_alpha (transition_widget.hpp:88-94): alpha_powers[num_independent_relations - 1] * alpha
+    s->alpha_out[0] = fe_sqr(s->alpha_base_sqr);     // permutation: alpha_base^4 (permutation_widget_impl.hpp:419)
+    s->alpha_out[1] = fe_mul(s->ap[1], alpha);       // arithmetic: 2 relations
+    s->alpha_out[2] = fe_mul(s->ap[6], alpha);       // fixed base: 7
+    s->alpha_out[3] = fe_mul(s->ap[3], alpha);       // range: 4
+    s->alpha_out[4] = fe_mul(s->ap[3], alpha);       // logic: 4
+}
+
+#define QLOAD(id, idx) fe_load<FrP>(a.p[id] + (idx))
+__device__ __forceinline__ Fr x4(const Fr& v)
+{
+    const Fr d = fe_add(v, v);
+    return fe_add(d, d);
+}
+// D (D - 1) (D - 2) (D - 3): vanishes exactly on the base-4 digits
+__device__ __forceinline__ Fr quad_check(const Fr& d, const QuotientSetup& s)
+{
+    Fr t = fe_sub(fe_sqr(d), d);
+    t = fe_mul(t, fe_sub(d, s.c2));
+    return fe_mul(t, fe_sub(d, s.c3));
+}
+
+// ---- permutation argument, 4 wire columns, identity permutation given implicitly by X, k1 X, k2 X, k3 X:
+//   q = alpha_base * [ z(X) prod_k (w_k + gamma + beta K_k X) - z(wX) prod_k (w_k + gamma + beta sigma_k)
+//                      + (z(wX) - delta) alpha_base L_{n-4}(X) + (z(X) - 1) alpha_base^2 L_1(X) ]
+// L_{n-4} is read from the L_1 table at the shifted index i + 4 + 4*4 (4 roots cut out of the vanishing polynomial).
+constexpr int PERM_CH = 4;
+__global__ void __launch_bounds__(256) k_quotient_permutation(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * PERM_CH;
+    if (i0 > a.mask) return;
+    Fr rb = fe_mul(s.beta_g, pow_from_table(a.dc->pow2_root, (uint64_t)i0)); // beta * g * w^i
+    const Fr root = a.dc->root;
+#pragma unroll 1
+    for (int e = 0; e < PERM_CH; e++) {
+        const uint32_t i = i0 + e, ish = (i + 4) & a.mask;
+        Fr wpg = fe_add(QLOAD(QP_W1, i), s.gamma);
+        Fr num = fe_add(wpg, rb);
+        Fr den = fe_add(wpg, fe_mul(QLOAD(QP_S1, i), s.beta));
+        wpg = fe_add(QLOAD(QP_W2, i), s.gamma);
+        num = fe_mul(num, fe_add(wpg, fe_mul(s.k1, rb)));
+        den = fe_mul(den, fe_add(wpg, fe_mul(QLOAD(QP_S2, i), s.beta)));
+        wpg = fe_add(QLOAD(QP_W3, i), s.gamma);
+        num = fe_mul(num, fe_add(wpg, fe_mul(s.k2, rb)));
+        den = fe_mul(den, fe_add(wpg, fe_mul(QLOAD(QP_S3, i), s.beta)));
+        wpg = fe_add(QLOAD(QP_W4, i), s.gamma);
+        num = fe_mul(num, fe_add(wpg, fe_mul(s.k3, rb)));
+        den = fe_mul(den, fe_add(wpg, fe_mul(QLOAD(QP_S4, i), s.beta)));
+        const Fr z = QLOAD(QP_Z, i), zw = QLOAD(QP_Z, ish);
+        num = fe_mul(num, z);
+        den = fe_mul(den, zw);
+        Fr t = fe_mul(fe_mul(fe_sub(zw, s.delta), s.ap[0]), QLOAD(QP_L1, (i + 4 + 16) & a.mask));
+        num = fe_add(num, t);
+        t = fe_mul(fe_mul(fe_sub(z, s.one), s.alpha_base_sqr), QLOAD(QP_L1, i));
+        num = fe_add(num, t);
+        fe_store<FrP>(a.quotient + i, fe_mul(fe_sub(num, den), s.ap[0]));
+        rb = fe_mul(rb, root);
+    }
+}
+
+// ---- turbo arithmetic gate:
+//   alpha_base * [ q_arith (q_m w1 w2 + q_1 w1 + q_2 w2 + q_3 w3 + q_4 w4 + q_c) + alpha q_5 q_arith w4 (w4 - 1)(w4 - 2) ]
+//   + alpha_base (q_arith^2 - q_arith) d (9 d - 2 d^2 - 7),   d = w3 - 4 w4   (high-bit extraction, active when q_arith = 2)
+__global__ void __launch_bounds__(256) k_quotient_turbo_arith(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const Fr w1 = QLOAD(QP_W1, i), w2 = QLOAD(QP_W2, i), w3 = QLOAD(QP_W3, i), w4 = QLOAD(QP_W4, i);
+    const Fr qa = QLOAD(QP_QARITH, i);
+    Fr gate = fe_mul(fe_mul(w1, w2), QLOAD(QP_QM, i));
+    gate = fe_add(gate, fe_mul(w1, QLOAD(QP_Q1, i)));
+    gate = fe_add(gate, fe_mul(w2, QLOAD(QP_Q2, i)));
+    gate = fe_add(gate, fe_mul(w3, QLOAD(QP_Q3, i)));
+    gate = fe_add(gate, fe_mul(w4, QLOAD(QP_Q4, i)));
+    gate = fe_add(gate, QLOAD(QP_QC, i));
+    Fr t = fe_mul(fe_sub(fe_sqr(w4), w4), fe_sub(w4, s.c2));
+    t = fe_mul(fe_mul(t, s.alpha), QLOAD(QP_Q5, i));
+    gate = fe_mul(fe_add(gate, t), qa);
+    const Fr d = fe_sub(w3, x4(w4));
+    const Fr d2 = fe_sqr(d);
+    Fr h = fe_add(x4(d), x4(d));          // 8 d
+    h = fe_sub(fe_add(h, d), fe_add(d2, d2)); // 9 d - 2 d^2
+    h = fe_mul(fe_sub(h, s.c7), d);
+    h = fe_mul(h, fe_sub(fe_sqr(qa), qa));
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(fe_add(gate, h), s.ap[0])));
+}
+
+// ---- fixed-base scalar multiplication ladder over Grumpkin (y^2 = x^3 - 17): see the identities below; ap[k] = alpha_base alpha^k
+__global__ void __launch_bounds__(256) k_quotient_turbo_fixed_base(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const uint32_t ish = (i + 4) & a.mask;
+    const Fr w1 = QLOAD(QP_W1, i), w2 = QLOAD(QP_W2, i), w3 = QLOAD(QP_W3, i), w4 = QLOAD(QP_W4, i);
+    const Fr w1n = QLOAD(QP_W1, ish), w2n = QLOAD(QP_W2, ish), w3n = QLOAD(QP_W3, ish), w4n = QLOAD(QP_W4, ish);
+    const Fr qc = QLOAD(QP_QC, i), qe = QLOAD(QP_QECC, i);
+    const Fr delta = fe_sub(w4n, x4(w4)); // the next quad, in {-3, -1, 1, 3}
+    // selector-weighted ("linear") terms
+    Fr lin = fe_mul(fe_mul(fe_mul(fe_sqr(delta), qe), s.ap[1]), QLOAD(QP_Q1, i));       // q_1: x-coordinate lookup, delta^2 term
+    lin = fe_add(lin, fe_mul(fe_mul(s.ap[1], qe), QLOAD(QP_Q2, i)));                       // q_2: constant term
+    Fr t3 = fe_mul(fe_mul(fe_mul(fe_sub(w1n, w1), delta), w3n), s.ap[3]);
+    Fr u = fe_mul(fe_mul(fe_mul(delta, w3n), w2), s.ap[2]);
+    t3 = fe_mul(fe_add(t3, fe_add(u, u)), qe);
+    lin = fe_add(lin, fe_mul(t3, QLOAD(QP_Q3, i)));                                        // q_3: y-coordinate lookup
+    const Fr qeqc = fe_mul(qe, qc);
+    lin = fe_add(lin, fe_mul(fe_mul(fe_mul(w3, qeqc), s.ap[5]), QLOAD(QP_Q4, i)));          // q_4, q_5, q_m: initialisation row
+    lin = fe_add(lin, fe_mul(fe_mul(fe_mul(fe_sub(s.one, w4), qeqc), s.ap[5]), QLOAD(QP_Q5, i)));
+    lin = fe_add(lin, fe_mul(fe_mul(fe_mul(w3, qeqc), s.ap[6]), QLOAD(QP_QM, i)));
+    // gate identities
+    Fr acc = fe_mul(fe_mul(fe_add(delta, s.one), fe_add(delta, s.c3)), fe_mul(fe_sub(delta, s.one), fe_sub(delta, s.c3)));
+    acc = fe_mul(acc, s.ap[0]);                                                            // delta in {-3,-1,1,3}
+    const Fr x_alpha = fe_neg(fe_mul(w3n, s.ap[1]));
+    const Fr dx = fe_sub(w3n, w1);
+    Fr xacc = fe_mul(fe_add(fe_add(w1n, w1), w3n), fe_sqr(dx));                            // (x3 + x1 + x_alpha)(x_alpha - x1)^2
+    Fr rhs = fe_sub(fe_add(fe_mul(fe_sqr(w3n), w3n), fe_sqr(w2)), s.c17);                  // x_alpha^3 + y1^2 - 17
+    Fr two_dy = fe_mul(fe_mul(delta, w2), qe);
+    two_dy = fe_add(two_dy, two_dy);
+    xacc = fe_mul(fe_add(fe_sub(xacc, rhs), two_dy), s.ap[2]);
+    Fr yacc = fe_mul(fe_add(w2n, w2), dx);
+    yacc = fe_add(yacc, fe_mul(fe_sub(w1, w1n), fe_sub(w2, fe_mul(qe, delta))));
+    yacc = fe_mul(yacc, s.ap[3]);
+    const Fr w4m1 = fe_sub(w4, s.one);
+    const Fr acc_init = fe_mul(fe_mul(w4m1, fe_sub(w4m1, w3)), s.ap[4]);
+    const Fr x_init = fe_neg(fe_mul(fe_mul(w1, w3), s.ap[5]));
+    const Fr y_init = fe_mul(fe_sub(fe_mul(fe_sub(s.one, w4), qc), fe_mul(w2, w3)), s.ap[6]);
+    Fr gate = fe_mul(fe_add(fe_add(acc_init, x_init), y_init), qc);
+    gate = fe_add(fe_add(fe_add(fe_add(gate, acc), x_alpha), xacc), yacc);
+    gate = fe_mul(gate, qe);
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_add(lin, gate)));
+}
+
+// ---- base-4 range check ("raster scan" over the 4 wire columns and the next row's 4th column):
+//   q_range * sum_k ap[k] f(D_k),  f(D) = D (D-1)(D-2)(D-3),  D_1 = w3 - 4 w4, D_2 = w2 - 4 w3, D_3 = w1 - 4 w2, D_4 = w4' - 4 w1
+__global__ void __launch_bounds__(256) k_quotient_turbo_range(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const Fr w1 = QLOAD(QP_W1, i), w2 = QLOAD(QP_W2, i), w3 = QLOAD(QP_W3, i), w4 = QLOAD(QP_W4, i);
+    const Fr w4n = QLOAD(QP_W4, (i + 4) & a.mask);
+    Fr sum = fe_mul(quad_check(fe_sub(w3, x4(w4)), s), s.ap[0]);
+    sum = fe_add(sum, fe_mul(quad_check(fe_sub(w2, x4(w3)), s), s.ap[1]));
+    sum = fe_add(sum, fe_mul(quad_check(fe_sub(w1, x4(w2)), s), s.ap[2]));
+    sum = fe_add(sum, fe_mul(quad_check(fe_sub(w4n, x4(w1)), s), s.ap[3]));
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(sum, QLOAD(QP_QRANGE, i))));
+}
+
+// ---- AND / XOR on base-4 quads a, b (c = the output quad, w3 = a*b):
+//   q_logic alpha_base [ ((2 (a b - w3) alpha + f(a)) alpha + f(b)) alpha + 3 (a + b + c) - 2 E + q_c (9 c - 3 (a + b)) ]
+//   E = w3 ( w3 (4 w3 - 18 (a + b) + 81) + 18 (a^2 + b^2) - 81 (a + b) + 83 )
+//   a = w1' - 4 w1, b = w2' - 4 w2, c = w4' - 4 w4
+__global__ void __launch_bounds__(256) k_quotient_turbo_logic(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const uint32_t ish = (i + 4) & a.mask;
+    const Fr w3 = QLOAD(QP_W3, i);
+    const Fr qa = fe_sub(QLOAD(QP_W1, ish), x4(QLOAD(QP_W1, i)));
+    const Fr qb = fe_sub(QLOAD(QP_W2, ish), x4(QLOAD(QP_W2, i)));
+    const Fr qcq = fe_sub(QLOAD(QP_W4, ish), x4(QLOAD(QP_W4, i)));
+    const Fr sum = fe_add(qa, qb);
+    Fr id = fe_sub(fe_mul(qa, qb), w3);
+    id = fe_mul(fe_add(id, id), s.alpha);
+    id = fe_mul(fe_add(id, quad_check(qa, s)), s.alpha);
+    id = fe_mul(fe_add(id, quad_check(qb, s)), s.alpha);
+    const Fr sum3 = fe_add(fe_add(sum, sum), sum), sum9 = fe_add(fe_add(sum3, sum3), sum3);
+    const Fr sum18 = fe_add(sum9, sum9);
+    Fr sum81 = x4(sum18);               // 72
+    sum81 = fe_add(sum81, sum9);        // 81
+    const Fr sq = fe_add(fe_sqr(qa), fe_sqr(qb));
+    const Fr sq3 = fe_add(fe_add(sq, sq), sq), sq9 = fe_add(fe_add(sq3, sq3), sq3);
+    const Fr sq18 = fe_add(sq9, sq9);
+    Fr e = fe_add(fe_sub(x4(w3), sum18), s.c81);
+    e = fe_mul(e, w3);
+    e = fe_add(e, fe_add(fe_sub(sq18, sum81), s.c83));
+    e = fe_mul(e, w3);
+    const Fr c3 = fe_add(fe_add(qcq, qcq), qcq), c9 = fe_add(fe_add(c3, c3), c3);
+    Fr tail = fe_sub(fe_add(c3, sum3), fe_add(e, e));
+    tail = fe_add(tail, fe_mul(fe_sub(c9, sum3), QLOAD(QP_QC, i)));
+    id = fe_mul(fe_add(id, tail), s.ap[0]);
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(id, QLOAD(QP_QLOGIC, i))));
+}
+
+int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
+
+// challenges: 9 Montgomery Fr on the host: alpha_base, alpha, beta, gamma, public_input_delta, g, k1, k2, k3
+int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
+                    uint64_t* alpha_out, hipStream_t st)
+{
+    if (widget < 0 || widget > 4) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
+    if (log2_large < 3 || log2_large > 28) { set_error("bbg_quotient_widget_device: need 3 <= log2 of the 4n domain <= 28"); return BBG_E_INVALID; }
+    if (!d_polys || !challenges || !d_quotient) { set_error("bbg_quotient_widget_device: null argument"); return BBG_E_INVALID; }
+    // which polynomials each widget reads (a null pointer for one of them is an error; the others may be null)
+    static const uint32_t NEED[5] = {
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) |
+            (1u << QP_S4) | (1u << QP_L1),
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
+            (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QARITH),
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
+            (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QECC),
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QRANGE),
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QC) | (1u << QP_QLOGIC),
+    };
+    QuotientArgs a;
+    for (int k = 0; k < QP_COUNT; k++) {
+        a.p[k] = (const Fr*)d_polys[k];
+        if (((NEED[widget] >> k) & 1u) && !a.p[k]) { set_error("bbg_quotient_widget_device: a polynomial this widget reads is null"); return BBG_E_INVALID; }
+    }
+    int rc = ensure_buffer(&ctx->quot_setup, &ctx->quot_setup_bytes, sizeof(QuotientSetup) + 9 * sizeof(Fr));
+    if (rc) return rc;
+    QuotientSetup* setup = (QuotientSetup*)ctx->quot_setup;
+    Fr* in = (Fr*)((char*)ctx->quot_setup + sizeof(QuotientSetup));
+    BBG_HIP(hipMemcpyAsync(in, challenges, 9 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setup, (const Fr*)in);
+    void* dc = nullptr;
+    rc = ntt_domain_consts(ctx, log2_large, &dc);
+    if (rc) return rc;
+    a.quotient = (Fr*)d_quotient;
+    a.mask = (uint32_t)(((size_t)1 << log2_large) - 1);
+    a.s = setup;
+    a.dc = (const DomainConsts*)dc;
+    const size_t m = (size_t)1 << log2_large;
+    ProfScope ps(ctx, "quotient_widget", st);
+    switch (widget) {
+    case 0: hipLaunchKernelGGL(k_quotient_permutation, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(k_quotient_turbo_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_quotient_turbo_fixed_base, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(k_quotient_turbo_range, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_quotient_turbo_logic, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    }
+    BBG_HIP(hipGetLastError());
+    if (alpha_out) {
+        BBG_HIP(hipMemcpyAsync(alpha_out, &setup->alpha_out[widget], sizeof(Fr), hipMemcpyDeviceToHost, st));
+        BBG_HIP(hipStreamSynchronize(st));
+    }
+    return BBG_OK;
+}
+
+} // namespace bbg

@@ -156,6 +156,29 @@ int bbg_dev_free(bbg_ctx* ctx, void* d_ptr);
 int bbg_dev_upload(bbg_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 
+/* ---- quotient-polynomial pointwise kernels on the 4n coset domain: the widgets' compute_quotient_contribution of
+ *      ProverBase::execute_fourth_round (prover.cpp:304-319).  Device-resident: every polynomial is an array of
+ *      2^log2_large_domain (+4) Fr values on the device, as left behind by the coset FFTs ("*_fft" arrays of the proving key). ---- */
+enum bbg_quotient_poly { /* index into d_polys[]; entries a widget does not read may be NULL */
+    BBG_QP_W_1 = 0, BBG_QP_W_2, BBG_QP_W_3, BBG_QP_W_4, BBG_QP_Z,
+    BBG_QP_SIGMA_1, BBG_QP_SIGMA_2, BBG_QP_SIGMA_3, BBG_QP_SIGMA_4,
+    BBG_QP_Q_1, BBG_QP_Q_2, BBG_QP_Q_3, BBG_QP_Q_4, BBG_QP_Q_5, BBG_QP_Q_M, BBG_QP_Q_C,
+    BBG_QP_Q_ARITH, BBG_QP_Q_FIXED_BASE, BBG_QP_Q_RANGE, BBG_QP_Q_LOGIC, BBG_QP_LAGRANGE_1,
+    BBG_QP_COUNT
+};
+enum bbg_quotient_widget {
+    BBG_WIDGET_PERMUTATION = 0,      /* ProverPermutationWidget<4,false> (permutation_widget_impl.hpp:316-420): ASSIGNS the quotient */
+    BBG_WIDGET_TURBO_ARITHMETIC = 1, /* TurboArithmeticKernel (turbo_arithmetic_widget.hpp): the transition widgets ACCUMULATE */
+    BBG_WIDGET_TURBO_FIXED_BASE = 2, /* TurboFixedBaseKernel */
+    BBG_WIDGET_TURBO_RANGE = 3,      /* TurboRangeKernel */
+    BBG_WIDGET_TURBO_LOGIC = 4       /* TurboLogicKernel */
+};
+/* challenges: 9 Montgomery Fr (4 limbs each) on the host -- alpha_base (this widget's starting power of alpha), alpha,
+ * beta, gamma, public_input_delta, g (the small domain's coset generator), k1, k2, k3 (fr::coset_generator(0..2)).
+ * alpha_base_out (may be NULL) receives the alpha_base for the next widget, as compute_quotient_contribution returns it. */
+int bbg_quotient_widget_device(bbg_ctx* ctx, int widget, const void* const d_polys[BBG_QP_COUNT], unsigned log2_large_domain,
+                               const uint64_t* challenges, void* d_quotient, uint64_t* alpha_base_out);
+
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
  * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (bucket window width: 0 = automatic [20 bits from n = 2^21 terms,
@@ -163,7 +186,7 @@ int bbg_dev_download(bbg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
  * 0 = recode + rocPRIM radix sort + offsets kernels; both feed the same accumulation and give identical results). */
 int bbg_set_option(bbg_ctx* ctx, const char* key, long value);
 /* Per-kernel timing with HIP events recorded on the launch stream.  Names: "msm_recode", "msm_sort", "msm_offsets",
- * "msm_accumulate", "msm_reduce", "ntt_pass".  enable(…, 1) clears previous samples. */
+ * "msm_accumulate", "msm_reduce", "ntt_pass", "quotient_widget".  enable(…, 1) clears previous samples. */
 int bbg_profile_enable(bbg_ctx* ctx, int on);
 int bbg_profile_get(bbg_ctx* ctx, const char* name, double* total_ms, size_t* launches);
 /* Field-level self test entry used by tests: out[i] = a[i] (op) b[i] computed by the device field code.

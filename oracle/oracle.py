@@ -584,3 +584,55 @@ class RefProver:
         if self.h:
             self.lib.refp_delete(self.h)
             self.h = None
+
+
+class RefWidgets:
+    """The reference's own quotient widgets of a TurboProver (permutation, turbo arithmetic / fixed base / range / logic) run
+    one at a time over caller-supplied "*_fft" arrays with a deterministic transcript (ref_prover_driver.cpp, refw_*)."""
+
+    # label of each polynomial in the order of include/bbg.h's bbg_quotient_poly
+    LABELS = ["w_1_fft", "w_2_fft", "w_3_fft", "w_4_fft", "z_fft", "sigma_1_fft", "sigma_2_fft", "sigma_3_fft", "sigma_4_fft",
+              "q_1_fft", "q_2_fft", "q_3_fft", "q_4_fft", "q_5_fft", "q_m_fft", "q_c_fft", "q_arith_fft", "q_ecc_1_fft",
+              "q_range_fft", "q_logic_fft", "lagrange_1"]
+
+    def __init__(self, prover):
+        self.prover = prover  # keeps the session (proving key) alive
+        L = self.lib = prover.lib
+        L.refw_new.argtypes = [vp]; L.refw_new.restype = vp
+        L.refw_delete.argtypes = [vp]
+        L.refw_poly_size.argtypes = [vp, ctypes.c_char_p]; L.refw_poly_size.restype = sz
+        L.refw_set_poly.argtypes = [vp, ctypes.c_char_p, vp, sz]; L.refw_set_poly.restype = cint
+        L.refw_get_poly.argtypes = [vp, ctypes.c_char_p, vp, sz]; L.refw_get_poly.restype = cint
+        L.refw_challenges.argtypes = [vp, vp]
+        L.refw_run_widget.argtypes = [vp, cint, vp, vp]; L.refw_run_widget.restype = cint
+        self.h = L.refw_new(prover.h)
+        if not self.h:
+            raise RuntimeError("refw_new failed")
+        self.m = 4 * prover.n  # large (coset) domain size
+
+    def set_poly(self, label, data):
+        a = _arr(data, 4)
+        assert self.lib.refw_set_poly(self.h, label.encode(), a.ctypes.data, a.shape[0]) == 0, label
+
+    def get_poly(self, label, count=None):
+        count = self.m if count is None else count
+        out = np.empty((count, 4), dtype=np.uint64)
+        assert self.lib.refw_get_poly(self.h, label.encode(), out.ctypes.data, count) == 0, label
+        return out
+
+    def challenges(self):
+        """(8, 4): alpha, beta, gamma, public_input_delta, k1, k2, k3, g  (Montgomery)."""
+        out = np.zeros((8, 4), dtype=np.uint64)
+        self.lib.refw_challenges(self.h, out.ctypes.data)
+        return out
+
+    def run(self, widget, alpha_base):
+        a = np.ascontiguousarray(alpha_base, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        assert self.lib.refw_run_widget(self.h, widget, a.ctypes.data, out.ctypes.data) == 0
+        return out
+
+    def free(self):
+        if self.h:
+            self.lib.refw_delete(self.h)
+            self.h = None

@@ -31,6 +31,7 @@
 #include <plonk/composer/turbo_composer.hpp>
 #include <plonk/proof_system/prover/prover.hpp>
 #include <plonk/proof_system/verifier/verifier.hpp>
+#include <plonk/proof_system/public_inputs/public_inputs.hpp>
 #include <plonk/reference_string/reference_string.hpp>
 #include <polynomials/polynomial_arithmetic.hpp>
 
@@ -323,5 +324,120 @@ int refp_verify(void* h)
 }
 
 void refp_delete(void* h) { delete (Session*)h; }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Quotient-widget harness: the reference's own widget objects of a TurboProver
+//   random_widgets[0]      = ProverPermutationWidget<4, false>
+//   transition_widgets[0..3] = ProverTurboArithmeticWidget, ProverTurboFixedBaseWidget, ProverTurboRangeWidget,
+//                              ProverTurboLogicWidget                      (turbo_composer.cpp:735-752)
+// run one at a time over caller-supplied polynomial data with a DETERMINISTIC transcript (fixed dummy commitments, the
+// pattern of transition_widgets/create_dummy_transcript.hpp), so that their compute_quotient_contribution
+// (permutation_widget_impl.hpp:316-420, transition_widget.hpp:262-290) can be compared with the GPU kernels on seeded
+// inputs and recorded as golden digests.  The widgets are pure functions of the key's *_fft arrays and the challenges.
+struct WidgetHarness {
+    Session* session;
+    transcript::StandardTranscript transcript;
+    WidgetHarness(Session* s)
+        : session(s)
+        , transcript(waffle::TurboComposer::create_manifest(0), waffle::turbo_settings::hash_type, waffle::turbo_settings::num_challenge_bytes)
+    {
+        std::vector<uint8_t> g1_vector(64, 1);
+        transcript.add_element("circuit_size", { 1, 2, 3, 4 });
+        transcript.add_element("public_input_size", { 0, 0, 0, 0 });
+        transcript.apply_fiat_shamir("init");
+        transcript.apply_fiat_shamir("eta");
+        transcript.add_element("public_inputs", {});
+        transcript.add_element("W_1", g1_vector);
+        transcript.add_element("W_2", g1_vector);
+        transcript.add_element("W_3", g1_vector);
+        transcript.add_element("W_4", g1_vector);
+        transcript.apply_fiat_shamir("beta");
+        transcript.add_element("Z", g1_vector);
+        transcript.apply_fiat_shamir("alpha");
+    }
+};
+
+static polynomial* find_poly(Session* s, const std::string& label)
+{
+    auto* key = s->prover->key.get();
+    if (label == "quotient_large") return &key->quotient_large;
+    if (label == "lagrange_1") return &key->lagrange_1;
+    auto it = key->wire_ffts.find(label);
+    if (it != key->wire_ffts.end()) return &it->second;
+    it = key->constraint_selector_ffts.find(label);
+    if (it != key->constraint_selector_ffts.end()) return &it->second;
+    it = key->permutation_selector_ffts.find(label);
+    if (it != key->permutation_selector_ffts.end()) return &it->second;
+    return nullptr;
+}
+
+extern "C" {
+
+void* refw_new(void* session)
+{
+    try {
+        return new WidgetHarness((Session*)session);
+    } catch (...) {
+        return nullptr;
+    }
+}
+void refw_delete(void* w) { delete (WidgetHarness*)w; }
+
+// size (in field elements) of a named polynomial of the proving key: "w_1_fft".."w_4_fft", "z_fft", "sigma_1_fft"..,
+// "q_1_fft".."q_5_fft", "q_m_fft", "q_c_fft", "q_arith_fft", "q_ecc_1_fft", "q_range_fft", "q_logic_fft",
+// "lagrange_1", "quotient_large"; 0 if unknown
+size_t refw_poly_size(void* w, const char* label)
+{
+    polynomial* p = find_poly(((WidgetHarness*)w)->session, label);
+    return p ? p->get_max_size() : 0;
+}
+int refw_set_poly(void* w, const char* label, const uint64_t* data, size_t count)
+{
+    polynomial* p = find_poly(((WidgetHarness*)w)->session, label);
+    if (!p || count > p->get_max_size()) return -1;
+    std::memcpy((void*)&(*p)[0], data, count * 32);
+    return 0;
+}
+int refw_get_poly(void* w, const char* label, uint64_t* out, size_t count)
+{
+    polynomial* p = find_poly(((WidgetHarness*)w)->session, label);
+    if (!p || count > p->get_max_size()) return -1;
+    std::memcpy(out, (const void*)&(*p)[0], count * 32);
+    return 0;
+}
+// out[0..3] = alpha, beta, gamma, public_input_delta (4 limbs each, Montgomery), out[4] = small-domain coset generators
+// k_1..k_3 = fr::coset_generator(0..2) and the small domain's generator g (work root start) as out[4..7]
+void refw_challenges(void* wp, uint64_t* out)
+{
+    auto* w = (WidgetHarness*)wp;
+    auto* key = w->session->prover->key.get();
+    fr alpha = fr::serialize_from_buffer(w->transcript.get_challenge("alpha").begin());
+    fr beta = fr::serialize_from_buffer(w->transcript.get_challenge("beta").begin());
+    fr gamma = fr::serialize_from_buffer(w->transcript.get_challenge("beta", 1).begin());
+    std::vector<fr> public_inputs = many_from_buffer<fr>(w->transcript.get_element("public_inputs"));
+    fr delta = waffle::compute_public_input_delta<fr>(public_inputs, beta, gamma, key->small_domain.root);
+    fr vals[8] = { alpha, beta, gamma, delta, fr::coset_generator(0), fr::coset_generator(1), fr::coset_generator(2),
+                   key->small_domain.generator };
+    std::memcpy(out, vals, sizeof(vals));
+}
+// widget 0 = permutation (ASSIGNS quotient_large), 1..4 = turbo arithmetic / fixed base / range / logic (ACCUMULATE into
+// it); alpha_base in, returns the widget's updated alpha_base in alpha_out.  Returns 0, or -1 on error.
+int refw_run_widget(void* wp, int widget, const uint64_t* alpha_base, uint64_t* alpha_out)
+{
+    try {
+        auto* w = (WidgetHarness*)wp;
+        auto& p = *w->session->prover;
+        fr a{ alpha_base[0], alpha_base[1], alpha_base[2], alpha_base[3] };
+        fr r;
+        if (widget == 0) r = p.random_widgets.at(0)->compute_quotient_contribution(a, w->transcript);
+        else r = p.transition_widgets.at((size_t)widget - 1)->compute_quotient_contribution(a, w->transcript);
+        std::memcpy(alpha_out, &r, 32);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
 
 } // extern "C"

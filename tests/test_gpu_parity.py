@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI (libbbg.so); results are compared
 bit-exactly, on canonical values, with the oracle on the same seeded inputs, with the golden vectors recorded from the
 compiled reference, and -- at BASELINE.json's full sizes -- through size-independent algebraic properties."""
+import json
 import os
 
 import numpy as np
@@ -434,6 +435,73 @@ def test_msm_2_22_properties_wide_windows(pkg, oracle, bbg, golden):
     assert np.array_equal(neg[:4], whole[:4])
     assert np.array_equal(neg[4:], oracle.fe_sub(1, np.zeros((1, 4), dtype=np.uint64), whole[4:])[0])
     srs.free()
+
+
+# ---------------------------------------------------------------------------------------------- quotient widgets (8f-2)
+def _widget_inputs(pkg, m):
+    from oracle.oracle import RefWidgets
+    seed = 0xBB254 + 9000
+    return [pkg.synthetic_scalars(seed + k, m) for k in range(len(RefWidgets.LABELS))]
+
+
+def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0):
+    """Uploads the 21 polynomials, runs the five widgets in the prover's order; yields (alpha_out, quotient) after each."""
+    import torch
+    dev = [torch.from_numpy(p.view(np.int64).reshape(-1)).cuda() for p in polys]
+    quot = torch.zeros((1 << log2_large) * 4, dtype=torch.int64, device="cuda")
+    ptrs = [d.data_ptr() for d in dev]
+    alpha_base = alpha0
+    for widget in range(5):
+        ch = ch9.copy()
+        ch[0] = alpha_base
+        alpha_base = bbg.quotient_widget_device(widget, ptrs, log2_large, ch, quot.data_ptr())
+        bbg.sync()
+        yield alpha_base, quot.cpu().numpy().view(np.uint64).reshape(-1, 4)
+
+
+def test_quotient_widgets_vs_reference_golden(pkg, oracle, bbg):
+    """Permutation + turbo arithmetic / fixed-base / range / logic quotient contributions on the 4n coset domain against digests
+    recorded from the reference's own widget objects (tests/golden/widgets.json, gen_golden_widgets.py), n = 2^6 and 2^10."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "widgets.json")) as f:
+        G = json.load(f)
+    for case in G["cases"]:
+        log2_large = case["log2n"] + 2
+        m = 1 << log2_large
+        c = case["challenges"]
+        ch9 = np.stack([unhex(c[k], 4)[0] for k in ("alpha", "alpha", "beta", "gamma", "public_input_delta", "g", "k1", "k2", "k3")])
+        polys = _widget_inputs(pkg, m)
+        for rec, (alpha_out, q) in zip(case["widgets"], _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, unhex(c["alpha"], 4)[0])):
+            assert np.array_equal(oracle.canon(0, alpha_out.reshape(1, 4))[0], unhex(rec["alpha_base_out"], 4)[0]), rec["widget"]
+            qc = oracle.canon(0, q)
+            assert np.array_equal(qc[:2], unhex(rec["quotient_first2"], 4)), rec["widget"]
+            assert sha(qc) == rec["quotient_sha256"], rec["widget"]
+
+
+def test_quotient_widgets_vs_reference_live(pkg, oracle, bbg):
+    """Same comparison, element by element, against the reference widgets run live at n = 2^14 (4n = 2^16)."""
+    from oracle.oracle import RefProver, RefWidgets, prover_available
+    if not prover_available():
+        pytest.skip("oracle/_ref/libbbprover.so absent on this machine")
+    log2n = 14
+    n = 1 << log2n
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    P = RefProver(n - 24, 5, oracle.srs_powers(x, n + 1), x)
+    W = RefWidgets(P)
+    m = 4 * n
+    polys = _widget_inputs(pkg, m)
+    for label, p in zip(RefWidgets.LABELS, polys):
+        W.set_poly(label, p)
+    ch = W.challenges()
+    ch9 = np.stack([ch[0], ch[0], ch[1], ch[2], ch[3], ch[7], ch[4], ch[5], ch[6]])
+    alpha_base = ch[0]
+    for widget, (alpha_out, q) in enumerate(_run_gpu_widgets(pkg, bbg, polys, log2n + 2, ch9, ch[0])):
+        want_alpha = W.run(widget, alpha_base)
+        want_q = oracle.canon(0, W.get_poly("quotient_large", m))
+        assert np.array_equal(oracle.canon(0, alpha_out.reshape(1, 4)), oracle.canon(0, want_alpha.reshape(1, 4))), widget
+        assert np.array_equal(oracle.canon(0, q), want_q), widget
+        alpha_base = want_alpha
+    W.free()
+    P.free()
 
 
 # ---------------------------------------------------------------------------------------------- the reference PROVER seam
