@@ -232,6 +232,30 @@ if "hostpath" in stages:
                 t0 = time.perf_counter(); B._ck(B.lib.bbg_ntt(B.ctx, ctypes.c_void_p(ptr), lg, 0, 0, None)); ts.append(time.perf_counter() - t0)
             print(f"bbg_ntt host path 2^{lg} ({name} coeffs, in place): best {min(ts)*1e3:.3f} ms  median {sorted(ts)[2]*1e3:.3f} ms", flush=True)
         srs.free()
+if "quotient" in stages:
+    import torch
+    names = ["permutation", "turbo_arithmetic", "turbo_fixed_base", "turbo_range", "turbo_logic"]
+    reads = [12, 13, 18, 7, 10]  # 32-byte values touched per point (distinct arrays + shifted rows + quotient read/write)
+    for lg in (20, 22, 24):
+        m = 1 << lg
+        polys = [torch.from_numpy(inp.synthetic_scalars(100 + k, m).view(np.int64).reshape(-1)).cuda() for k in range(21)]
+        quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+        ptrs = [p.data_ptr() for p in polys]
+        ch = inp.synthetic_scalars(7, 9)
+        B.ntt_prepare(lg)
+        tot = 0.0
+        for w in range(5):
+            B.quotient_widget_device(w, ptrs, lg, ch, quot.data_ptr()); B.sync()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                B.quotient_widget_device(w, ptrs, lg, ch, quot.data_ptr())
+            B.sync()
+            dt = (time.perf_counter() - t0) / reps
+            tot += dt
+            print(f"quotient widget {names[w]:18s} 4n=2^{lg}: {dt*1e3:.3f} ms  {reads[w]*32*m/dt/1e9:.0f} GB/s ({reads[w]} x 32 B per point)", flush=True)
+        print(f"all five widgets 4n=2^{lg}: {tot*1e3:.3f} ms", flush=True)
+        del polys, quot
 if "msmexp" in stages:
     import torch
     n = 1 << 20
