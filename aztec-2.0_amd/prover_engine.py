@@ -1,0 +1,82 @@
+"""Host-side glue that puts libbbg.so behind a PLONK prover's work queue -- the Python mirror of the callbacks a barretenberg
+maintainer writes in C++.  Works on raw host addresses of the prover's own buffers, in place:
+
+    msm_raw(scalars, count, out)                    work_queue SCALAR_MULTIPLICATION (work_queue.hpp:218-245) -> bbg_msm
+    fft_item_raw(wire, log2n, wire_fft, log2_4n)    work_queue FFT (:252-264)                                 -> bbg_coset_fft_extend
+    coset_fft_raw / ifft_raw                                                                                  -> bbg_ntt
+    round4_raw(poly_ptrs, challenges, log2n, q)     the quotient of execute_fourth_round (prover.cpp:304-343): the five TurboPLONK
+                                                    widgets, divide_by_pseudo_vanishing_polynomial and coset_ifft on the device;
+                                                    selector / sigma / L_1 arrays are uploaded once per proving key
+
+Used by tests/test_gpu_parity.py and bench_prover_real.py with the reference's real prover on the other side
+(oracle/ref_prover_driver.cpp).  Nothing here imports the oracle.
+"""
+import ctypes
+
+import numpy as np
+
+from . import binding
+
+
+class WorkQueueEngine:
+    """MSM / coset FFT / iFFT items through the host entry points (the FFT item as copy + coset_fft + 4 appended values on the
+    prover's side, exactly as work_queue::process_queue does it)."""
+    raw = True
+
+    def __init__(self, bbg, srs):
+        self.bbg, self.srs = bbg, srs
+
+    def msm_raw(self, scalars, count, out):
+        b = self.bbg
+        b._ck(b.lib.bbg_msm(b.ctx, self.srs.handle, ctypes.c_void_p(scalars), 0, count, ctypes.c_void_p(out)))
+
+    def coset_fft_raw(self, coeffs, log2_domain, generator_size):
+        b = self.bbg
+        b._ck(b.lib.bbg_ntt(b.ctx, ctypes.c_void_p(coeffs), log2_domain, binding.COSET_FFT, generator_size, None))
+
+    def ifft_raw(self, coeffs, log2n):
+        b = self.bbg
+        b._ck(b.lib.bbg_ntt(b.ctx, ctypes.c_void_p(coeffs), log2n, binding.IFFT, 0, None))
+
+
+class FusedFftEngine(WorkQueueEngine):
+    """+ the whole FFT work item as one call (n coefficients up, 4n + 4 values down)."""
+
+    def fft_item_raw(self, wire, log2n, wire_fft, log2_domain):
+        b = self.bbg
+        b._ck(b.lib.bbg_coset_fft_extend(b.ctx, ctypes.c_void_p(wire), log2n, log2_domain, ctypes.c_void_p(wire_fft)))
+
+
+class Round4Engine(FusedFftEngine):
+    """+ the quotient of execute_fourth_round on the device."""
+
+    def __init__(self, bbg, srs):
+        super().__init__(bbg, srs)
+        self._static = {}  # per proving key: device copies of the arrays that do not change between proofs
+
+    def _upload(self, host_ptr, count):
+        import torch
+        t = torch.empty(count * 4, dtype=torch.int64, device="cuda")
+        b = self.bbg
+        b._ck(b.lib.bbg_dev_upload(b.ctx, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(host_ptr), count * 32))
+        return t
+
+    def round4_raw(self, poly_ptrs, challenges, log2n, quotient_ptr):
+        import torch
+        b = self.bbg
+        m = 4 << log2n
+        key = (tuple(poly_ptrs[5:]), log2n)
+        if key not in self._static:  # sigma_1..4, q_*, L_1 on the coset: fixed per proving key
+            self._static = {key: [self._upload(p, m) for p in poly_ptrs[5:]]}
+        wires = [self._upload(p, m) for p in poly_ptrs[:5]]  # w_1..4, z: new for every proof
+        dev = wires + self._static[key]
+        ptrs = [t.data_ptr() for t in dev]
+        quot = torch.empty(m * 4, dtype=torch.int64, device="cuda")
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64).copy()
+        alpha_base = ch[0].copy()
+        for widget in range(5):  # the prover's order: permutation, arithmetic, fixed base, range, logic
+            ch[0] = alpha_base
+            alpha_base = b.quotient_widget_device(widget, ptrs, log2n + 2, ch, quot.data_ptr())
+        b.divide_by_pseudo_vanishing_device(quot.data_ptr(), log2n, log2n + 2, 4)
+        b.ntt_device(quot.data_ptr(), log2n + 2, binding.COSET_IFFT)
+        b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(quotient_ptr), ctypes.c_void_p(quot.data_ptr()), m * 32))

@@ -551,9 +551,13 @@ class RefProver:
         self.t_rounds = self.t_queue = 0.0  # seconds in the prover's own round logic / in the MSM+FFT work items
         self.t_round = [0.0] * 7           # per execute_*_round (0 = preamble)
         import time
+        self.round4_mismatch = None
         for k in range(7):
             t0 = time.perf_counter()
-            self.lib.refp_execute_round(self.h, k)
+            if k == 4 and engine is not None and hasattr(engine, "round4_raw"):
+                self._round4_with(engine, check)
+            else:
+                self.lib.refp_execute_round(self.h, k)
             t1 = time.perf_counter()
             self.t_rounds += t1 - t0
             self.t_round[k] = t1 - t0
@@ -576,6 +580,30 @@ class RefProver:
         buf = (ctypes.c_uint8 * size)()
         self.lib.refp_export_proof(self.h, buf, size)
         return bytes(buf)
+
+    def _round4_with(self, engine, check):
+        """execute_fourth_round with the quotient (widgets + divide_by_pseudo_vanishing + coset_ifft) computed by the engine."""
+        L = self.lib
+        L.refp_round4_begin.argtypes = [vp, vp, vp, vp]; L.refp_round4_begin.restype = cint
+        L.refp_round4_reference_quotient.argtypes = [vp]; L.refp_round4_reference_quotient.restype = cint
+        L.refp_round4_end.argtypes = [vp]; L.refp_round4_end.restype = cint
+        ptrs = (ctypes.c_void_p * 21)()
+        ch = np.zeros((9, 4), dtype=np.uint64)
+        q = ctypes.c_void_p()
+        log2n = L.refp_round4_begin(self.h, ptrs, ch.ctypes.data, ctypes.byref(q))
+        if log2n < 0:
+            raise RuntimeError("refp_round4_begin failed")
+        m = 4 << log2n
+        engine.round4_raw([int(p) for p in ptrs], ch, log2n, q.value)
+        if check:
+            got = np.ctypeslib.as_array(ctypes.cast(q.value, ctypes.POINTER(ctypes.c_uint64)), shape=(m, 4)).copy()
+            assert L.refp_round4_reference_quotient(self.h) == 0
+            want = np.ctypeslib.as_array(ctypes.cast(q.value, ctypes.POINTER(ctypes.c_uint64)), shape=(m, 4))
+            from_canon = Oracle().canon
+            self.round4_mismatch = int(not np.array_equal(from_canon(0, got), from_canon(0, want)))
+            self.mismatches += self.round4_mismatch
+        if L.refp_round4_end(self.h) != 0:
+            raise RuntimeError("refp_round4_end failed")
 
     def verify(self):
         return int(self.lib.refp_verify(self.h))

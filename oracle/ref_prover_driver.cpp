@@ -441,3 +441,70 @@ int refw_run_widget(void* wp, int widget, const uint64_t* alpha_base, uint64_t* 
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 4 through the prover's public members (prover.cpp:275-363): flush, Fiat-Shamir "alpha", [quotient = widgets,
+// divide_by_pseudo_vanishing_polynomial, coset_ifft -- delegated], compute_quotient_pre_commitment.  Lets the tests put the
+// GPU quotient kernels (csrc/quotient.hip + poly.hip + ntt.hip) inside a real proof and have the reference verifier judge it.
+static const char* const ROUND4_LABELS[21] = { "w_1_fft", "w_2_fft", "w_3_fft", "w_4_fft", "z_fft", "sigma_1_fft", "sigma_2_fft",
+                                               "sigma_3_fft", "sigma_4_fft", "q_1_fft", "q_2_fft", "q_3_fft", "q_4_fft", "q_5_fft",
+                                               "q_m_fft", "q_c_fft", "q_arith_fft", "q_ecc_1_fft", "q_range_fft", "q_logic_fft",
+                                               "lagrange_1" };
+extern "C" {
+// poly_ptrs[21]: host addresses of the key's arrays in include/bbg.h's bbg_quotient_poly order; challenges[9][4] in the order
+// bbg_quotient_widget_device takes them (alpha_base = alpha); *quotient = &quotient_large[0] (4n entries to fill with the
+// COEFFICIENTS of the quotient polynomial).  Returns log2(n), or -1.
+int refp_round4_begin(void* h, const uint64_t** poly_ptrs, uint64_t* challenges, uint64_t** quotient)
+{
+    try {
+        auto* s = (Session*)h;
+        auto& p = *s->prover;
+        auto* key = p.key.get();
+        p.queue.flush_queue();
+        p.transcript.apply_fiat_shamir("alpha");
+        for (int k = 0; k < 21; k++) {
+            polynomial* poly = find_poly(s, ROUND4_LABELS[k]);
+            if (!poly) return -1;
+            poly_ptrs[k] = (const uint64_t*)&(*poly)[0];
+        }
+        fr alpha = fr::serialize_from_buffer(p.transcript.get_challenge("alpha").begin());
+        fr beta = fr::serialize_from_buffer(p.transcript.get_challenge("beta").begin());
+        fr gamma = fr::serialize_from_buffer(p.transcript.get_challenge("beta", 1).begin());
+        std::vector<fr> public_inputs = many_from_buffer<fr>(p.transcript.get_element("public_inputs"));
+        fr delta = waffle::compute_public_input_delta<fr>(public_inputs, beta, gamma, key->small_domain.root);
+        fr vals[9] = { alpha, alpha, beta, gamma, delta, key->small_domain.generator, fr::coset_generator(0), fr::coset_generator(1),
+                       fr::coset_generator(2) };
+        std::memcpy(challenges, vals, sizeof(vals));
+        *quotient = (uint64_t*)&key->quotient_large[0];
+        return (int)key->small_domain.log2_size;
+    } catch (...) {
+        return -1;
+    }
+}
+// the reference's own computation of the same thing (prover.cpp:304-343), for comparison: fills quotient_large
+int refp_round4_reference_quotient(void* h)
+{
+    try {
+        auto& p = *((Session*)h)->prover;
+        auto* key = p.key.get();
+        fr alpha_base = fr::serialize_from_buffer(p.transcript.get_challenge("alpha").begin());
+        for (auto& widget : p.random_widgets) alpha_base = widget->compute_quotient_contribution(alpha_base, p.transcript);
+        for (auto& widget : p.transition_widgets) alpha_base = widget->compute_quotient_contribution(alpha_base, p.transcript);
+        polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial(key->quotient_large.get_coefficients(), key->small_domain,
+                                                                     key->large_domain);
+        key->quotient_large.coset_ifft(key->large_domain);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+int refp_round4_end(void* h)
+{
+    try {
+        ((Session*)h)->prover->compute_quotient_pre_commitment();
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+} // extern "C"

@@ -562,6 +562,23 @@ def test_reference_prover_linked_against_shim(pkg, oracle, bbg):
     P.free()
 
 
+def test_reference_prover_round4_on_gpu(pkg, oracle, bbg):
+    """execute_fourth_round's quotient (five widgets + divide_by_pseudo_vanishing_polynomial + coset_ifft, prover.cpp:304-343)
+    computed on the device inside a REAL proof of the reference prover: the resulting quotient coefficients equal the
+    reference's (canonical), every MSM / FFT item is bit-exact, and the reference's TurboVerifier accepts the proof."""
+    from oracle.oracle import RefProver, prover_available
+    if not prover_available():
+        pytest.skip("oracle/_ref/libbbprover.so absent on this machine")
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    P = RefProver(1 << 12, 13, oracle.srs_powers(x, (2 << 12) + 1), x)
+    srs = bbg.srs_register(P.monomials())
+    proof = P.prove(pkg.prover_engine.Round4Engine(bbg, srs), check=True)
+    assert P.round4_mismatch == 0 and P.mismatches == 0
+    assert len(proof) > 0 and P.verify() == 1
+    srs.free()
+    P.free()
+
+
 # ---------------------------------------------------------------------------------------------- the C++ drop-in shim
 def test_shim_reference_api_on_gpu():
     """oracle/_ref/shim_check: barretenberg's own TUs + shim/bbg_barretenberg_shim.cpp, MSM/FFT entry points wrapped at
