@@ -34,6 +34,7 @@ int ensure_buffer(void** buf, size_t* have, size_t need)
 }
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st);
 int msm_pick_window(const bbg_ctx* ctx, size_t n);
+int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
 int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
                     uint64_t* alpha_out, hipStream_t st);
 int msm_windows_for(int c);
@@ -544,6 +545,14 @@ int bbg_coset_fft_split_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, siz
     if (!d_coeffs) { set_error("bbg_coset_fft_split: null coeffs"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     return ntt_coset_split(ctx, d_coeffs, log2n, ext, ctx->stream);
+}
+
+int bbg_poly_linear_combination_device(bbg_ctx* ctx, const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base,
+                                       void* d_out, size_t n)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return poly_lincomb(d_polys, scalars, count, d_base, d_out, n, ctx->stream);
 }
 
 int bbg_quotient_widget_device(bbg_ctx* ctx, int widget, const void* const d_polys[BBG_QP_COUNT], unsigned log2_large_domain,

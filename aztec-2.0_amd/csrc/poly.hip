@@ -6,6 +6,8 @@
 //   divide_by_pseudo_vanishing_polynomial:628-725   pointwise division by Z*_H on the coset of the target domain
 // All results are the same field elements the reference computes (compared on canonical values).
 #include "bbg_internal.h"
+
+#include <cstring>
 #include "ntt_consts.hip.h"
 
 namespace bbg {
@@ -33,6 +35,43 @@ int poly_binop(int op, const void* a, const void* b, void* r, size_t n, hipStrea
     if (op == 0) hipLaunchKernelGGL(k_poly_binop<0>, dim3(grid), dim3(256), 0, st, (const Fr*)a, (const Fr*)b, (Fr*)r, n);
     else if (op == 1) hipLaunchKernelGGL(k_poly_binop<1>, dim3(grid), dim3(256), 0, st, (const Fr*)a, (const Fr*)b, (Fr*)r, n);
     else hipLaunchKernelGGL(k_poly_binop<2>, dim3(grid), dim3(256), 0, st, (const Fr*)a, (const Fr*)b, (Fr*)r, n);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+// out[i] = base[i] + sum_k polys[k][i] * scalars[k]   (base may be null = 0; out may alias base)
+// KateCommitmentScheme::batch_open's accumulation of the opening polynomials (kate_commitment_scheme.cpp:216-226): ~25
+// polynomials x one transcript challenge each.  One product per term against 32 B of traffic: balanced between the
+// multiplier and HBM.
+constexpr int LC_MAX = 32;
+struct LinCombArgs {
+    const Fr* polys[LC_MAX];
+    Fr scalars[LC_MAX];
+    int count;
+};
+__global__ void __launch_bounds__(256) k_poly_lincomb(LinCombArgs a, const Fr* __restrict__ base, Fr* out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = base ? fe_load<FrP>(base + i) : Fr::zero();
+        for (int k = 0; k < a.count; k++) acc = fe_add(acc, fe_mul(fe_load<FrP>(a.polys[k] + i), a.scalars[k]));
+        fe_store<FrP>(out + i, acc);
+    }
+}
+int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st)
+{
+    if (count > (size_t)LC_MAX) { set_error("bbg_poly_linear_combination_device: at most 32 terms per call"); return BBG_E_INVALID; }
+    if ((count && (!d_polys || !scalars)) || !d_out) { set_error("bbg_poly_linear_combination_device: null argument"); return BBG_E_INVALID; }
+    if (n == 0) return BBG_OK;
+    LinCombArgs a;
+    a.count = (int)count;
+    for (size_t k = 0; k < count; k++) {
+        if (!d_polys[k]) { set_error("bbg_poly_linear_combination_device: null polynomial"); return BBG_E_INVALID; }
+        a.polys[k] = (const Fr*)d_polys[k];
+        memcpy(&a.scalars[k], scalars + 4 * k, 32);
+    }
+    int grid = grid_for(n, 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(k_poly_lincomb, dim3(grid), dim3(256), 0, st, a, (const Fr*)d_base, (Fr*)d_out, n);
     BBG_HIP(hipGetLastError());
     return BBG_OK;
 }

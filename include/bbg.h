@@ -141,6 +141,11 @@ int bbg_cross_dft_device(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned l
  * polynomial_arithmetic::add / sub / mul (polynomials/polynomial_arithmetic.cpp:486-505): r[i] = a[i] (op) b[i], op = 0 add,
  * 1 sub, 2 mul; r may alias a or b. */
 int bbg_poly_op_device(bbg_ctx* ctx, int op, const void* d_a, const void* d_b, void* d_r, size_t n);
+/* out[i] = base[i] + sum_k polys[k][i] * scalars[k], k < count <= 32 (base may be NULL = 0; out may alias base): the
+ * accumulation of the opening polynomials in KateCommitmentScheme::batch_open (kate_commitment_scheme.cpp:216-226).
+ * d_polys: host array of device addresses; scalars: count Montgomery Fr on the host. */
+int bbg_poly_linear_combination_device(bbg_ctx* ctx, const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base,
+                                       void* d_out, size_t n);
 /* polynomial_arithmetic::evaluate (:507-538): out = sum_i coeffs[i] z^i (canonical Montgomery).  Synchronous. */
 int bbg_poly_evaluate_device(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
 /* polynomial_arithmetic::compute_kate_opening_coefficients (:727-750): dest = coefficients of (F(X) - F(z)) / (X - z),

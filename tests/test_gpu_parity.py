@@ -437,6 +437,32 @@ def test_msm_2_22_properties_wide_windows(pkg, oracle, bbg, golden):
     srs.free()
 
 
+def test_poly_linear_combination(pkg, oracle, bbg):
+    """opening_poly[i] = t[i] + sum_k poly_k[i] * nu_k (kate_commitment_scheme.cpp:216-226) against the oracle's field ops."""
+    import torch
+    n, k = 5000, 25
+    polys = [pkg.synthetic_scalars(600 + j, n) for j in range(k)]
+    scal = pkg.synthetic_scalars(700, k)
+    base = pkg.synthetic_scalars(701, n)
+    want = oracle.canon(0, base)
+    for j in range(k):
+        want = oracle.fe_add(0, want, oracle.fe_mul(0, polys[j], np.tile(scal[j], (n, 1))))
+    dev = [torch.from_numpy(p.view(np.int64).reshape(-1)).cuda() for p in polys]
+    dbase = torch.from_numpy(base.view(np.int64).reshape(-1)).cuda()
+    out = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+    bbg.poly_linear_combination_device([d.data_ptr() for d in dev], scal, dbase.data_ptr(), out.data_ptr(), n)
+    bbg.sync()
+    assert np.array_equal(oracle.canon(0, out.cpu().numpy().view(np.uint64).reshape(-1, 4)), want)
+    bbg.poly_linear_combination_device([d.data_ptr() for d in dev[:3]], scal[:3], None, dbase.data_ptr(), n)  # no base, output elsewhere
+    bbg.sync()
+    want3 = oracle.canon(0, np.zeros((n, 4), dtype=np.uint64))
+    for j in range(3):
+        want3 = oracle.fe_add(0, want3, oracle.fe_mul(0, polys[j], np.tile(scal[j], (n, 1))))
+    assert np.array_equal(oracle.canon(0, dbase.cpu().numpy().view(np.uint64).reshape(-1, 4)), want3)
+    with pytest.raises(pkg.BbgError):
+        bbg.poly_linear_combination_device([dev[0].data_ptr()] * 33, pkg.synthetic_scalars(1, 33), None, out.data_ptr(), n)
+
+
 # ---------------------------------------------------------------------------------------------- quotient widgets (8f-2)
 def _widget_inputs(pkg, m):
     from oracle.oracle import RefWidgets
