@@ -74,6 +74,7 @@ def load_library():
         "bbg_coset_fft_extend": (cint, [vp, vp, ctypes.c_uint, ctypes.c_uint, vp]),
         "bbg_quotient_widget_device": (cint, [vp, cint, vp, ctypes.c_uint, vp, vp, vp]),
         "bbg_poly_linear_combination_device": (cint, [vp, vp, vp, sz, vp, vp, sz]),
+        "bbg_permutation_grand_product_device": (cint, [vp, vp, vp, ctypes.c_uint, vp, vp]),
         "bbg_ntt_device": (cint, [vp, vp, ctypes.c_uint, cint, sz, vp]),
         "bbg_ntt_prepare": (cint, [vp, ctypes.c_uint]),
         "bbg_coset_fft_split": (cint, [vp, vp, ctypes.c_uint, sz]),
@@ -106,7 +107,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
-    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device",
+    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device", "bbg_permutation_grand_product_device",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
@@ -258,6 +259,12 @@ class Bbg:
         sc = _u64(scalars, 4) if len(d_polys) else np.zeros((1, 4), dtype=np.uint64)
         self._ck(self.lib.bbg_poly_linear_combination_device(self.ctx, arr, sc.ctypes.data, len(d_polys),
                                                              ctypes.c_void_p(d_base) if d_base else None, ctypes.c_void_p(d_out), n))
+
+    def permutation_grand_product_device(self, d_wires, d_sigmas, log2n, beta, gamma, ks, d_z):
+        w = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(int(p)) for p in d_wires])
+        s_ = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(int(p)) for p in d_sigmas])
+        ch = np.ascontiguousarray(np.concatenate([np.reshape(beta, (1, 4)), np.reshape(gamma, (1, 4)), np.reshape(ks, (3, 4))]), dtype=np.uint64)
+        self._ck(self.lib.bbg_permutation_grand_product_device(self.ctx, w, s_, log2n, ch.ctypes.data, ctypes.c_void_p(d_z)))
 
     def quotient_widget_device(self, widget, d_polys, log2_large, challenges, d_quotient):
         """d_polys: list of BBG_QP_COUNT device addresses (0 = not supplied); challenges: (9, 4) uint64.  Returns the next alpha_base."""

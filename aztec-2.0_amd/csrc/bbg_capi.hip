@@ -34,6 +34,8 @@ int ensure_buffer(void** buf, size_t* have, size_t need)
 }
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st);
 int msm_pick_window(const bbg_ctx* ctx, size_t n);
+int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
+                              void* d_z, hipStream_t st);
 int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
 int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
                     uint64_t* alpha_out, hipStream_t st);
@@ -129,6 +131,7 @@ void bbg_destroy(bbg_ctx* ctx)
     }
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
     if (ctx->quot_setup) (void)hipFree(ctx->quot_setup);
+    if (ctx->gp_totals) (void)hipFree(ctx->gp_totals);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
     if (ctx->poly_scratch) (void)hipFree(ctx->poly_scratch);
@@ -553,6 +556,14 @@ int bbg_poly_linear_combination_device(bbg_ctx* ctx, const void* const* d_polys,
     CHECK_CTX(ctx);
     std::lock_guard<std::mutex> lk(ctx->mu);
     return poly_lincomb(d_polys, scalars, count, d_base, d_out, n, ctx->stream);
+}
+
+int bbg_permutation_grand_product_device(bbg_ctx* ctx, const void* const d_wires[4], const void* const d_sigmas[4], unsigned log2n,
+                                         const uint64_t* challenges, void* d_z)
+{
+    CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return permutation_grand_product(ctx, d_wires, d_sigmas, log2n, challenges, d_z, ctx->stream);
 }
 
 int bbg_quotient_widget_device(bbg_ctx* ctx, int widget, const void* const d_polys[BBG_QP_COUNT], unsigned log2_large_domain,

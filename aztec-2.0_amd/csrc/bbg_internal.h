@@ -85,6 +85,8 @@ struct bbg_ctx {
     bool ev_done_valid[2] = { false, false };
     unsigned long msm_seq = 0;
     bool msm_async_reduce = false;
+    void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
+    size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
     int msm_window = 0; // 0 = automatic (20 from n = 2^21, else 16), or 16 / 20

@@ -14,6 +14,8 @@
 // One thread per domain point (the permutation kernel walks 4 consecutive points to amortise w^i).  All reads are
 // coalesced 32-byte elements: this is the one part of the prover that is genuinely HBM-streaming.
 #include "bbg_internal.h"
+
+#include <cstring>
 #include "field.hip.h"
 #include "ntt_consts.hip.h"
 
@@ -268,7 +270,168 @@ __global__ void __launch_bounds__(256) k_quotient_turbo_logic(QuotientArgs a)
     fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(id, QLOAD(QP_QLOGIC, i))));
 }
 
+// ---------------------------------------------------------------------------------------------- permutation grand product
+// z of ProverPermutationWidget<4,false>::compute_round_commitments (permutation_widget_impl.hpp:48-268, steps 1-3; the
+// blinding of the last rows and the ifft stay with the caller):
+//   z[0] = 1,   z[j+1] = prod_{i <= j} N_i / D_i,   N_i = prod_k (w_k[i] + gamma + beta K_k w^i),  D_i = prod_k (w_k[i] + gamma + beta sigma_k[i])
+// The reference runs 8 serial prefix products and one batched inversion per thread; here:
+//   k_gp_ratio  : thread = GP_E consecutive rows: N_i, D_i, Montgomery's trick over the thread's GP_E denominators (one
+//                 Fermat inversion per thread), R_i = N_i / D_i, thread-local running products; per-thread totals
+//   k_gp_scan   : exclusive prefix PRODUCT of the thread totals (one block, serial over chunks + LDS Hillis-Steele)
+//   k_gp_apply  : z[j+1] = (thread prefix) * (local running product)
+constexpr int GP_E = 16;
+__device__ inline Fr fr_inverse(const Fr& a) // a^(r-2)
+{
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = FrP::MOD[i];
+    e[0] -= 2;
+    Fr acc = Fr::one();
+    for (int i = 253; i >= 0; i--) {
+        acc = fe_sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
+    }
+    return acc;
+}
+struct GpArgs {
+    const Fr* w[4];
+    const Fr* sigma[4];
+    Fr* z;       // n entries
+    Fr* totals;  // ceil(n / GP_E) thread totals, then their exclusive prefix products
+    size_t n;
+    const QuotientSetup* s; // beta, gamma, k1..k3
+    const DomainConsts* dc; // small (n) domain
+};
+__global__ void __launch_bounds__(128) k_gp_ratio(GpArgs a)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t j0 = t * GP_E;
+    if (j0 >= a.n) return;
+    const QuotientSetup& s = *a.s;
+    const int cnt = (a.n - j0 < (size_t)GP_E) ? (int)(a.n - j0) : GP_E;
+    Fr rb = fe_mul(s.beta, pow_from_table(a.dc->pow2_root, (uint64_t)j0)); // beta * w^j
+    const Fr root = a.dc->root;
+    Fr num[GP_E], pd[GP_E]; // numerators; running products of the denominators
+    Fr run = Fr::one();
+#pragma unroll 1
+    for (int e = 0; e < cnt; e++) {
+        const size_t j = j0 + e;
+        Fr wpg = fe_add(fe_load<FrP>(a.w[0] + j), s.gamma);
+        Fr n_ = fe_add(wpg, rb);
+        Fr d_ = fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[0] + j), s.beta));
+        wpg = fe_add(fe_load<FrP>(a.w[1] + j), s.gamma);
+        n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k1, rb)));
+        d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[1] + j), s.beta)));
+        wpg = fe_add(fe_load<FrP>(a.w[2] + j), s.gamma);
+        n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k2, rb)));
+        d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[2] + j), s.beta)));
+        wpg = fe_add(fe_load<FrP>(a.w[3] + j), s.gamma);
+        n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k3, rb)));
+        d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[3] + j), s.beta)));
+        num[e] = n_;
+        // z is written shifted by one (z[j+1] belongs to row j); park D_j there until the backward pass
+        if (j + 1 < a.n) fe_store<FrP>(a.z + j + 1, d_);
+        else fe_store<FrP>(a.z, d_); // the last row's denominator: slot 0 is free until k_gp_apply sets z[0] = 1
+        run = fe_mul(run, d_);
+        pd[e] = run;
+        rb = fe_mul(rb, root);
+    }
+    Fr inv = fr_inverse(run); // 1 / (D_j0 ... D_j0+cnt-1); a zero denominator has probability ~2^-250 (random beta, gamma)
+    Fr ratio[GP_E];
+#pragma unroll 1
+    for (int e = cnt - 1; e >= 0; e--) {
+        const size_t j = j0 + e;
+        const Fr d_ = fe_load<FrP>(j + 1 < a.n ? a.z + j + 1 : a.z);
+        const Fr dinv = e ? fe_mul(inv, pd[e - 1]) : inv; // 1 / D_j
+        inv = fe_mul(inv, d_);
+        ratio[e] = fe_mul(num[e], dinv);
+    }
+    run = Fr::one();
+#pragma unroll 1
+    for (int e = 0; e < cnt; e++) { // local running products R_j0 ... R_j
+        run = fe_mul(run, ratio[e]);
+        const size_t j = j0 + e;
+        if (j + 1 < a.n) fe_store<FrP>(a.z + j + 1, run);
+    }
+    fe_store<FrP>(a.totals + t, run);
+}
+__global__ void __launch_bounds__(256) k_gp_scan(Fr* totals, size_t count)
+{
+    __shared__ Fr sm[256];
+    const int tid = threadIdx.x;
+    const size_t per = (count + 255) / 256;
+    const size_t lo = (size_t)tid * per, hi = lo + per < count ? lo + per : count;
+    Fr run = Fr::one();
+    for (size_t i = lo; i < hi; i++) run = fe_mul(run, fe_load<FrP>(totals + i));
+    sm[tid] = run;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele product scan of the 256 chunk totals
+        Fr v = sm[tid];
+        if (tid >= d) v = fe_mul(sm[tid - d], v);
+        __syncthreads();
+        sm[tid] = v;
+        __syncthreads();
+    }
+    Fr pre = tid ? sm[tid - 1] : Fr::one(); // product of everything before this chunk
+    for (size_t i = lo; i < hi; i++) {
+        const Fr v = fe_load<FrP>(totals + i);
+        fe_store<FrP>(totals + i, pre); // exclusive prefix
+        pre = fe_mul(pre, v);
+    }
+}
+__global__ void __launch_bounds__(256) k_gp_apply(GpArgs a)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // row j -> z[j+1]
+    if (j == 0) fe_store<FrP>(a.z, Fr::one());
+    if (j + 1 >= a.n) return;
+    const size_t t = j / GP_E;
+    if (t == 0) return; // prefix of the first thread is 1
+    fe_store<FrP>(a.z + j + 1, fe_mul(fe_load<FrP>(a.z + j + 1), fe_load<FrP>(a.totals + t)));
+}
+
 int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
+
+int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
+                              void* d_z, hipStream_t st)
+{
+    if (log2n > 28) { set_error("bbg_permutation_grand_product_device: log2n > 28"); return BBG_E_INVALID; }
+    if (!d_wires || !d_sigmas || !challenges || !d_z) { set_error("bbg_permutation_grand_product_device: null argument"); return BBG_E_INVALID; }
+    GpArgs a;
+    for (int k = 0; k < 4; k++) {
+        if (!d_wires[k] || !d_sigmas[k]) { set_error("bbg_permutation_grand_product_device: null polynomial"); return BBG_E_INVALID; }
+        a.w[k] = (const Fr*)d_wires[k];
+        a.sigma[k] = (const Fr*)d_sigmas[k];
+    }
+    const size_t n = (size_t)1 << log2n, threads = (n + GP_E - 1) / GP_E;
+    int rc = ensure_buffer(&ctx->quot_setup, &ctx->quot_setup_bytes, sizeof(QuotientSetup) + 9 * sizeof(Fr));
+    if (rc) return rc;
+    rc = ensure_buffer(&ctx->gp_totals, &ctx->gp_totals_bytes, threads * sizeof(Fr));
+    if (rc) return rc;
+    QuotientSetup* setup = (QuotientSetup*)ctx->quot_setup;
+    Fr* in = (Fr*)((char*)ctx->quot_setup + sizeof(QuotientSetup));
+    // same set-up kernel as the widgets: slots alpha_base, alpha, delta, g are unused here (zeros)
+    uint64_t ch[9 * 4] = { 0 };
+    memcpy(ch + 2 * 4, challenges, 32);          // beta
+    memcpy(ch + 3 * 4, challenges + 4, 32);      // gamma
+    memcpy(ch + 6 * 4, challenges + 8, 3 * 32);  // k1..k3
+    BBG_HIP(hipMemcpyAsync(in, ch, sizeof(ch), hipMemcpyHostToDevice, st));
+    BBG_HIP(hipStreamSynchronize(st)); // ch lives on this stack frame
+    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setup, (const Fr*)in);
+    void* dc = nullptr;
+    rc = ntt_domain_consts(ctx, log2n, &dc);
+    if (rc) return rc;
+    a.z = (Fr*)d_z;
+    a.totals = (Fr*)ctx->gp_totals;
+    a.n = n;
+    a.s = setup;
+    a.dc = (const DomainConsts*)dc;
+    ProfScope ps(ctx, "grand_product", st);
+    hipLaunchKernelGGL(k_gp_ratio, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(256), 0, st, a.totals, threads);
+    hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
 
 // challenges: 9 Montgomery Fr on the host: alpha_base, alpha, beta, gamma, public_input_delta, g, k1, k2, k3
 int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,

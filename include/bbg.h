@@ -184,6 +184,14 @@ enum bbg_quotient_widget {
 int bbg_quotient_widget_device(bbg_ctx* ctx, int widget, const void* const d_polys[BBG_QP_COUNT], unsigned log2_large_domain,
                                const uint64_t* challenges, void* d_quotient, uint64_t* alpha_base_out);
 
+/* The permutation grand product z of ProverPermutationWidget<4,false>::compute_round_commitments
+ * (permutation_widget_impl.hpp:48-268, before the blinding of the last rows and the ifft): d_z[0] = 1,
+ * d_z[j+1] = prod_{i<=j} prod_k (w_k[i] + gamma + beta K_k w^i) / (w_k[i] + gamma + beta sigma_k[i]).  d_wires / d_sigmas: 4 device
+ * arrays of 2^log2n Lagrange-base values each; challenges: 5 Montgomery Fr on the host -- beta, gamma, k1, k2, k3; d_z: 2^log2n
+ * values.  Asynchronous on the context stream. */
+int bbg_permutation_grand_product_device(bbg_ctx* ctx, const void* const d_wires[4], const void* const d_sigmas[4], unsigned log2n,
+                                         const uint64_t* challenges, void* d_z);
+
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
  * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (bucket window width: 0 = automatic [20 bits from n = 2^21 terms,

@@ -971,3 +971,33 @@ int oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* Permutation grand product z (ProverPermutationWidget<4,false>::compute_round_commitments, reference
+ * plonk/proof_system/widgets/random_widgets/permutation_widget_impl.hpp:48-268, steps 1-3 without the blinding and the ifft):
+ *   z[0] = 1,  z[j+1] = z[j] * prod_k (w_k[j] + gamma + beta K_k w^j) / prod_k (w_k[j] + gamma + beta sigma_k[j]),  j < n - 1
+ * K_0 = 1, K_1..K_3 = coset generators.  wires / sigmas: 4 arrays of n Lagrange-base values each (concatenated). */
+void oracle_permutation_z(const uint64_t* wires, const uint64_t* sigmas, unsigned log2n, const uint64_t* beta_mont,
+                          const uint64_t* gamma_mont, const uint64_t* k_mont /* 3 x 4 limbs */, uint64_t* z)
+{
+    const size_t n = (size_t)1 << log2n;
+    fe beta, gamma, K[4];
+    memcpy(beta.d, beta_mont, 32); memcpy(gamma.d, gamma_mont, 32);
+    K[0] = fe_one(&FR);
+    for (int k = 0; k < 3; k++) memcpy(K[k + 1].d, k_mont + 4 * k, 32);
+    const fe root = fr_root_of_unity(log2n);
+    fe acc = fe_one(&FR), root_beta = beta; /* beta * w^j */
+    memcpy(z, acc.d, 32);
+    for (size_t j = 0; j + 1 < n; j++) {
+        fe num = fe_one(&FR), den = fe_one(&FR);
+        for (int k = 0; k < 4; k++) {
+            fe w, s; memcpy(w.d, wires + 4 * (k * n + j), 32); memcpy(s.d, sigmas + 4 * (k * n + j), 32);
+            fe wpg = fe_add(&FR, fe_canon(&FR, w), gamma);
+            num = fe_mul(&FR, num, fe_add(&FR, wpg, fe_mul(&FR, K[k], root_beta)));
+            den = fe_mul(&FR, den, fe_add(&FR, wpg, fe_mul(&FR, fe_canon(&FR, s), beta)));
+        }
+        acc = fe_mul(&FR, acc, fe_mul(&FR, num, fe_inv(&FR, den)));
+        fe c = fe_canon(&FR, acc);
+        memcpy(z + 4 * (j + 1), c.d, 32);
+        root_beta = fe_mul(&FR, root_beta, root);
+    }
+}

@@ -60,6 +60,7 @@ class Oracle:
         L.oracle_poly_binop.argtypes = [cint, vp, vp, vp, sz]; L.oracle_poly_binop.restype = None
         L.oracle_kate_opening.argtypes = [vp, vp, sz, vp, vp]; L.oracle_kate_opening.restype = None
         L.oracle_divide_by_pseudo_vanishing.argtypes = [vp, cu, cu, sz]; L.oracle_divide_by_pseudo_vanishing.restype = cint
+        L.oracle_permutation_z.argtypes = [vp, vp, cu, vp, vp, vp, vp]
 
     # ---- fields (which: 0 Fr, 1 Fq)
     def _bin(self, fn, which, a, b):
@@ -221,6 +222,17 @@ class Oracle:
         dest, f = np.empty_like(a), np.empty(4, dtype=np.uint64)
         self.lib.oracle_kate_opening(a.ctypes.data, dest.ctypes.data, a.shape[0], z.ctypes.data, f.ctypes.data)
         return dest, f
+
+    def permutation_z(self, wires, sigmas, beta, gamma, ks):
+        """wires, sigmas: (4, n, 4) Lagrange-base values; ks: (3, 4) coset generators.  Returns z (n, 4), canonical."""
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        s_ = np.ascontiguousarray(sigmas, dtype=np.uint64)
+        n = w.shape[1]
+        z = np.empty((n, 4), dtype=np.uint64)
+        b, g, k = (np.ascontiguousarray(v, dtype=np.uint64) for v in (beta, gamma, ks))
+        self.lib.oracle_permutation_z(w.ctypes.data, s_.ctypes.data, n.bit_length() - 1, b.ctypes.data, g.ctypes.data, k.ctypes.data,
+                                      z.ctypes.data)
+        return z
 
     def divide_by_pseudo_vanishing(self, evals, log2_src, cut=4):
         a = _arr(evals, 4).copy()

@@ -508,3 +508,36 @@ int refp_round4_end(void* h)
     }
 }
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3 probe: the inputs and the output of the reference's permutation grand product in a REAL proof.
+// Call after rounds 0..2 (and their queues).  Snapshots the Lagrange-base wires (key->wire_ffts[..][0..n)), the sigma
+// permutations in Lagrange base, beta / gamma; runs execute_third_round (which computes z, blinds three of its last rows
+// with fr::random_element() and iffts it, permutation_widget_impl.hpp:48-297); transforms the resulting z back to Lagrange
+// base with the reference's own fft.  Rows 0 .. n-4 of z_lagrange are deterministic functions of the snapshot.
+extern "C" int refp_round3_probe(void* h, uint64_t* wires /* 4 x n x 4 */, uint64_t* sigmas /* 4 x n x 4 */, uint64_t* challenges /* beta, gamma, k1..k3 */,
+                                 uint64_t* z_lagrange /* n x 4 */)
+{
+    try {
+        auto* s = (Session*)h;
+        auto& p = *s->prover;
+        auto* key = p.key.get();
+        const size_t n = key->n;
+        for (int k = 0; k < 4; k++) {
+            const std::string idx = std::to_string(k + 1);
+            std::memcpy(wires + (size_t)k * n * 4, (const void*)&key->wire_ffts.at("w_" + idx + "_fft")[0], n * 32);
+            std::memcpy(sigmas + (size_t)k * n * 4, (const void*)&key->permutation_selectors_lagrange_base.at("sigma_" + idx)[0], n * 32);
+        }
+        p.execute_third_round(); // applies Fiat-Shamir "beta" first, then the widgets' compute_round_commitments
+        fr beta = fr::serialize_from_buffer(p.transcript.get_challenge("beta").begin());
+        fr gamma = fr::serialize_from_buffer(p.transcript.get_challenge("beta", 1).begin());
+        fr vals[5] = { beta, gamma, fr::coset_generator(0), fr::coset_generator(1), fr::coset_generator(2) };
+        std::memcpy(challenges, vals, sizeof(vals));
+        polynomial zc(p.witness->wires.at("z"), n);
+        polynomial_arithmetic::fft(&zc[0], key->small_domain);
+        std::memcpy(z_lagrange, (const void*)&zc[0], n * 32);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}

@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI (libbbg.so); results are compared
 bit-exactly, on canonical values, with the oracle on the same seeded inputs, with the golden vectors recorded from the
 compiled reference, and -- at BASELINE.json's full sizes -- through size-independent algebraic properties."""
+import ctypes
 import json
 import os
 
@@ -461,6 +462,56 @@ def test_poly_linear_combination(pkg, oracle, bbg):
     assert np.array_equal(oracle.canon(0, dbase.cpu().numpy().view(np.uint64).reshape(-1, 4)), want3)
     with pytest.raises(pkg.BbgError):
         bbg.poly_linear_combination_device([dev[0].data_ptr()] * 33, pkg.synthetic_scalars(1, 33), None, out.data_ptr(), n)
+
+
+# ---------------------------------------------------------------------------------------------- permutation grand product
+def _gpu_grand_product(pkg, bbg, wires, sigmas, log2n, beta, gamma, ks):
+    import torch
+    dw = [torch.from_numpy(np.ascontiguousarray(wires[k]).view(np.int64).reshape(-1)).cuda() for k in range(4)]
+    ds = [torch.from_numpy(np.ascontiguousarray(sigmas[k]).view(np.int64).reshape(-1)).cuda() for k in range(4)]
+    z = torch.zeros((1 << log2n) * 4, dtype=torch.int64, device="cuda")
+    bbg.permutation_grand_product_device([t.data_ptr() for t in dw], [t.data_ptr() for t in ds], log2n, beta, gamma, ks, z.data_ptr())
+    bbg.sync()
+    return z.cpu().numpy().view(np.uint64).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("log2n", [0, 1, 3, 4, 5, 9, 12])
+def test_permutation_grand_product_vs_oracle(pkg, oracle, bbg, log2n):
+    """z[0] = 1, z[j+1] = prod_{i<=j} N_i / D_i (permutation_widget_impl.hpp:48-268) against the oracle's serial restatement."""
+    n = 1 << log2n
+    wires = np.stack([pkg.synthetic_scalars(800 + k, n) for k in range(4)])
+    sigmas = np.stack([pkg.synthetic_scalars(810 + k, n) for k in range(4)])
+    ch = pkg.synthetic_scalars(820, 5)
+    got = oracle.canon(0, _gpu_grand_product(pkg, bbg, wires, sigmas, log2n, ch[0], ch[1], ch[2:5]))
+    assert np.array_equal(got, oracle.permutation_z(wires, sigmas, ch[0], ch[1], ch[2:5]))
+
+
+def test_permutation_grand_product_in_a_real_proof(pkg, oracle, bbg):
+    """The same kernel on the inputs of a real proof of the reference prover (round 3): rows 0 .. n-4 of the reference's z
+    (ifft'ed by the prover, transformed back with its own fft) are reproduced bit for bit; the last three rows are the
+    reference's random blinding.  A valid permutation also closes: the product over all rows is 1."""
+    from oracle.oracle import RefProver, prover_available
+    if not prover_available():
+        pytest.skip("oracle/_ref/libbbprover.so absent on this machine")
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    P = RefProver(1 << 11, 14, oracle.srs_powers(x, (2 << 11) + 1), x)
+    n = P.n
+    for k in range(3):
+        P.lib.refp_execute_round(P.h, k)
+        P.lib.refp_process_queue_reference(P.h)
+    wires = np.zeros((4, n, 4), dtype=np.uint64)
+    sigmas = np.zeros((4, n, 4), dtype=np.uint64)
+    ch = np.zeros((5, 4), dtype=np.uint64)
+    zref = np.zeros((n, 4), dtype=np.uint64)
+    P.lib.refp_round3_probe.restype = ctypes.c_int
+    rc = P.lib.refp_round3_probe(ctypes.c_void_p(P.h), ctypes.c_void_p(wires.ctypes.data), ctypes.c_void_p(sigmas.ctypes.data),
+                                 ctypes.c_void_p(ch.ctypes.data), ctypes.c_void_p(zref.ctypes.data))
+    assert rc == 0
+    got = oracle.canon(0, _gpu_grand_product(pkg, bbg, wires, sigmas, n.bit_length() - 1, ch[0], ch[1], ch[2:5]))
+    want = oracle.canon(0, zref)
+    assert np.array_equal(got[: n - 3], want[: n - 3])
+    assert not np.array_equal(got[n - 3:], want[n - 3:])  # the reference blinds these rows with fresh randomness
+    P.free()
 
 
 # ---------------------------------------------------------------------------------------------- quotient widgets (8f-2)
