@@ -256,6 +256,22 @@ if "quotient" in stages:
             print(f"quotient widget {names[w]:18s} 4n=2^{lg}: {dt*1e3:.3f} ms  {reads[w]*32*m/dt/1e9:.0f} GB/s ({reads[w]} x 32 B per point)", flush=True)
         print(f"all five widgets 4n=2^{lg}: {tot*1e3:.3f} ms", flush=True)
         del polys, quot
+if "grandproduct" in stages:
+    import torch
+    for lg in (16, 20, 22):
+        n = 1 << lg
+        dw = [torch.from_numpy(inp.synthetic_scalars(800 + k, n).view(np.int64).reshape(-1)).cuda() for k in range(4)]
+        ds = [torch.from_numpy(inp.synthetic_scalars(810 + k, n).view(np.int64).reshape(-1)).cuda() for k in range(4)]
+        z = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+        ch = inp.synthetic_scalars(820, 5)
+        B.ntt_prepare(lg)
+        f = lambda: B.permutation_grand_product_device([t.data_ptr() for t in dw], [t.data_ptr() for t in ds], lg, ch[0], ch[1], ch[2:5], z.data_ptr())
+        f(); B.sync()
+        t0 = time.perf_counter()
+        for _ in range(5): f()
+        B.sync()
+        dt = (time.perf_counter() - t0) / 5
+        print(f"permutation grand product n=2^{lg}: {dt*1e3:.3f} ms  ({n/dt/1e6:.0f} M rows/s)", flush=True)
 if "msmexp" in stages:
     import torch
     n = 1 << 20
