@@ -633,6 +633,48 @@ int bbg_kate_opening_device(bbg_ctx* ctx, const void* d_src, void* d_dest, size_
     std::lock_guard<std::mutex> lk(ctx->mu);
     return poly_kate_opening(ctx, d_src, d_dest, n, z, f_out, ctx->stream);
 }
+int bbg_poly_evaluate(bbg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4])
+{
+    CHECK_CTX(ctx);
+    if ((!coeffs && n) || !z || !out) { set_error("bbg_poly_evaluate: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * 32 + 32);
+    if (rc) return rc;
+    if (n) BBG_HIP(hipMemcpyAsync(ctx->staging, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return poly_evaluate(ctx, ctx->staging, n, z, out, ctx->stream);
+}
+int bbg_kate_opening(bbg_ctx* ctx, const uint64_t* src, uint64_t* dest, size_t n, const uint64_t z[4], uint64_t f_out[4])
+{
+    CHECK_CTX(ctx);
+    if ((n && (!src || !dest)) || !z || !f_out) { set_error("bbg_kate_opening: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, 2 * n * 32 + 64);
+    if (rc) return rc;
+    char* d_src = (char*)ctx->staging;
+    char* d_dest = d_src + n * 32 + 32;
+    if (n) BBG_HIP(hipMemcpyAsync(d_src, src, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = poly_kate_opening(ctx, d_src, d_dest, n, z, f_out, ctx->stream);
+    if (rc) return rc;
+    if (n) BBG_HIP(hipMemcpyAsync(dest, d_dest, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+int bbg_divide_by_pseudo_vanishing(bbg_ctx* ctx, uint64_t* evals, unsigned log2_src, unsigned log2_target, size_t num_roots_cut)
+{
+    CHECK_CTX(ctx);
+    if (!evals) { set_error("bbg_divide_by_pseudo_vanishing: null argument"); return BBG_E_INVALID; }
+    if (log2_target > 28) { set_error("bbg_divide_by_pseudo_vanishing: log2_target > 28"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t bytes = ((size_t)1 << log2_target) * 32;
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, bytes);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(ctx->staging, evals, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = poly_divide_pseudo_vanishing(ctx, ctx->staging, log2_src, log2_target, num_roots_cut, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(evals, ctx->staging, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
 int bbg_divide_by_pseudo_vanishing_device(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t num_roots_cut)
 {
     CHECK_CTX(ctx);

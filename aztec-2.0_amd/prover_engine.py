@@ -48,7 +48,9 @@ class FusedFftEngine(WorkQueueEngine):
 
 
 class Round4Engine(FusedFftEngine):
-    """+ the quotient of execute_fourth_round on the device."""
+    """+ the quotient of execute_fourth_round on the device.  With queue_via_reference = True only round 4 is taken over and
+    the work queue is left to the prover's own process_queue (for a prover that is already linked against the shim)."""
+    queue_via_reference = False
 
     def __init__(self, bbg, srs):
         super().__init__(bbg, srs)
@@ -65,8 +67,10 @@ class Round4Engine(FusedFftEngine):
         import torch
         b = self.bbg
         m = 4 << log2n
-        key = (tuple(poly_ptrs[5:]), log2n)
-        if key not in self._static:  # sigma_1..4, q_*, L_1 on the coset: fixed per proving key
+        # sigma_1..4, q_*, L_1 on the coset are fixed per proving key (= per circuit): uploaded once and recognised by a
+        # fingerprint of their leading 256 bytes, the way an SRS is registered once
+        key = (log2n,) + tuple(ctypes.string_at(p, 256) for p in poly_ptrs[5:])
+        if key not in self._static:
             self._static = {key: [self._upload(p, m) for p in poly_ptrs[5:]]}
         wires = [self._upload(p, m) for p in poly_ptrs[:5]]  # w_1..4, z: new for every proof
         dev = wires + self._static[key]

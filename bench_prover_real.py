@@ -85,7 +85,7 @@ def main():
     gpu4 = {"total_ms": round(t4 * 1e3, 1), "rounds_ms": round(P4.t_rounds * 1e3, 1), "queue_ms": round(P4.t_queue * 1e3, 1),
             "round_ms": [round(t * 1e3, 1) for t in P4.t_round], "verified": P4.verify() == 1}
     P4.free()
-    linked = None
+    linked = both = None
     from oracle.oracle import PROVER_GPU_SO
     if os.path.exists(PROVER_GPU_SO):  # the unmodified prover with the shim linked in front (no callbacks, inline FFTs included)
         srs.free()
@@ -96,13 +96,26 @@ def main():
         t0 = time.perf_counter()
         PL.prove()
         t_l = time.perf_counter() - t0
+        # shim-linked prover (queue + inline helpers through --wrap) AND round 4 taken over by the engine
+        eng5 = pkg.prover_engine.Round4Engine(bbg, None)
+        eng5.queue_via_reference = True
+        PB = RefProver(gates, 11, pts, x, gpu_linked=True)
+        PB.prove(eng5, check=False)  # warm-up: uploads the per-key arrays
+        PB.free()
+        PB = RefProver(gates, 11, pts, x, gpu_linked=True)
+        t0 = time.perf_counter()
+        PB.prove(eng5, check=False)
+        t_b = time.perf_counter() - t0
+        both = {"total_ms": round(t_b * 1e3, 1), "rounds_ms": round(PB.t_rounds * 1e3, 1), "queue_ms": round(PB.t_queue * 1e3, 1),
+                "round_ms": [round(t * 1e3, 1) for t in PB.t_round], "verified": PB.verify() == 1}
+        PB.free()
         linked = {"total_ms": round(t_l * 1e3, 1), "rounds_ms": round(PL.t_rounds * 1e3, 1), "queue_ms": round(PL.t_queue * 1e3, 1),
                   "round_ms": [round(t * 1e3, 1) for t in PL.t_round], "verified": PL.verify() == 1}
         PL.free()
         srs = bbg.srs_register(P.monomials())
     out = {"workload": f"reference TurboProver, arithmetic circuit, n = 2^{args.log2n} gates after padding",
            "host_threads": P.threads, "srs_setup_s": round(t_srs, 2),
-           "cpu_engine": cpu, "gpu_engine": gpu, "gpu_engine_plus_round4": gpu4, "gpu_shim_linked": linked, "proof_bytes": len(proof_gpu),
+           "cpu_engine": cpu, "gpu_engine": gpu, "gpu_engine_plus_round4": gpu4, "gpu_shim_linked": linked, "gpu_shim_linked_plus_round4": both, "proof_bytes": len(proof_gpu),
            "verified": {"cpu": ok_cpu == 1, "gpu": ok_gpu == 1},
            "queue_speedup": round(cpu["queue_ms"] / max(gpu["queue_ms"], 1e-9), 1),
            "end_to_end_speedup": round(cpu["total_ms"] / max(gpu["total_ms"], 1e-9), 2)}

@@ -155,6 +155,13 @@ int bbg_kate_opening_device(bbg_ctx* ctx, const void* d_src, void* d_dest, size_
  * src domain 2^log2_src, num_roots_cut roots cut out of the vanishing polynomial (the reference default is 4). */
 int bbg_divide_by_pseudo_vanishing_device(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t num_roots_cut);
 
+/* Host-buffer forms of the three helpers above (what the C++ shim binds polynomial_arithmetic::evaluate,
+ * compute_kate_opening_coefficients and divide_by_pseudo_vanishing_polynomial to): upload, compute, download; synchronous.
+ * bbg_kate_opening: dest may alias src, as the prover calls it (kate_commitment_scheme.cpp:231-235). */
+int bbg_poly_evaluate(bbg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
+int bbg_kate_opening(bbg_ctx* ctx, const uint64_t* src, uint64_t* dest, size_t n, const uint64_t z[4], uint64_t f_out[4]);
+int bbg_divide_by_pseudo_vanishing(bbg_ctx* ctx, uint64_t* evals, unsigned log2_src, unsigned log2_target, size_t num_roots_cut);
+
 /* ---- device memory helpers for hosts that do not link HIP (bbmalloc/bbfree analogue, c_bind.cpp:11-15) ---- */
 int bbg_dev_alloc(bbg_ctx* ctx, size_t bytes, void** d_ptr);
 int bbg_dev_free(bbg_ctx* ctx, void* d_ptr);

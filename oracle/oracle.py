@@ -523,7 +523,9 @@ class RefProver:
     def prove(self, engine=None, check=True):
         """Runs all rounds (prover.cpp:420-436 construct_proof); returns the proof bytes."""
         cbs = None
-        if engine is not None and getattr(engine, "raw", False):
+        if engine is not None and getattr(engine, "queue_via_reference", False):
+            pass  # the prover's own process_queue handles the items (shim-linked build); the engine only takes round 4
+        elif engine is not None and getattr(engine, "raw", False):
             # raw engine: gets the prover's own buffers (addresses) and works in place -- what a C++ binding does
             item = None
             if hasattr(engine, "fft_item_raw"):  # the whole FFT work item (n coefficients -> 4n + 4 values) in one call

@@ -161,6 +161,14 @@ void coset_fft_with_generator_shift(fr* coeffs, const evaluation_domain& domain,
     SHIM_NAME("_ZN12barretenberg21polynomial_arithmetic30coset_fft_with_generator_shiftEPNS_5fieldINS_13Bn254FrParamsEEERKNS_17evaluation_domainERKS3_");
 void ifft_with_constant(fr* coeffs, const evaluation_domain& domain, const fr& value)
     SHIM_NAME("_ZN12barretenberg21polynomial_arithmetic18ifft_with_constantEPNS_5fieldINS_13Bn254FrParamsEEERKNS_17evaluation_domainERKS3_");
+// the O(n) helpers between the FFTs and the MSMs (polynomial_arithmetic.hpp:16,56,64)
+fr evaluate(const fr* coeffs, const fr& z, const size_t n)
+    SHIM_NAME("_ZN12barretenberg21polynomial_arithmetic8evaluateEPKNS_5fieldINS_13Bn254FrParamsEEERS4_m");
+fr compute_kate_opening_coefficients(const fr* src, fr* dest, const fr& z, const size_t n)
+    SHIM_NAME("_ZN12barretenberg21polynomial_arithmetic33compute_kate_opening_coefficientsEPKNS_5fieldINS_13Bn254FrParamsEEEPS3_RS4_m");
+void divide_by_pseudo_vanishing_polynomial(fr* coeffs, const evaluation_domain& src_domain, const evaluation_domain& target_domain,
+                                           const size_t num_roots_cut_out_of_vanishing_polynomial)
+    SHIM_NAME("_ZN12barretenberg21polynomial_arithmetic37divide_by_pseudo_vanishing_polynomialEPNS_5fieldINS_13Bn254FrParamsEEERKNS_17evaluation_domainES7_m");
 
 g1::element pippenger(fr* scalars, g1::affine_element* points, const size_t num_points, pippenger_runtime_state&, bool)
 {
@@ -190,4 +198,30 @@ void coset_fft_with_generator_shift(fr* coeffs, const evaluation_domain& domain,
     ntt(coeffs, domain, BBG_COSET_FFT_WITH_GENERATOR_SHIFT, &constant);
 }
 void ifft_with_constant(fr* coeffs, const evaluation_domain& domain, const fr& value) { ntt(coeffs, domain, BBG_IFFT_WITH_CONSTANT, &value); }
+fr evaluate(const fr* coeffs, const fr& z, const size_t n)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    fr out;
+    if (bbg_poly_evaluate(context(), reinterpret_cast<const uint64_t*>(coeffs), n, reinterpret_cast<const uint64_t*>(&z),
+                          reinterpret_cast<uint64_t*>(&out)) != BBG_OK)
+        fail("bbg_poly_evaluate");
+    return out;
+}
+fr compute_kate_opening_coefficients(const fr* src, fr* dest, const fr& z, const size_t n)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    fr f;
+    if (bbg_kate_opening(context(), reinterpret_cast<const uint64_t*>(src), reinterpret_cast<uint64_t*>(dest), n,
+                         reinterpret_cast<const uint64_t*>(&z), reinterpret_cast<uint64_t*>(&f)) != BBG_OK)
+        fail("bbg_kate_opening");
+    return f;
+}
+void divide_by_pseudo_vanishing_polynomial(fr* coeffs, const evaluation_domain& src_domain, const evaluation_domain& target_domain,
+                                           const size_t num_roots_cut_out_of_vanishing_polynomial)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    if (bbg_divide_by_pseudo_vanishing(context(), reinterpret_cast<uint64_t*>(coeffs), (unsigned)src_domain.log2_size,
+                                       (unsigned)target_domain.log2_size, num_roots_cut_out_of_vanishing_polynomial) != BBG_OK)
+        fail("bbg_divide_by_pseudo_vanishing");
+}
 } // namespace bbg_shim

@@ -42,6 +42,11 @@ void coset_fft_with_generator_shift(fr*, const evaluation_domain&, const fr&)
     REAL("_ZN12barretenberg21polynomial_arithmetic30coset_fft_with_generator_shiftEPNS_5fieldINS_13Bn254FrParamsEEERKNS_17evaluation_domainERKS3_");
 void ifft_with_constant(fr*, const evaluation_domain&, const fr&)
     REAL("_ZN12barretenberg21polynomial_arithmetic18ifft_with_constantEPNS_5fieldINS_13Bn254FrParamsEEERKNS_17evaluation_domainERKS3_");
+fr evaluate(const fr*, const fr&, const size_t) REAL("_ZN12barretenberg21polynomial_arithmetic8evaluateEPKNS_5fieldINS_13Bn254FrParamsEEERS4_m");
+fr compute_kate_opening_coefficients(const fr*, fr*, const fr&, const size_t)
+    REAL("_ZN12barretenberg21polynomial_arithmetic33compute_kate_opening_coefficientsEPKNS_5fieldINS_13Bn254FrParamsEEEPS3_RS4_m");
+void divide_by_pseudo_vanishing_polynomial(fr*, const evaluation_domain&, const evaluation_domain&, const size_t)
+    REAL("_ZN12barretenberg21polynomial_arithmetic37divide_by_pseudo_vanishing_polynomialEPNS_5fieldINS_13Bn254FrParamsEEERKNS_17evaluation_domainES7_m");
 } // namespace real
 
 static uint64_t sm_state = 0xBB254;
@@ -170,6 +175,24 @@ int main(int argc, char** argv)
         polynomial_arithmetic::coset_fft(a.data(), small, large, 4);
         real::coset_fft4(b.data(), small, large, 4);
         expect(same(a, b), "coset_fft(coeffs, small, large, 4)");
+    }
+    { // the O(n) helpers
+        const fr z = rand_fr();
+        expect(polynomial_arithmetic::evaluate(base.data(), z, n) == real::evaluate(base.data(), z, n), "evaluate");
+        expect(polynomial_arithmetic::evaluate(base.data(), z, n - 3) == real::evaluate(base.data(), z, n - 3), "evaluate (ragged n)");
+        std::vector<fr> a = base, b = base; // in place, as KateCommitmentScheme::batch_open calls it
+        const fr fa = polynomial_arithmetic::compute_kate_opening_coefficients(a.data(), a.data(), z, n);
+        const fr fb = real::compute_kate_opening_coefficients(b.data(), b.data(), z, n);
+        expect(fa == fb && same(a, b), "compute_kate_opening_coefficients (dest == src)");
+        const size_t m = n / 4;
+        evaluation_domain small(m, m), large(n, m);
+        small.compute_lookup_table();
+        large.compute_lookup_table();
+        a = base;
+        b = base;
+        polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial(a.data(), small, large, 4);
+        real::divide_by_pseudo_vanishing_polynomial(b.data(), small, large, 4);
+        expect(same(a, b), "divide_by_pseudo_vanishing_polynomial(4n coset, 4 roots cut)");
     }
     aligned_free(table);
     std::printf(failures ? "shim_check FAILED (%d)\n" : "shim_check PASS\n", failures);
