@@ -623,7 +623,7 @@ __device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
 // with the next MSM's accumulation) cost 40 lane-additions per bucket instead of 17 -- 5 % of the pipelined step time.
 constexpr int MSM_COMBINE_LANES = 4;
 template <int C> __global__ void __launch_bounds__(256, 1)
-k_combine8(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+k_combine_lanes(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
 {
     constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
@@ -1003,7 +1003,7 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
     {
         ProfScope ps(ctx, "msm_reduce", rst);
         if (L.lanes > (size_t)2 * K::buckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
-            hipLaunchKernelGGL(k_combine8<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
+            hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
                                L.seg, head, tail, buckets, long_count, long_list);
         else
             hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,

@@ -13,7 +13,7 @@ BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace -d /tmp/prof_kt -o bench -- $BENCH > /tmp/bench_kt.log 2>&1
 {
   echo "# rocprofv3 --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, round 1, build $TAG)"
-  echo "# durations include overlap: the MSM reduce kernels (k_combine8 .. k_final_sum) run on an auxiliary stream beside the next step"
+  echo "# durations include overlap: the MSM reduce kernels (k_combine_lanes .. k_final_sum) run on an auxiliary stream beside the next step"
   echo "# bench line of this run:"
   grep "^{\"metric\"" /tmp/bench_kt.log | tail -1
   echo

@@ -464,6 +464,26 @@ def test_poly_linear_combination(pkg, oracle, bbg):
         bbg.poly_linear_combination_device([dev[0].data_ptr()] * 33, pkg.synthetic_scalars(1, 33), None, out.data_ptr(), n)
 
 
+def test_round_kernel_error_paths(pkg, bbg):
+    import torch
+    buf = torch.zeros(64 * 4, dtype=torch.int64, device="cuda")
+    ch9 = pkg.synthetic_scalars(1, 9)
+    ptrs = [buf.data_ptr()] * 21
+    with pytest.raises(pkg.BbgError):
+        bbg.quotient_widget_device(5, ptrs, 6, ch9, buf.data_ptr())      # unknown widget
+    with pytest.raises(pkg.BbgError):
+        bbg.quotient_widget_device(0, ptrs, 2, ch9, buf.data_ptr())      # domain too small for the shifted rows
+    missing = list(ptrs)
+    missing[20] = 0                                                       # the permutation widget reads L_1
+    with pytest.raises(pkg.BbgError):
+        bbg.quotient_widget_device(0, missing, 6, ch9, buf.data_ptr())
+    bbg.quotient_widget_device(3, missing, 6, ch9, buf.data_ptr())        # the range widget does not
+    with pytest.raises(pkg.BbgError):
+        bbg.permutation_grand_product_device([buf.data_ptr()] * 4, [buf.data_ptr()] * 3 + [0], 6, ch9[0], ch9[1], ch9[2:5],
+                                             buf.data_ptr())
+    bbg.sync()
+
+
 # ---------------------------------------------------------------------------------------------- permutation grand product
 def _gpu_grand_product(pkg, bbg, wires, sigmas, log2n, beta, gamma, ks):
     import torch
