@@ -51,7 +51,7 @@ def pmc_traffic(kernel):
         tot = 0.0
         for line in open(path):
             f = line.split()
-            if len(f) >= 4 and f[0].endswith(kernel) and f[-3] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if len(f) >= 4 and any(kernel in tok for tok in f[:-3]) and f[-3] in ("FETCH_SIZE", "WRITE_SIZE"):
                 tot += float(f[-1]) * 1024.0
         return round(tot) if tot else None
     except OSError:
