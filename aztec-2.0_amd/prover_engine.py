@@ -8,7 +8,7 @@ maintainer writes in C++.  Works on raw host addresses of th
                                                     widgets, divide_by_pseudo_vanishing_polynomial and coset_ifft on the device;
                                                     selector / sigma / L_1 arrays are uploaded once per proving key
 
-Used by tests/test_gpu_parity.py and bench_prover_real.py with the reference's real prover on the other side
+Used by tests/test_gpu_parity.py and tests/tools/bench_prover_real.py with the reference's real prover on the other side
 (oracle/ref_prover_driver.cpp).  Nothing here imports the oracle.
 """
 import ctypes

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end check of the drop-in seam with the REAL reference prover (not a bench.py line; supplementary evidence).
+"""End-to-end check of the drop-in seam with the REAL reference prover (test tooling: it drives the checker under oracle/, so it
+lives under tests/; not a bench.py line, supplementary evidence).
 
 Runs the reference's TurboPLONK prover (oracle/ref_prover_driver.cpp, prebuilt into oracle/_ref/libbbprover.so from the
 reference's own sources) over the same circuit twice:
@@ -11,7 +12,7 @@ reference's own sources) over the same circuit twice:
 and reports wall-clock split into "rounds" (the prover's own widget / transcript / polynomial logic, always on the CPU) and
 "queue" (the MSM + FFT work items).  Both proofs are verified with the reference's TurboVerifier.
 
-    python bench_prover_real.py [--log2n 16] [--check]
+    python tests/tools/bench_prover_real.py [--log2n 16] [--check]
 """
 import argparse
 import json
@@ -21,7 +22,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 

@@ -1,12 +1,12 @@
 """Developer probe (not a test, not the bench): shakes the HIP path against the oracle on a GPU box and prints
-timings.  Usage: python scripts/gpu_probe.py [stage ...]  with stages: field ntt msm time"""
+timings.  Usage: python tests/tools/gpu_probe.py [stage ...]  with stages: field ntt msm time"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
