@@ -4,6 +4,8 @@ maintainer writes in C++.  Works on raw host addresses of th
     msm_raw(scalars, count, out)                    work_queue SCALAR_MULTIPLICATION (work_queue.hpp:218-245) -> bbg_msm
     fft_item_raw(wire, log2n, wire_fft, log2_4n)    work_queue FFT (:252-264)                                 -> bbg_coset_fft_extend
     coset_fft_raw / ifft_raw                                                                                  -> bbg_ntt
+    round3_raw(wires, sigmas, challenges, blind, log2n, z)   the permutation polynomial of execute_third_round
+                                                    (permutation_widget_impl.hpp:48-297): grand product, blinded rows, ifft
     round4_raw(poly_ptrs, challenges, log2n, q)     the quotient of execute_fourth_round (prover.cpp:304-343): the five TurboPLONK
                                                     widgets, divide_by_pseudo_vanishing_polynomial and coset_ifft on the device;
                                                     selector / sigma / L_1 arrays are uploaded once per proving key
@@ -84,3 +86,29 @@ class Round4Engine(FusedFftEngine):
         b.divide_by_pseudo_vanishing_device(quot.data_ptr(), log2n, log2n + 2, 4)
         b.ntt_device(quot.data_ptr(), log2n + 2, binding.COSET_IFFT)
         b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(quotient_ptr), ctypes.c_void_p(quot.data_ptr()), m * 32))
+
+
+class Round34Engine(Round4Engine):
+    """+ the permutation polynomial z of execute_third_round on the device (sigma permutations resident per proving key)."""
+
+    def __init__(self, bbg, srs):
+        super().__init__(bbg, srs)
+        self._sigma = {}
+
+    def round3_raw(self, wire_ptrs, sigma_ptrs, challenges, blind, log2n, z_ptr):
+        import torch
+        b = self.bbg
+        n = 1 << log2n
+        key = (log2n,) + tuple(ctypes.string_at(p, 256) for p in sigma_ptrs)
+        if key not in self._sigma:
+            self._sigma = {key: [self._upload(p, n) for p in sigma_ptrs]}
+        wires = [self._upload(p, n) for p in wire_ptrs]
+        z = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        b.permutation_grand_product_device([t.data_ptr() for t in wires], [t.data_ptr() for t in self._sigma[key]], log2n, ch[0], ch[1],
+                                           ch[2:5], z.data_ptr())
+        # rows n-3 .. n-1 carry the prover's zero-knowledge blinding (4 roots are cut out of the vanishing polynomial)
+        bl = np.ascontiguousarray(blind, dtype=np.uint64)
+        b._ck(b.lib.bbg_dev_upload(b.ctx, ctypes.c_void_p(z.data_ptr() + (n - 3) * 32), bl.ctypes.data, 96))
+        b.ntt_device(z.data_ptr(), log2n, binding.IFFT)
+        b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(z_ptr), ctypes.c_void_p(z.data_ptr()), n * 32))

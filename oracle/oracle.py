@@ -568,7 +568,9 @@ class RefProver:
         self.round4_mismatch = None
         for k in range(7):
             t0 = time.perf_counter()
-            if k == 4 and engine is not None and hasattr(engine, "round4_raw"):
+            if k == 3 and engine is not None and hasattr(engine, "round3_raw"):
+                self._round3_with(engine)
+            elif k == 4 and engine is not None and hasattr(engine, "round4_raw"):
                 self._round4_with(engine, check)
             else:
                 self.lib.refp_execute_round(self.h, k)
@@ -594,6 +596,23 @@ class RefProver:
         buf = (ctypes.c_uint8 * size)()
         self.lib.refp_export_proof(self.h, buf, size)
         return bytes(buf)
+
+    def _round3_with(self, engine):
+        """execute_third_round with the permutation polynomial z (grand product, blinding, ifft) computed by the engine."""
+        L = self.lib
+        L.refp_round3_begin.argtypes = [vp, vp, vp, vp, vp, vp]; L.refp_round3_begin.restype = cint
+        L.refp_round3_end.argtypes = [vp]; L.refp_round3_end.restype = cint
+        wires = (ctypes.c_void_p * 4)()
+        sigmas = (ctypes.c_void_p * 4)()
+        ch = np.zeros((5, 4), dtype=np.uint64)
+        blind = np.zeros((3, 4), dtype=np.uint64)
+        z = ctypes.c_void_p()
+        log2n = L.refp_round3_begin(self.h, wires, sigmas, ch.ctypes.data, blind.ctypes.data, ctypes.byref(z))
+        if log2n < 0:
+            raise RuntimeError("refp_round3_begin failed")
+        engine.round3_raw([int(p) for p in wires], [int(p) for p in sigmas], ch, blind, log2n, z.value)
+        if L.refp_round3_end(self.h) != 0:
+            raise RuntimeError("refp_round3_end failed")
 
     def _round4_with(self, engine, check):
         """execute_fourth_round with the quotient (widgets + divide_by_pseudo_vanishing + coset_ifft) computed by the engine."""

@@ -541,3 +541,51 @@ extern "C" int refp_round3_probe(void* h, uint64_t* wires /* 4 x n x 4 */, uint6
         return -1;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3 through the prover's public members (prover.cpp:239-268 + permutation_widget_impl.hpp:48-312): flush, Fiat-Shamir
+// "beta", [z = grand product, three blinded rows, ifft -- delegated], queue the Z commitment and the z / w_i coset FFTs.
+extern "C" {
+// wire_ptrs / sigma_ptrs: host addresses of the 4 Lagrange-base wire arrays (key->wire_ffts[..][0..n)) and sigma permutations;
+// challenges[5][4] = beta, gamma, k1, k2, k3; blind[3][4] = fresh fr::random_element() values for rows n-3 .. n-1;
+// *z = &witness->wires["z"][0]: n entries to fill with the COEFFICIENTS of the blinded z.  Returns log2(n) or -1.
+int refp_round3_begin(void* h, const uint64_t** wire_ptrs, const uint64_t** sigma_ptrs, uint64_t* challenges, uint64_t* blind, uint64_t** z)
+{
+    try {
+        auto* s = (Session*)h;
+        auto& p = *s->prover;
+        auto* key = p.key.get();
+        p.queue.flush_queue();
+        p.transcript.apply_fiat_shamir("beta");
+        for (int k = 0; k < 4; k++) {
+            const std::string idx = std::to_string(k + 1);
+            wire_ptrs[k] = (const uint64_t*)&key->wire_ffts.at("w_" + idx + "_fft")[0];
+            sigma_ptrs[k] = (const uint64_t*)&key->permutation_selectors_lagrange_base.at("sigma_" + idx)[0];
+        }
+        fr beta = fr::serialize_from_buffer(p.transcript.get_challenge("beta").begin());
+        fr gamma = fr::serialize_from_buffer(p.transcript.get_challenge("beta", 1).begin());
+        fr vals[5] = { beta, gamma, fr::coset_generator(0), fr::coset_generator(1), fr::coset_generator(2) };
+        std::memcpy(challenges, vals, sizeof(vals));
+        fr r[3] = { fr::random_element(), fr::random_element(), fr::random_element() };
+        std::memcpy(blind, r, sizeof(r));
+        *z = (uint64_t*)&p.witness->wires.at("z")[0];
+        return (int)key->small_domain.log2_size;
+    } catch (...) {
+        return -1;
+    }
+}
+int refp_round3_end(void* h)
+{
+    try {
+        auto& p = *((Session*)h)->prover;
+        polynomial& z = p.witness->wires.at("z");
+        p.queue.add_to_queue({ waffle::work_queue::WorkType::SCALAR_MULTIPLICATION, z.get_coefficients(), "Z", fr(0), 0 });
+        p.queue.add_to_queue({ waffle::work_queue::WorkType::FFT, nullptr, "z", fr(0), 0 });
+        for (size_t i = 0; i < 4; ++i)
+            p.queue.add_to_queue({ waffle::work_queue::WorkType::FFT, nullptr, "w_" + std::to_string(i + 1), fr(0), 0 });
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+} // extern "C"
