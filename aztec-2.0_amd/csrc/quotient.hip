@@ -169,50 +169,73 @@ __global__ void __launch_bounds__(256) k_quotient_turbo_arith(QuotientArgs a)
     fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(fe_add(gate, h), s.ap[0])));
 }
 
-// ---- fixed-base scalar multiplication ladder over Grumpkin (y^2 = x^3 - 17): see the identities below; ap[k] = alpha_base alpha^k
-__global__ void __launch_bounds__(256) k_quotient_turbo_fixed_base(QuotientArgs a)
+// ---- fixed-base scalar multiplication ladder over Grumpkin (y^2 = x^3 - 17); ap[k] = alpha_base alpha^k.  Two kernels -- the
+// selector-weighted terms and the gate identities -- because one kernel holding 8 wire values, 8 selectors and 7 alpha
+// powers needs 250 VGPRs (2 waves per SIMD, 5.0 ms at 4n = 2^22); split, each half re-reads the wires and stays near 128.
+//   delta = w4' - 4 w4 is the next quad, in {-3, -1, 1, 3}
+__global__ void __launch_bounds__(256) k_quotient_turbo_fixed_base_linear(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const uint32_t ish = (i + 4) & a.mask;
+    const Fr qe = QLOAD(QP_QECC, i);
+    const Fr w4 = QLOAD(QP_W4, i);
+    const Fr delta = fe_sub(QLOAD(QP_W4, ish), x4(w4));
+    const Fr w3n = QLOAD(QP_W3, ish);
+    Fr lin = fe_mul(fe_mul(fe_sqr(delta), s.ap[1]), QLOAD(QP_Q1, i));                       // q_1: x-coordinate lookup, delta^2 term
+    lin = fe_add(lin, fe_mul(s.ap[1], QLOAD(QP_Q2, i)));                                     // q_2: constant term
+    {
+        const Fr w1 = QLOAD(QP_W1, i);
+        Fr t3 = fe_mul(fe_mul(fe_mul(fe_sub(QLOAD(QP_W1, ish), w1), delta), w3n), s.ap[3]);
+        const Fr u = fe_mul(fe_mul(fe_mul(delta, w3n), QLOAD(QP_W2, i)), s.ap[2]);
+        t3 = fe_add(t3, fe_add(u, u));
+        lin = fe_add(lin, fe_mul(t3, QLOAD(QP_Q3, i)));                                      // q_3: y-coordinate lookup
+    }
+    {
+        const Fr w3 = QLOAD(QP_W3, i), qc = QLOAD(QP_QC, i);                                 // q_4, q_5, q_m: initialisation row
+        Fr init = fe_mul(fe_mul(w3, s.ap[5]), QLOAD(QP_Q4, i));
+        init = fe_add(init, fe_mul(fe_mul(fe_sub(s.one, w4), s.ap[5]), QLOAD(QP_Q5, i)));
+        init = fe_add(init, fe_mul(fe_mul(w3, s.ap[6]), QLOAD(QP_QM, i)));
+        lin = fe_add(lin, fe_mul(init, qc));
+    }
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(lin, qe)));
+}
+__global__ void __launch_bounds__(256) k_quotient_turbo_fixed_base_gate(QuotientArgs a)
 {
     const QuotientSetup& s = *a.s;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > a.mask) return;
     const uint32_t ish = (i + 4) & a.mask;
     const Fr w1 = QLOAD(QP_W1, i), w2 = QLOAD(QP_W2, i), w3 = QLOAD(QP_W3, i), w4 = QLOAD(QP_W4, i);
-    const Fr w1n = QLOAD(QP_W1, ish), w2n = QLOAD(QP_W2, ish), w3n = QLOAD(QP_W3, ish), w4n = QLOAD(QP_W4, ish);
+    const Fr w1n = QLOAD(QP_W1, ish), w3n = QLOAD(QP_W3, ish);
     const Fr qc = QLOAD(QP_QC, i), qe = QLOAD(QP_QECC, i);
-    const Fr delta = fe_sub(w4n, x4(w4)); // the next quad, in {-3, -1, 1, 3}
-    // selector-weighted ("linear") terms
-    Fr lin = fe_mul(fe_mul(fe_mul(fe_sqr(delta), qe), s.ap[1]), QLOAD(QP_Q1, i));       // q_1: x-coordinate lookup, delta^2 term
-    lin = fe_add(lin, fe_mul(fe_mul(s.ap[1], qe), QLOAD(QP_Q2, i)));                       // q_2: constant term
-    Fr t3 = fe_mul(fe_mul(fe_mul(fe_sub(w1n, w1), delta), w3n), s.ap[3]);
-    Fr u = fe_mul(fe_mul(fe_mul(delta, w3n), w2), s.ap[2]);
-    t3 = fe_mul(fe_add(t3, fe_add(u, u)), qe);
-    lin = fe_add(lin, fe_mul(t3, QLOAD(QP_Q3, i)));                                        // q_3: y-coordinate lookup
-    const Fr qeqc = fe_mul(qe, qc);
-    lin = fe_add(lin, fe_mul(fe_mul(fe_mul(w3, qeqc), s.ap[5]), QLOAD(QP_Q4, i)));          // q_4, q_5, q_m: initialisation row
-    lin = fe_add(lin, fe_mul(fe_mul(fe_mul(fe_sub(s.one, w4), qeqc), s.ap[5]), QLOAD(QP_Q5, i)));
-    lin = fe_add(lin, fe_mul(fe_mul(fe_mul(w3, qeqc), s.ap[6]), QLOAD(QP_QM, i)));
-    // gate identities
+    const Fr delta = fe_sub(QLOAD(QP_W4, ish), x4(w4));
     Fr acc = fe_mul(fe_mul(fe_add(delta, s.one), fe_add(delta, s.c3)), fe_mul(fe_sub(delta, s.one), fe_sub(delta, s.c3)));
-    acc = fe_mul(acc, s.ap[0]);                                                            // delta in {-3,-1,1,3}
-    const Fr x_alpha = fe_neg(fe_mul(w3n, s.ap[1]));
+    Fr gate = fe_sub(fe_mul(acc, s.ap[0]), fe_mul(w3n, s.ap[1]));                            // accumulator + x_alpha identities
     const Fr dx = fe_sub(w3n, w1);
-    Fr xacc = fe_mul(fe_add(fe_add(w1n, w1), w3n), fe_sqr(dx));                            // (x3 + x1 + x_alpha)(x_alpha - x1)^2
-    Fr rhs = fe_sub(fe_add(fe_mul(fe_sqr(w3n), w3n), fe_sqr(w2)), s.c17);                  // x_alpha^3 + y1^2 - 17
-    Fr two_dy = fe_mul(fe_mul(delta, w2), qe);
-    two_dy = fe_add(two_dy, two_dy);
-    xacc = fe_mul(fe_add(fe_sub(xacc, rhs), two_dy), s.ap[2]);
-    Fr yacc = fe_mul(fe_add(w2n, w2), dx);
-    yacc = fe_add(yacc, fe_mul(fe_sub(w1, w1n), fe_sub(w2, fe_mul(qe, delta))));
-    yacc = fe_mul(yacc, s.ap[3]);
-    const Fr w4m1 = fe_sub(w4, s.one);
-    const Fr acc_init = fe_mul(fe_mul(w4m1, fe_sub(w4m1, w3)), s.ap[4]);
-    const Fr x_init = fe_neg(fe_mul(fe_mul(w1, w3), s.ap[5]));
-    const Fr y_init = fe_mul(fe_sub(fe_mul(fe_sub(s.one, w4), qc), fe_mul(w2, w3)), s.ap[6]);
-    Fr gate = fe_mul(fe_add(fe_add(acc_init, x_init), y_init), qc);
-    gate = fe_add(fe_add(fe_add(fe_add(gate, acc), x_alpha), xacc), yacc);
-    gate = fe_mul(gate, qe);
+    {
+        Fr xacc = fe_mul(fe_add(fe_add(w1n, w1), w3n), fe_sqr(dx));                          // (x3 + x1 + x_alpha)(x_alpha - x1)^2
+        const Fr rhs = fe_sub(fe_add(fe_mul(fe_sqr(w3n), w3n), fe_sqr(w2)), s.c17);          // x_alpha^3 + y1^2 - 17
+        Fr two_dy = fe_mul(fe_mul(delta, w2), qe);
+        two_dy = fe_add(two_dy, two_dy);
+        gate = fe_add(gate, fe_mul(fe_add(fe_sub(xacc, rhs), two_dy), s.ap[2]));
+    }
+    {
+        Fr yacc = fe_mul(fe_add(QLOAD(QP_W2, ish), w2), dx);
+        yacc = fe_add(yacc, fe_mul(fe_sub(w1, w1n), fe_sub(w2, fe_mul(qe, delta))));
+        gate = fe_add(gate, fe_mul(yacc, s.ap[3]));
+    }
+    {
+        const Fr w4m1 = fe_sub(w4, s.one);
+        Fr init = fe_mul(fe_mul(w4m1, fe_sub(w4m1, w3)), s.ap[4]);                           // accumulator / x / y initialisation
+        init = fe_sub(init, fe_mul(fe_mul(w1, w3), s.ap[5]));
+        init = fe_add(init, fe_mul(fe_sub(fe_mul(fe_sub(s.one, w4), qc), fe_mul(w2, w3)), s.ap[6]));
+        gate = fe_add(gate, fe_mul(init, qc));
+    }
     const Fr q = fe_load<FrP>(a.quotient + i);
-    fe_store<FrP>(a.quotient + i, fe_add(q, fe_add(lin, gate)));
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(gate, qe)));
 }
 
 // ---- base-4 range check ("raster scan" over the 4 wire columns and the next row's 4th column):
@@ -474,7 +497,10 @@ int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsign
     switch (widget) {
     case 0: hipLaunchKernelGGL(k_quotient_permutation, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
     case 1: hipLaunchKernelGGL(k_quotient_turbo_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_quotient_turbo_fixed_base, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    case 2:
+        hipLaunchKernelGGL(k_quotient_turbo_fixed_base_linear, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_quotient_turbo_fixed_base_gate, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+        break;
     case 3: hipLaunchKernelGGL(k_quotient_turbo_range, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL(k_quotient_turbo_logic, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     }
