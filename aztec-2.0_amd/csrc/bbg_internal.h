@@ -84,6 +84,8 @@ struct bbg_ctx {
     hipEvent_t ev_acc[2] = { nullptr, nullptr }, ev_done[2] = { nullptr, nullptr };
     bool ev_done_valid[2] = { false, false };
     unsigned long msm_seq = 0;
+    size_t msm_layout_n = 0; // (n, window width) of the layout the scratch arena currently holds: a change of either moves
+    int msm_layout_c = 0;    // every region, so pending reduce phases are joined first (msm_run_c)
     bool msm_async_reduce = false;
     void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
     size_t gp_totals_bytes = 0;

@@ -931,6 +931,14 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
             BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
         }
     }
+    if (ctx->msm_layout_n != n || ctx->msm_layout_c != C) {
+        // a different (n, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
+        // regions this call is about to overwrite, so the main stream first waits for both slots (no host sync)
+        for (int k = 0; k < 2; k++)
+            if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
+        ctx->msm_layout_n = n;
+        ctx->msm_layout_c = C;
+    }
     const int slot = (int)(ctx->msm_seq++ & 1);
     char* base = (char*)ctx->msm.buf;
     uint32_t* keys0 = (uint32_t*)(base + L.off_keys0);

@@ -372,6 +372,35 @@ def test_msm_window20_vs_oracle(pkg, oracle, bbg, golden, srs16):
         bbg.set_option("msm_window", 0)
 
 
+def test_msm_async_reduce_with_changing_shapes(pkg, oracle, bbg, srs16):
+    """msm_async_reduce = 1 queues each MSM's bucket reduction on an auxiliary stream with double-buffered slots.  Back-to-back
+    MSMs of DIFFERENT sizes / window widths re-lay-out the scratch arena, so the library must join the pending reductions
+    first: every result of an interleaved sequence must equal the synchronous one."""
+    import torch
+    sizes = [1 << 16, 1000, 1 << 15, 17, 40001, 1 << 16, 3]
+    windows = [16, 20, 16, 16, 20, 20, 16]
+    scal = [pkg.synthetic_scalars(900 + i, n) for i, n in enumerate(sizes)]
+    want = []
+    for sc, w in zip(scal, windows):
+        bbg.set_option("msm_window", w)
+        want.append(oracle.jac_to_affine(bbg.msm(srs16, sc)))
+    dsc = [torch.from_numpy(sc.view(np.int64).reshape(-1)).cuda() for sc in scal]
+    outs = [torch.zeros(12, dtype=torch.int64, device="cuda") for _ in sizes]
+    bbg.set_option("msm_async_reduce", 1)
+    try:
+        for rep in range(3):
+            for d, o, n, w in zip(dsc, outs, sizes, windows):
+                bbg.set_option("msm_window", w)
+                bbg.msm_device(srs16, d.data_ptr(), n, o.data_ptr())
+            bbg.join()
+            bbg.sync()
+            for o, wnt in zip(outs, want):
+                assert np.array_equal(oracle.jac_to_affine(o.cpu().numpy().view(np.uint64)), wnt), rep
+    finally:
+        bbg.set_option("msm_async_reduce", 0)
+        bbg.set_option("msm_window", 0)
+
+
 def test_g1_sum_and_normalize(pkg, oracle, bbg, srs16):
     sc = pkg.synthetic_scalars(21, 300)
     parts = np.stack([bbg.msm(srs16, sc[i * 100:(i + 1) * 100], start=i * 100) for i in range(3)])
