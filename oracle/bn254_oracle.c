@@ -1001,3 +1001,143 @@ void oracle_permutation_z(const uint64_t* wires, const uint64_t* sigmas, unsigne
         root_beta = fe_mul(&FR, root_beta, root);
     }
 }
+
+/* ------------------------------------------------------------------- quotient widgets of a TurboPLONK prover
+ * CPU restatement of what ProverBase::execute_fourth_round's widgets add to the quotient on the 4n coset domain (reference
+ * plonk/proof_system/widgets: random_widgets/permutation_widget_impl.hpp:316-420 and transition_widgets/transition_widget.hpp:262-290
+ * with turbo_arithmetic_widget.hpp, turbo_fixed_base_widget.hpp, turbo_range_widget.hpp, turbo_logic_widget.hpp), written from
+ * the identities they enforce.  polys[] in the order of include/bbg.h's bbg_quotient_poly (w_1..4, z, sigma_1..4, q_1..5, q_m, q_c,
+ * q_arith, q_ecc_1, q_range, q_logic, L_1), each 2^log2_large values; challenges = alpha_base, alpha, beta, gamma,
+ * public_input_delta, g, k1, k2, k3 (Montgomery).  widget 0 assigns the quotient, 1..4 accumulate; alpha_out = the
+ * alpha_base handed to the next widget.  Pinned by tests/golden/widgets.json (recorded from the reference's widget objects). */
+static fe fr_small(uint64_t k) { fe r = { { k, 0, 0, 0 } }; return fe_to_mont(&FR, r); }
+static fe fr_ld(const uint64_t* p, size_t i) { fe r; memcpy(r.d, p + 4 * i, 32); return fe_canon(&FR, r); }
+#define FM(a, b) fe_mul(&FR, (a), (b))
+#define FA(a, b) fe_add(&FR, (a), (b))
+#define FS(a, b) fe_sub(&FR, (a), (b))
+static fe fr_x4(fe v) { fe d = FA(v, v); return FA(d, d); }
+static fe fr_quad(fe d) /* D (D-1)(D-2)(D-3) */
+{
+    fe t = FS(FM(d, d), d);
+    t = FM(t, FS(d, fr_small(2)));
+    return FM(t, FS(d, fr_small(3)));
+}
+int oracle_quotient_widget(int widget, const uint64_t* const* polys, unsigned log2_large, const uint64_t* challenges, uint64_t* quotient,
+                           uint64_t* alpha_out)
+{
+    if (widget < 0 || widget > 4 || log2_large < 3) return -1;
+    const size_t m = (size_t)1 << log2_large, mask = m - 1;
+    fe ch[9];
+    for (int k = 0; k < 9; k++) { memcpy(ch[k].d, challenges + 4 * k, 32); ch[k] = fe_canon(&FR, ch[k]); }
+    const fe alpha_base = ch[0], alpha = ch[1], beta = ch[2], gamma = ch[3], delta_pi = ch[4], g = ch[5];
+    const fe K[4] = { fe_one(&FR), ch[6], ch[7], ch[8] };
+    fe ap[8];
+    ap[0] = alpha_base;
+    for (int k = 1; k < 8; k++) ap[k] = FM(ap[k - 1], alpha);
+    const fe one = fe_one(&FR);
+    const uint64_t *W1 = polys[0], *W2 = polys[1], *W3 = polys[2], *W4 = polys[3], *Z = polys[4];
+    const uint64_t *Q1 = polys[9], *Q2 = polys[10], *Q3 = polys[11], *Q4 = polys[12], *Q5 = polys[13], *QM = polys[14], *QC = polys[15];
+    fe next;
+    if (widget == 0) {
+        const fe root = fr_root_of_unity(log2_large);
+        fe rb = FM(beta, g); /* beta * g * w^i */
+        const fe ab2 = FM(alpha_base, alpha_base);
+        for (size_t i = 0; i < m; i++) {
+            fe num = one, den = one;
+            for (int k = 0; k < 4; k++) {
+                fe wpg = FA(fr_ld(polys[k], i), gamma);
+                num = FM(num, FA(wpg, FM(K[k], rb)));
+                den = FM(den, FA(wpg, FM(fr_ld(polys[5 + k], i), beta)));
+            }
+            const fe z = fr_ld(Z, i), zw = fr_ld(Z, (i + 4) & mask);
+            num = FM(num, z);
+            den = FM(den, zw);
+            num = FA(num, FM(FM(FS(zw, delta_pi), alpha_base), fr_ld(polys[20], (i + 4 + 16) & mask)));
+            num = FA(num, FM(FM(FS(z, one), ab2), fr_ld(polys[20], i)));
+            fe q = FM(FS(num, den), alpha_base);
+            memcpy(quotient + 4 * i, q.d, 32);
+            rb = FM(rb, root);
+        }
+        next = FM(ab2, ab2);
+    } else {
+        for (size_t i = 0; i < m; i++) {
+            const size_t ish = (i + 4) & mask;
+            const fe w1 = fr_ld(W1, i), w2 = fr_ld(W2, i), w3 = fr_ld(W3, i), w4 = fr_ld(W4, i);
+            const fe w1n = fr_ld(W1, ish), w2n = fr_ld(W2, ish), w3n = fr_ld(W3, ish), w4n = fr_ld(W4, ish);
+            fe add;
+            if (widget == 1) { /* arithmetic gate + high-bit extraction */
+                const fe qa = fr_ld(polys[16], i);
+                fe gate = FM(FM(w1, w2), fr_ld(QM, i));
+                gate = FA(gate, FM(w1, fr_ld(Q1, i)));
+                gate = FA(gate, FM(w2, fr_ld(Q2, i)));
+                gate = FA(gate, FM(w3, fr_ld(Q3, i)));
+                gate = FA(gate, FM(w4, fr_ld(Q4, i)));
+                gate = FA(gate, fr_ld(QC, i));
+                fe t = FM(FM(FS(FM(w4, w4), w4), FS(w4, fr_small(2))), alpha);
+                gate = FM(FA(gate, FM(t, fr_ld(Q5, i))), qa);
+                const fe d = FS(w3, fr_x4(w4));
+                fe h = FS(FS(FM(fr_small(9), d), FM(fr_small(2), FM(d, d))), fr_small(7));
+                h = FM(FM(h, d), FS(FM(qa, qa), qa));
+                add = FM(FA(gate, h), ap[0]);
+            } else if (widget == 2) { /* fixed-base ladder over y^2 = x^3 - 17 */
+                const fe qc = fr_ld(QC, i), qe = fr_ld(polys[17], i);
+                const fe dl = FS(w4n, fr_x4(w4));
+                fe lin = FM(FM(FM(dl, dl), ap[1]), fr_ld(Q1, i));
+                lin = FA(lin, FM(ap[1], fr_ld(Q2, i)));
+                fe t3 = FM(FM(FM(FS(w1n, w1), dl), w3n), ap[3]);
+                fe u = FM(FM(FM(dl, w3n), w2), ap[2]);
+                lin = FA(lin, FM(FA(t3, FA(u, u)), fr_ld(Q3, i)));
+                fe init = FM(FM(w3, ap[5]), fr_ld(Q4, i));
+                init = FA(init, FM(FM(FS(one, w4), ap[5]), fr_ld(Q5, i)));
+                init = FA(init, FM(FM(w3, ap[6]), fr_ld(QM, i)));
+                lin = FA(lin, FM(init, qc));
+                const fe three = fr_small(3);
+                fe gate = FM(FM(FM(FA(dl, one), FA(dl, three)), FM(FS(dl, one), FS(dl, three))), ap[0]);
+                gate = FS(gate, FM(w3n, ap[1]));
+                const fe dx = FS(w3n, w1);
+                fe xacc = FM(FA(FA(w1n, w1), w3n), FM(dx, dx));
+                xacc = FS(xacc, FS(FA(FM(FM(w3n, w3n), w3n), FM(w2, w2)), fr_small(17)));
+                fe tdy = FM(FM(dl, w2), qe);
+                xacc = FA(xacc, FA(tdy, tdy));
+                gate = FA(gate, FM(xacc, ap[2]));
+                fe yacc = FA(FM(FA(w2n, w2), dx), FM(FS(w1, w1n), FS(w2, FM(qe, dl))));
+                gate = FA(gate, FM(yacc, ap[3]));
+                const fe w4m1 = FS(w4, one);
+                fe gi = FM(FM(w4m1, FS(w4m1, w3)), ap[4]);
+                gi = FS(gi, FM(FM(w1, w3), ap[5]));
+                gi = FA(gi, FM(FS(FM(FS(one, w4), qc), FM(w2, w3)), ap[6]));
+                gate = FA(gate, FM(gi, qc));
+                add = FM(FA(lin, gate), qe);
+            } else if (widget == 3) { /* base-4 range raster */
+                fe sum = FM(fr_quad(FS(w3, fr_x4(w4))), ap[0]);
+                sum = FA(sum, FM(fr_quad(FS(w2, fr_x4(w3))), ap[1]));
+                sum = FA(sum, FM(fr_quad(FS(w1, fr_x4(w2))), ap[2]));
+                sum = FA(sum, FM(fr_quad(FS(w4n, fr_x4(w1))), ap[3]));
+                add = FM(sum, fr_ld(polys[18], i));
+            } else { /* AND / XOR on quads */
+                const fe qa = FS(w1n, fr_x4(w1)), qb = FS(w2n, fr_x4(w2)), qq = FS(w4n, fr_x4(w4));
+                const fe sm = FA(qa, qb), sq = FA(FM(qa, qa), FM(qb, qb));
+                fe id = FM(FM(fr_small(2), FS(FM(qa, qb), w3)), alpha);
+                id = FM(FA(id, fr_quad(qa)), alpha);
+                id = FM(FA(id, fr_quad(qb)), alpha);
+                fe e = FA(FS(fr_x4(w3), FM(fr_small(18), sm)), fr_small(81));
+                e = FM(e, w3);
+                e = FA(e, FA(FS(FM(fr_small(18), sq), FM(fr_small(81), sm)), fr_small(83)));
+                e = FM(e, w3);
+                fe tail = FS(FM(fr_small(3), FA(qq, sm)), FA(e, e));
+                tail = FA(tail, FM(FS(FM(fr_small(9), qq), FM(fr_small(3), sm)), fr_ld(QC, i)));
+                add = FM(FM(FA(id, tail), ap[0]), fr_ld(polys[19], i));
+            }
+            fe q = FA(fr_ld(quotient, i), add);
+            memcpy(quotient + 4 * i, q.d, 32);
+        }
+        static const int NREL[5] = { 0, 2, 7, 4, 4 }; /* independent relations per widget: update_alpha */
+        next = FM(ap[NREL[widget] - 1], alpha);
+    }
+    next = fe_canon(&FR, next);
+    memcpy(alpha_out, next.d, 32);
+    return 0;
+}
+#undef FM
+#undef FA
+#undef FS

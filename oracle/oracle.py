@@ -61,6 +61,7 @@ class Oracle:
         L.oracle_kate_opening.argtypes = [vp, vp, sz, vp, vp]; L.oracle_kate_opening.restype = None
         L.oracle_divide_by_pseudo_vanishing.argtypes = [vp, cu, cu, sz]; L.oracle_divide_by_pseudo_vanishing.restype = cint
         L.oracle_permutation_z.argtypes = [vp, vp, cu, vp, vp, vp, vp]
+        L.oracle_quotient_widget.argtypes = [cint, vp, cu, vp, vp, vp]; L.oracle_quotient_widget.restype = cint
 
     # ---- fields (which: 0 Fr, 1 Fq)
     def _bin(self, fn, which, a, b):
@@ -222,6 +223,18 @@ class Oracle:
         dest, f = np.empty_like(a), np.empty(4, dtype=np.uint64)
         self.lib.oracle_kate_opening(a.ctypes.data, dest.ctypes.data, a.shape[0], z.ctypes.data, f.ctypes.data)
         return dest, f
+
+    def quotient_widget(self, widget, polys, log2_large, challenges, quotient):
+        """polys: list of 21 (m, 4) arrays in bbg_quotient_poly order; challenges (9, 4); quotient (m, 4) updated in place.
+        Returns the next alpha_base (canonical)."""
+        arrs = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+        ptrs = (ctypes.c_void_p * 21)(*[a.ctypes.data for a in arrs])
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        assert quotient.flags["C_CONTIGUOUS"] and quotient.dtype == np.uint64
+        rc = self.lib.oracle_quotient_widget(widget, ptrs, log2_large, ch.ctypes.data, quotient.ctypes.data, out.ctypes.data)
+        assert rc == 0, rc
+        return out
 
     def permutation_z(self, wires, sigmas, beta, gamma, ks):
         """wires, sigmas: (4, n, 4) Lagrange-base values; ks: (3, 4) coset generators.  Returns z (n, 4), canonical."""

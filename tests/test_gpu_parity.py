@@ -585,6 +585,23 @@ def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0):
         yield alpha_base, quot.cpu().numpy().view(np.uint64).reshape(-1, 4)
 
 
+@pytest.mark.parametrize("log2_large", [3, 5, 8, 13])
+def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large):
+    """All five widgets against the oracle's restatement (itself pinned by the reference goldens) on arbitrary challenge values
+    -- public_input_delta, g, k1..k3 are NOT the transcript / field constants here -- and on the smallest legal domain."""
+    m = 1 << log2_large
+    polys = [pkg.synthetic_scalars(5000 + 31 * log2_large + k, m) for k in range(21)]
+    ch9 = pkg.synthetic_scalars(6000 + log2_large, 9)
+    quot = np.zeros((m, 4), dtype=np.uint64)
+    alpha_base = ch9[0].copy()
+    for widget, (alpha_out, q) in enumerate(_run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, ch9[0])):
+        ch = ch9.copy()
+        ch[0] = alpha_base
+        alpha_base = oracle.quotient_widget(widget, polys, log2_large, ch, quot)
+        assert np.array_equal(oracle.canon(0, alpha_out.reshape(1, 4))[0], alpha_base), widget
+        assert np.array_equal(oracle.canon(0, q), oracle.canon(0, quot)), widget
+
+
 def test_quotient_widgets_vs_reference_golden(pkg, oracle, bbg):
     """Permutation + turbo arithmetic / fixed-base / range / logic quotient contributions on the 4n coset domain against digests
     recorded from the reference's own widget objects (tests/golden/widgets.json, gen_golden_widgets.py), n = 2^6 and 2^10."""

@@ -287,3 +287,32 @@ def test_reference_prover_with_oracle_engine(oracle):
     proof = P.prove(FusedEngine(P.monomials()))
     assert P.mismatches == 0 and len(proof) > 0 and P.verify() == 1
     P.free()
+
+
+def test_quotient_widgets_oracle_vs_reference_golden(oracle):
+    """The oracle's restatement of the five TurboPLONK quotient widgets (oracle_quotient_widget) against the digests recorded
+    from the reference's own widget objects (tests/golden/widgets.json, gen_golden_widgets.py): same seeded inputs, the
+    prover's widget order, quotient array and returned alpha_base after each widget."""
+    import json
+    import os
+    from oracle.oracle import RefWidgets
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "widgets.json")) as f:
+        G = json.load(f)
+    for case in G["cases"]:
+        log2_large = case["log2n"] + 2
+        m = 1 << log2_large
+        c = case["challenges"]
+        ch9 = np.stack([unhex(c[k], 4)[0] for k in ("alpha", "alpha", "beta", "gamma", "public_input_delta", "g", "k1", "k2", "k3")])
+        polys = [pkg.synthetic_scalars(G["seed"] + k, m) for k in range(len(RefWidgets.LABELS))]
+        quot = np.zeros((m, 4), dtype=np.uint64)
+        alpha_base = unhex(c["alpha"], 4)[0]
+        for rec in case["widgets"]:
+            ch = ch9.copy()
+            ch[0] = alpha_base
+            alpha_base = oracle.quotient_widget(rec["widget"], polys, log2_large, ch, quot)
+            assert np.array_equal(alpha_base, unhex(rec["alpha_base_out"], 4)[0]), rec["widget"]
+            qc = oracle.canon(0, quot)
+            assert np.array_equal(qc[:2], unhex(rec["quotient_first2"], 4)), rec["widget"]
+            assert sha(qc) == rec["quotient_sha256"], rec["widget"]
