@@ -32,7 +32,7 @@ struct QuotientSetup {
     Fr beta_g;      // beta * g (g = the small domain's coset generator): beta*g*w^i is the identity-permutation term
     Fr k1, k2, k3;  // coset generators of the wire columns 2..4 (fr::coset_generator(0..2))
     Fr one, c2, c3, c6, c7, c17, c81, c83;
-    Fr alpha_out[5]; // per widget: the alpha_base the next widget starts from
+    Fr alpha_out[7]; // per widget: the alpha_base the next widget starts from
 };
 struct QuotientArgs {
     const Fr* p[QP_COUNT];
@@ -85,6 +85,8 @@ __global__ void k_quotient_setup(QuotientSetup* s, const Fr* in /* alpha_base, a
     s->alpha_out[2] = fe_mul(s->ap[6], alpha);       // fixed base: 7
     s->alpha_out[3] = fe_mul(s->ap[3], alpha);       // range: 4
     s->alpha_out[4] = fe_mul(s->ap[3], alpha);       // logic: 4
+    s->alpha_out[5] = s->alpha_out[0];               // permutation, 3 wires
+    s->alpha_out[6] = s->ap[1];                      // standard arithmetic: 1 relation
 }
 
 #define QLOAD(id, idx) fe_load<FrP>(a.p[id] + (idx))
@@ -106,7 +108,7 @@ __device__ __forceinline__ Fr quad_check(const Fr& d, const QuotientSetup& s)
 //                      + (z(wX) - delta) alpha_base L_{n-4}(X) + (z(X) - 1) alpha_base^2 L_1(X) ]
 // L_{n-4} is read from the L_1 table at the shifted index i + 4 + 4*4 (4 roots cut out of the vanishing polynomial).
 constexpr int PERM_CH = 4;
-__global__ void __launch_bounds__(256) k_quotient_permutation(QuotientArgs a)
+template <int WIDTH> __global__ void __launch_bounds__(256) k_quotient_permutation(QuotientArgs a)
 {
     const QuotientSetup& s = *a.s;
     const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * PERM_CH;
@@ -125,9 +127,11 @@ __global__ void __launch_bounds__(256) k_quotient_permutation(QuotientArgs a)
         wpg = fe_add(QLOAD(QP_W3, i), s.gamma);
         num = fe_mul(num, fe_add(wpg, fe_mul(s.k2, rb)));
         den = fe_mul(den, fe_add(wpg, fe_mul(QLOAD(QP_S3, i), s.beta)));
-        wpg = fe_add(QLOAD(QP_W4, i), s.gamma);
-        num = fe_mul(num, fe_add(wpg, fe_mul(s.k3, rb)));
-        den = fe_mul(den, fe_add(wpg, fe_mul(QLOAD(QP_S4, i), s.beta)));
+        if constexpr (WIDTH == 4) { // StandardPLONK has three wire columns (ProverPermutationWidget<3,false>)
+            wpg = fe_add(QLOAD(QP_W4, i), s.gamma);
+            num = fe_mul(num, fe_add(wpg, fe_mul(s.k3, rb)));
+            den = fe_mul(den, fe_add(wpg, fe_mul(QLOAD(QP_S4, i), s.beta)));
+        }
         const Fr z = QLOAD(QP_Z, i), zw = QLOAD(QP_Z, ish);
         num = fe_mul(num, z);
         den = fe_mul(den, zw);
@@ -138,6 +142,22 @@ __global__ void __launch_bounds__(256) k_quotient_permutation(QuotientArgs a)
         fe_store<FrP>(a.quotient + i, fe_mul(fe_sub(num, den), s.ap[0]));
         rb = fe_mul(rb, root);
     }
+}
+
+// ---- StandardPLONK arithmetic gate (arithmetic_widget.hpp): alpha_base (q_m w1 w2 + q_1 w1 + q_2 w2 + q_3 w3 + q_c)
+__global__ void __launch_bounds__(256) k_quotient_standard_arith(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const Fr w1 = QLOAD(QP_W1, i), w2 = QLOAD(QP_W2, i);
+    Fr gate = fe_mul(fe_mul(w1, w2), QLOAD(QP_QM, i));
+    gate = fe_add(gate, fe_mul(w1, QLOAD(QP_Q1, i)));
+    gate = fe_add(gate, fe_mul(w2, QLOAD(QP_Q2, i)));
+    gate = fe_add(gate, fe_mul(QLOAD(QP_W3, i), QLOAD(QP_Q3, i)));
+    gate = fe_add(gate, QLOAD(QP_QC, i));
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(gate, s.ap[0])));
 }
 
 // ---- turbo arithmetic gate:
@@ -460,11 +480,11 @@ int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const vo
 int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
                     uint64_t* alpha_out, hipStream_t st)
 {
-    if (widget < 0 || widget > 4) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
+    if (widget < 0 || widget > 6) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
     if (log2_large < 3 || log2_large > 28) { set_error("bbg_quotient_widget_device: need 3 <= log2 of the 4n domain <= 28"); return BBG_E_INVALID; }
     if (!d_polys || !challenges || !d_quotient) { set_error("bbg_quotient_widget_device: null argument"); return BBG_E_INVALID; }
     // which polynomials each widget reads (a null pointer for one of them is an error; the others may be null)
-    static const uint32_t NEED[5] = {
+    static const uint32_t NEED[7] = {
         (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) |
             (1u << QP_S4) | (1u << QP_L1),
         (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
@@ -473,6 +493,8 @@ int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsign
             (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QECC),
         (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QRANGE),
         (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QC) | (1u << QP_QLOGIC),
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) | (1u << QP_L1),
+        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_QM) | (1u << QP_QC),
     };
     QuotientArgs a;
     for (int k = 0; k < QP_COUNT; k++) {
@@ -495,7 +517,9 @@ int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsign
     const size_t m = (size_t)1 << log2_large;
     ProfScope ps(ctx, "quotient_widget", st);
     switch (widget) {
-    case 0: hipLaunchKernelGGL(k_quotient_permutation, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+    case 0: hipLaunchKernelGGL(k_quotient_permutation<4>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(k_quotient_permutation<3>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(k_quotient_standard_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     case 1: hipLaunchKernelGGL(k_quotient_turbo_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     case 2:
         hipLaunchKernelGGL(k_quotient_turbo_fixed_base_linear, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);

@@ -183,7 +183,9 @@ enum bbg_quotient_widget {
     BBG_WIDGET_TURBO_ARITHMETIC = 1, /* TurboArithmeticKernel (turbo_arithmetic_widget.hpp): the transition widgets ACCUMULATE */
     BBG_WIDGET_TURBO_FIXED_BASE = 2, /* TurboFixedBaseKernel */
     BBG_WIDGET_TURBO_RANGE = 3,      /* TurboRangeKernel */
-    BBG_WIDGET_TURBO_LOGIC = 4       /* TurboLogicKernel */
+    BBG_WIDGET_TURBO_LOGIC = 4,      /* TurboLogicKernel */
+    BBG_WIDGET_PERMUTATION_3 = 5,    /* StandardPLONK: ProverPermutationWidget<3,false> (w_4 / sigma_4 not read): ASSIGNS */
+    BBG_WIDGET_ARITHMETIC = 6        /* StandardPLONK: ArithmeticKernel (arithmetic_widget.hpp): accumulates */
 };
 /* challenges: 9 Montgomery Fr (4 limbs each) on the host -- alpha_base (this widget's starting power of alpha), alpha,
  * beta, gamma, public_input_delta, g (the small domain's coset generator), k1, k2, k3 (fr::coset_generator(0..2)).

@@ -1025,7 +1025,7 @@ static fe fr_quad(fe d) /* D (D-1)(D-2)(D-3) */
 int oracle_quotient_widget(int widget, const uint64_t* const* polys, unsigned log2_large, const uint64_t* challenges, uint64_t* quotient,
                            uint64_t* alpha_out)
 {
-    if (widget < 0 || widget > 4 || log2_large < 3) return -1;
+    if (widget < 0 || widget > 6 || log2_large < 3) return -1;
     const size_t m = (size_t)1 << log2_large, mask = m - 1;
     fe ch[9];
     for (int k = 0; k < 9; k++) { memcpy(ch[k].d, challenges + 4 * k, 32); ch[k] = fe_canon(&FR, ch[k]); }
@@ -1038,13 +1038,14 @@ int oracle_quotient_widget(int widget, const uint64_t* const* polys, unsigned lo
     const uint64_t *W1 = polys[0], *W2 = polys[1], *W3 = polys[2], *W4 = polys[3], *Z = polys[4];
     const uint64_t *Q1 = polys[9], *Q2 = polys[10], *Q3 = polys[11], *Q4 = polys[12], *Q5 = polys[13], *QM = polys[14], *QC = polys[15];
     fe next;
-    if (widget == 0) {
+    if (widget == 0 || widget == 5) { /* 5 = StandardPLONK: three wire columns */
+        const int width = widget == 0 ? 4 : 3;
         const fe root = fr_root_of_unity(log2_large);
         fe rb = FM(beta, g); /* beta * g * w^i */
         const fe ab2 = FM(alpha_base, alpha_base);
         for (size_t i = 0; i < m; i++) {
             fe num = one, den = one;
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < width; k++) {
                 fe wpg = FA(fr_ld(polys[k], i), gamma);
                 num = FM(num, FA(wpg, FM(K[k], rb)));
                 den = FM(den, FA(wpg, FM(fr_ld(polys[5 + k], i), beta)));
@@ -1059,6 +1060,18 @@ int oracle_quotient_widget(int widget, const uint64_t* const* polys, unsigned lo
             rb = FM(rb, root);
         }
         next = FM(ab2, ab2);
+    } else if (widget == 6) { /* StandardPLONK arithmetic gate (arithmetic_widget.hpp) */
+        for (size_t i = 0; i < m; i++) {
+            const fe w1 = fr_ld(W1, i), w2 = fr_ld(W2, i);
+            fe gate = FM(FM(w1, w2), fr_ld(QM, i));
+            gate = FA(gate, FM(w1, fr_ld(Q1, i)));
+            gate = FA(gate, FM(w2, fr_ld(Q2, i)));
+            gate = FA(gate, FM(fr_ld(W3, i), fr_ld(Q3, i)));
+            gate = FA(gate, fr_ld(QC, i));
+            fe q = FA(fr_ld(quotient, i), FM(gate, ap[0]));
+            memcpy(quotient + 4 * i, q.d, 32);
+        }
+        next = ap[1];
     } else {
         for (size_t i = 0; i < m; i++) {
             const size_t ish = (i + 4) & mask;

@@ -669,7 +669,9 @@ class RefWidgets:
               "q_1_fft", "q_2_fft", "q_3_fft", "q_4_fft", "q_5_fft", "q_m_fft", "q_c_fft", "q_arith_fft", "q_ecc_1_fft",
               "q_range_fft", "q_logic_fft", "lagrange_1"]
 
-    def __init__(self, prover):
+    def __init__(self, prover, standard=None):
+        """prover: a RefProver (TurboPLONK widgets 0..4).  standard=(num_gates, points, x_mont): instead build a StandardPLONK key
+        through the same library; its widgets are 0 = permutation over three wires, 1 = arithmetic."""
         self.prover = prover  # keeps the session (proving key) alive
         L = self.lib = prover.lib
         L.refw_new.argtypes = [vp]; L.refw_new.restype = vp
@@ -679,10 +681,21 @@ class RefWidgets:
         L.refw_get_poly.argtypes = [vp, ctypes.c_char_p, vp, sz]; L.refw_get_poly.restype = cint
         L.refw_challenges.argtypes = [vp, vp]
         L.refw_run_widget.argtypes = [vp, cint, vp, vp]; L.refw_run_widget.restype = cint
-        self.h = L.refw_new(prover.h)
+        L.refw_new_standard.argtypes = [sz, vp, sz, vp]; L.refw_new_standard.restype = vp
+        L.refw_circuit_size.argtypes = [vp]; L.refw_circuit_size.restype = sz
+        if standard is None:
+            self.h = L.refw_new(prover.h)
+        else:
+            gates, pts, x = standard
+            pts = _arr(pts, 8)
+            x = np.ascontiguousarray(x, dtype=np.uint64)
+            self.h = L.refw_new_standard(gates, pts.ctypes.data, pts.shape[0], x.ctypes.data)
         if not self.h:
             raise RuntimeError("refw_new failed")
-        self.m = 4 * prover.n  # large (coset) domain size
+        self.m = 4 * int(L.refw_circuit_size(self.h))  # large (coset) domain size
+
+    def has_poly(self, label):
+        return int(self.lib.refw_poly_size(self.h, label.encode())) > 0
 
     def set_poly(self, label, data):
         a = _arr(data, 4)

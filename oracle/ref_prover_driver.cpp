@@ -28,6 +28,7 @@
 #include <ecc/curves/bn254/pairing.hpp>
 #include <ecc/curves/bn254/scalar_multiplication/pippenger.hpp>
 #include <ecc/curves/bn254/scalar_multiplication/scalar_multiplication.hpp>
+#include <plonk/composer/standard_composer.hpp>
 #include <plonk/composer/turbo_composer.hpp>
 #include <plonk/proof_system/prover/prover.hpp>
 #include <plonk/proof_system/verifier/verifier.hpp>
@@ -336,32 +337,52 @@ void refp_delete(void* h) { delete (Session*)h; }
 // pattern of transition_widgets/create_dummy_transcript.hpp), so that their compute_quotient_contribution
 // (permutation_widget_impl.hpp:316-420, transition_widget.hpp:262-290) can be compared with the GPU kernels on seeded
 // inputs and recorded as golden digests.  The widgets are pure functions of the key's *_fft arrays and the challenges.
+// a StandardPLONK (3 wires) composer + prover, only to obtain its key layout and widget objects
+struct StdSession {
+    std::unique_ptr<waffle::StandardComposer> composer;
+    std::unique_ptr<waffle::Prover> prover;
+};
 struct WidgetHarness {
-    Session* session;
+    waffle::proving_key* key;
+    std::vector<std::unique_ptr<waffle::ProverRandomWidget>>* random_widgets;
+    std::vector<std::unique_ptr<waffle::widget::TransitionWidgetBase<fr>>>* transition_widgets;
     transcript::StandardTranscript transcript;
-    WidgetHarness(Session* s)
-        : session(s)
-        , transcript(waffle::TurboComposer::create_manifest(0), waffle::turbo_settings::hash_type, waffle::turbo_settings::num_challenge_bytes)
+    std::unique_ptr<StdSession> owned;
+    static transcript::StandardTranscript dummy_transcript(const transcript::Manifest& manifest, transcript::HashType hash, size_t challenge_bytes,
+                                                           int wires, bool eta_round)
     {
+        transcript::StandardTranscript t(manifest, hash, challenge_bytes);
         std::vector<uint8_t> g1_vector(64, 1);
-        transcript.add_element("circuit_size", { 1, 2, 3, 4 });
-        transcript.add_element("public_input_size", { 0, 0, 0, 0 });
-        transcript.apply_fiat_shamir("init");
-        transcript.apply_fiat_shamir("eta");
-        transcript.add_element("public_inputs", {});
-        transcript.add_element("W_1", g1_vector);
-        transcript.add_element("W_2", g1_vector);
-        transcript.add_element("W_3", g1_vector);
-        transcript.add_element("W_4", g1_vector);
-        transcript.apply_fiat_shamir("beta");
-        transcript.add_element("Z", g1_vector);
-        transcript.apply_fiat_shamir("alpha");
+        t.add_element("circuit_size", { 1, 2, 3, 4 });
+        t.add_element("public_input_size", { 0, 0, 0, 0 });
+        t.apply_fiat_shamir("init");
+        if (eta_round) t.apply_fiat_shamir("eta");
+        t.add_element("public_inputs", {});
+        for (int k = 1; k <= wires; k++) t.add_element("W_" + std::to_string(k), g1_vector);
+        t.apply_fiat_shamir("beta");
+        t.add_element("Z", g1_vector);
+        t.apply_fiat_shamir("alpha");
+        return t;
     }
+    WidgetHarness(Session* s)
+        : key(s->prover->key.get())
+        , random_widgets(&s->prover->random_widgets)
+        , transition_widgets(&s->prover->transition_widgets)
+        , transcript(dummy_transcript(waffle::TurboComposer::create_manifest(0), waffle::turbo_settings::hash_type,
+                                      waffle::turbo_settings::num_challenge_bytes, 4, true))
+    {}
+    WidgetHarness(std::unique_ptr<StdSession> s)
+        : key(s->prover->key.get())
+        , random_widgets(&s->prover->random_widgets)
+        , transition_widgets(&s->prover->transition_widgets)
+        , transcript(dummy_transcript(waffle::StandardComposer::create_manifest(0), waffle::standard_settings::hash_type,
+                                      waffle::standard_settings::num_challenge_bytes, 3, true))
+        , owned(std::move(s))
+    {}
 };
 
-static polynomial* find_poly(Session* s, const std::string& label)
+static polynomial* find_poly(waffle::proving_key* key, const std::string& label)
 {
-    auto* key = s->prover->key.get();
     if (label == "quotient_large") return &key->quotient_large;
     if (label == "lagrange_1") return &key->lagrange_1;
     auto it = key->wire_ffts.find(label);
@@ -383,6 +404,30 @@ void* refw_new(void* session)
         return nullptr;
     }
 }
+// StandardPLONK flavour: widget 0 = ProverPermutationWidget<3, false>, widget 1 = ProverArithmeticWidget (standard_composer.cpp:569-577)
+void* refw_new_standard(size_t num_gates, const uint64_t* points, size_t num_points, const uint64_t* x_mont)
+{
+    try {
+        fr x{ x_mont[0], x_mont[1], x_mont[2], x_mont[3] };
+        auto s = std::make_unique<StdSession>();
+        s->composer = std::make_unique<waffle::StandardComposer>(
+            std::unique_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
+        fr a = fr(3).to_montgomery_form();
+        uint32_t ai = s->composer->add_variable(a);
+        for (size_t k = 0; k < num_gates; k++) { // a * a = b, chained
+            fr b = a * a;
+            uint32_t bi = s->composer->add_variable(b);
+            s->composer->create_mul_gate({ ai, ai, bi, fr::one(), fr::neg_one(), fr::zero() });
+            a = b;
+            ai = bi;
+        }
+        s->prover = std::make_unique<waffle::Prover>(s->composer->create_prover());
+        return new WidgetHarness(std::move(s));
+    } catch (...) {
+        return nullptr;
+    }
+}
+size_t refw_circuit_size(void* w) { return ((WidgetHarness*)w)->key->n; }
 void refw_delete(void* w) { delete (WidgetHarness*)w; }
 
 // size (in field elements) of a named polynomial of the proving key: "w_1_fft".."w_4_fft", "z_fft", "sigma_1_fft"..,
@@ -390,19 +435,19 @@ void refw_delete(void* w) { delete (WidgetHarness*)w; }
 // "lagrange_1", "quotient_large"; 0 if unknown
 size_t refw_poly_size(void* w, const char* label)
 {
-    polynomial* p = find_poly(((WidgetHarness*)w)->session, label);
+    polynomial* p = find_poly(((WidgetHarness*)w)->key, label);
     return p ? p->get_max_size() : 0;
 }
 int refw_set_poly(void* w, const char* label, const uint64_t* data, size_t count)
 {
-    polynomial* p = find_poly(((WidgetHarness*)w)->session, label);
+    polynomial* p = find_poly(((WidgetHarness*)w)->key, label);
     if (!p || count > p->get_max_size()) return -1;
     std::memcpy((void*)&(*p)[0], data, count * 32);
     return 0;
 }
 int refw_get_poly(void* w, const char* label, uint64_t* out, size_t count)
 {
-    polynomial* p = find_poly(((WidgetHarness*)w)->session, label);
+    polynomial* p = find_poly(((WidgetHarness*)w)->key, label);
     if (!p || count > p->get_max_size()) return -1;
     std::memcpy(out, (const void*)&(*p)[0], count * 32);
     return 0;
@@ -412,7 +457,7 @@ int refw_get_poly(void* w, const char* label, uint64_t* out, size_t count)
 void refw_challenges(void* wp, uint64_t* out)
 {
     auto* w = (WidgetHarness*)wp;
-    auto* key = w->session->prover->key.get();
+    auto* key = w->key;
     fr alpha = fr::serialize_from_buffer(w->transcript.get_challenge("alpha").begin());
     fr beta = fr::serialize_from_buffer(w->transcript.get_challenge("beta").begin());
     fr gamma = fr::serialize_from_buffer(w->transcript.get_challenge("beta", 1).begin());
@@ -428,11 +473,10 @@ int refw_run_widget(void* wp, int widget, const uint64_t* alpha_base, uint64_t* 
 {
     try {
         auto* w = (WidgetHarness*)wp;
-        auto& p = *w->session->prover;
         fr a{ alpha_base[0], alpha_base[1], alpha_base[2], alpha_base[3] };
         fr r;
-        if (widget == 0) r = p.random_widgets.at(0)->compute_quotient_contribution(a, w->transcript);
-        else r = p.transition_widgets.at((size_t)widget - 1)->compute_quotient_contribution(a, w->transcript);
+        if (widget == 0) r = w->random_widgets->at(0)->compute_quotient_contribution(a, w->transcript);
+        else r = w->transition_widgets->at((size_t)widget - 1)->compute_quotient_contribution(a, w->transcript);
         std::memcpy(alpha_out, &r, 32);
         return 0;
     } catch (...) {
@@ -463,7 +507,7 @@ int refp_round4_begin(void* h, const uint64_t** poly_ptrs, uint64_t* challenges,
         p.queue.flush_queue();
         p.transcript.apply_fiat_shamir("alpha");
         for (int k = 0; k < 21; k++) {
-            polynomial* poly = find_poly(s, ROUND4_LABELS[k]);
+            polynomial* poly = find_poly(s->prover->key.get(), ROUND4_LABELS[k]);
             if (!poly) return -1;
             poly_ptrs[k] = (const uint64_t*)&(*poly)[0];
         }

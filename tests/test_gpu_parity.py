@@ -499,7 +499,7 @@ def test_round_kernel_error_paths(pkg, bbg):
     ch9 = pkg.synthetic_scalars(1, 9)
     ptrs = [buf.data_ptr()] * 21
     with pytest.raises(pkg.BbgError):
-        bbg.quotient_widget_device(5, ptrs, 6, ch9, buf.data_ptr())      # unknown widget
+        bbg.quotient_widget_device(7, ptrs, 6, ch9, buf.data_ptr())      # unknown widget
     with pytest.raises(pkg.BbgError):
         bbg.quotient_widget_device(0, ptrs, 2, ch9, buf.data_ptr())      # domain too small for the shifted rows
     missing = list(ptrs)
@@ -570,14 +570,14 @@ def _widget_inputs(pkg, m):
     return [pkg.synthetic_scalars(seed + k, m) for k in range(len(RefWidgets.LABELS))]
 
 
-def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0):
-    """Uploads the 21 polynomials, runs the five widgets in the prover's order; yields (alpha_out, quotient) after each."""
+def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0, widgets=(0, 1, 2, 3, 4)):
+    """Uploads the 21 polynomials, runs the widgets in the prover's order; yields (alpha_out, quotient) after each."""
     import torch
     dev = [torch.from_numpy(p.view(np.int64).reshape(-1)).cuda() for p in polys]
     quot = torch.zeros((1 << log2_large) * 4, dtype=torch.int64, device="cuda")
     ptrs = [d.data_ptr() for d in dev]
     alpha_base = alpha0
-    for widget in range(5):
+    for widget in widgets:
         ch = ch9.copy()
         ch[0] = alpha_base
         alpha_base = bbg.quotient_widget_device(widget, ptrs, log2_large, ch, quot.data_ptr())
@@ -594,7 +594,8 @@ def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large):
     ch9 = pkg.synthetic_scalars(6000 + log2_large, 9)
     quot = np.zeros((m, 4), dtype=np.uint64)
     alpha_base = ch9[0].copy()
-    for widget, (alpha_out, q) in enumerate(_run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, ch9[0])):
+    order = (0, 1, 2, 3, 4, 5, 6)  # the StandardPLONK pair (5 assigns again, 6 accumulates) after the TurboPLONK five
+    for widget, (alpha_out, q) in zip(order, _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, ch9[0], order)):
         ch = ch9.copy()
         ch[0] = alpha_base
         alpha_base = oracle.quotient_widget(widget, polys, log2_large, ch, quot)
@@ -607,13 +608,14 @@ def test_quotient_widgets_vs_reference_golden(pkg, oracle, bbg):
     recorded from the reference's own widget objects (tests/golden/widgets.json, gen_golden_widgets.py), n = 2^6 and 2^10."""
     with open(os.path.join(os.path.dirname(__file__), "golden", "widgets.json")) as f:
         G = json.load(f)
-    for case in G["cases"]:
+    for case in G["cases"] + G["standard_cases"]:  # TurboPLONK 0..4, then StandardPLONK (three wires): widgets 5, 6
         log2_large = case["log2n"] + 2
         m = 1 << log2_large
         c = case["challenges"]
         ch9 = np.stack([unhex(c[k], 4)[0] for k in ("alpha", "alpha", "beta", "gamma", "public_input_delta", "g", "k1", "k2", "k3")])
         polys = _widget_inputs(pkg, m)
-        for rec, (alpha_out, q) in zip(case["widgets"], _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, unhex(c["alpha"], 4)[0])):
+        order = [rec["widget"] for rec in case["widgets"]]
+        for rec, (alpha_out, q) in zip(case["widgets"], _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, unhex(c["alpha"], 4)[0], order)):
             assert np.array_equal(oracle.canon(0, alpha_out.reshape(1, 4))[0], unhex(rec["alpha_base_out"], 4)[0]), rec["widget"]
             qc = oracle.canon(0, q)
             assert np.array_equal(qc[:2], unhex(rec["quotient_first2"], 4)), rec["widget"]

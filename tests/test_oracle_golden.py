@@ -300,7 +300,7 @@ def test_quotient_widgets_oracle_vs_reference_golden(oracle):
     pkg = ge.load_package()
     with open(os.path.join(os.path.dirname(__file__), "golden", "widgets.json")) as f:
         G = json.load(f)
-    for case in G["cases"]:
+    for case in G["cases"] + G["standard_cases"]:  # TurboPLONK widgets 0..4, then StandardPLONK (three wires) widgets 5, 6
         log2_large = case["log2n"] + 2
         m = 1 << log2_large
         c = case["challenges"]
