@@ -453,8 +453,19 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
         __syncthreads();
         for (uint32_t q = tid; q < len; q += 1024) svals[pb + q] = stage[q];
     } else {
+        // Large partition: chunks of 8192 entries are grouped by bucket in LDS and written out as runs (one run per bucket
+        // and chunk, on consecutive addresses) instead of 8192 independent 4-byte stores.  off[] = running global position
+        // of every bucket; cnt[] / cstart[] = this chunk's counts and their exclusive scan (reusing hist[] and wsum[]).
+        uint32_t* cnt = hist;
+        __shared__ uint32_t cstart[BINS];
+        uint32_t* stage_val = stage;
+        uint32_t* stage_bin = stage + CHUNK;
+        static_assert(2 * CHUNK <= (uint32_t)SORTB_CAP, "chunk staging must fit the fast path's stage buffer");
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
             uint64_t x[SORTB_UNROLL];
+            uint32_t rk[SORTB_UNROLL];
+            if (tid < BINS) cnt[tid] = 0;
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < SORTB_UNROLL; u++) {
                 const uint32_t q = q0 + u * 1024 + tid;
@@ -462,11 +473,41 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
                 x[u] = q < len ? v : ~0ull;
             }
 #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
-                const bool on = x[u] != ~0ull;
-                const uint32_t pos = lds_take(off, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, on);
-                if (on) svals[pb + pos] = (uint32_t)x[u];
+            for (int u = 0; u < SORTB_UNROLL; u++) rk[u] = lds_take(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
+            __syncthreads();
+            { // exclusive scan of this chunk's counts
+                const uint32_t c = tid < BINS ? cnt[tid] : 0u;
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d);
+                    if ((tid & 63) >= d) incl += t;
+                }
+                if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t before = 0;
+                for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
+                if (tid < BINS) cstart[tid] = before + incl - c;
             }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) {
+                if (x[u] != ~0ull) {
+                    const uint32_t b = (uint32_t)(x[u] >> 32) & SORT_LO_MASK;
+                    const uint32_t slot = cstart[b] + rk[u];
+                    stage_val[slot] = (uint32_t)x[u];
+                    stage_bin[slot] = b;
+                }
+            }
+            __syncthreads();
+            const uint32_t chunk_len = len - q0 < CHUNK ? len - q0 : CHUNK;
+            for (uint32_t slot = tid; slot < chunk_len; slot += 1024) {
+                const uint32_t b = stage_bin[slot];
+                svals[pb + off[b] + (slot - cstart[b])] = stage_val[slot];
+            }
+            __syncthreads();
+            if (tid < BINS) off[tid] += cnt[tid];
+            __syncthreads();
         }
     }
 }
