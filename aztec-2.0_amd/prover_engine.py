@@ -112,3 +112,31 @@ class Round34Engine(Round4Engine):
         b._ck(b.lib.bbg_dev_upload(b.ctx, ctypes.c_void_p(z.data_ptr() + (n - 3) * 32), bl.ctypes.data, 96))
         b.ntt_device(z.data_ptr(), log2n, binding.IFFT)
         b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(z_ptr), ctypes.c_void_p(z.data_ptr()), n * 32))
+
+
+class ResidentEngine(Round34Engine):
+    """+ the coset FFTs of the work queue stay ON THE DEVICE: with rounds 3 and 4 computed there, nothing on the host reads the
+    4n-point "*_fft" arrays any more, so the FFT work item neither downloads its 128 MiB result nor is it uploaded again for the
+    quotient.  (The host arrays are left untouched: only valid together with round4_raw.)"""
+
+    def __init__(self, bbg, srs):
+        import torch
+        super().__init__(bbg, srs)
+        self._fft = {}  # host address of a wire_fft array -> device tensor holding its 4n + 4 values
+        # this engine mixes torch kernels (zero fill, slice copy) with library kernels on the same buffers: one stream for both
+        bbg.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def fft_item_raw(self, wire, log2n, wire_fft, log2_domain):
+        import torch
+        b = self.bbg
+        n, m = 1 << log2n, 1 << log2_domain
+        t = torch.zeros((m + 4) * 4, dtype=torch.int64, device="cuda")
+        b._ck(b.lib.bbg_dev_upload(b.ctx, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(wire), n * 32))
+        b.ntt_device(t.data_ptr(), log2_domain, binding.COSET_FFT, n)
+        t[m * 4:] = t[:16]  # add_lagrange_base_coefficient x4: the first four values again at 4n .. 4n+3
+        self._fft[wire_fft] = t
+
+    def _upload(self, host_ptr, count):
+        if host_ptr in self._fft and self._fft[host_ptr].numel() >= count * 4:
+            return self._fft.pop(host_ptr)  # produced on the device by fft_item_raw: no transfer
+        return super()._upload(host_ptr, count)

@@ -705,6 +705,14 @@ def test_reference_prover_linked_against_shim(pkg, oracle, bbg):
     proof = P.prove()  # engine=None: the reference's own process_queue -> __wrap_* -> libbbg.so
     assert len(proof) > 0 and P.verify() == 1
     P.free()
+    # the same shim-linked prover with the work queue through the callbacks, rounds 3 and 4 on the device and the coset FFT
+    # outputs kept resident for the quotient (prover_engine.ResidentEngine): the fastest configuration measured
+    P = RefProver(1 << 13, 12, pts, x, gpu_linked=True)
+    srs = bbg.srs_register(P.monomials())
+    proof = P.prove(pkg.prover_engine.ResidentEngine(bbg, srs), check=False)  # (per-item check needs the host copies)
+    assert len(proof) > 0 and P.verify() == 1
+    srs.free()
+    P.free()
 
 
 def test_reference_prover_round4_on_gpu(pkg, oracle, bbg):
