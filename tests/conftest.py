@@ -52,6 +52,10 @@ def kats():
 def bbg(pkg):
     """GPU context through the C ABI.  Fails loudly (no fallback) when the extension or the GPU is missing."""
     ctx = pkg.Bbg(0)
+    # several tests stage device buffers with torch (zeros, clones) and then hand them to the library: run both on torch's
+    # current stream so that a torch fill can never race a library kernel on the same buffer
+    import torch
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     yield ctx
     ctx.close()
 
