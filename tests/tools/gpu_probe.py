@@ -16,6 +16,8 @@ from oracle.oracle import Oracle  # noqa: E402
 stages = sys.argv[1:] or ["field", "ntt", "msm", "time"]
 O = Oracle()
 B = pkg.Bbg(0)
+import torch  # noqa: E402
+B.set_stream(torch.cuda.current_stream().cuda_stream)  # torch fills and library kernels share one stream
 inp = pkg.inputs
 
 
