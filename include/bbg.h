@@ -53,7 +53,9 @@ int bbg_join(bbg_ctx* ctx);
 /* Like bbg_join but leaves the `lag` most recent reductions outstanding (lag = 1: wait for everything except the
  * MSM issued last) -- lets a caller consume result i-1 while MSM i is still reducing. */
 int bbg_join_lag(bbg_ctx* ctx, int lag);
-/* Use a caller-owned HIP stream (hipStream_t passed as void*; e.g. torch.cuda.current_stream().cuda_stream). */
+/* Use a caller-owned HIP stream (hipStream_t passed as void*; e.g. torch.cuda.current_stream().cuda_stream).  Every *_device
+ * entry point enqueues on the context stream and returns; a caller that fills or reads those device buffers on ANOTHER stream
+ * (a framework's memset, a copy) must order the two itself -- sharing one stream through this call is the simple way. */
 int bbg_set_stream(bbg_ctx* ctx, void* hip_stream);
 
 /* ---- SRS: replaces scalar_multiplication::Pippenger (ecc/curves/bn254/scalar_multiplication/pippenger.hpp:35-52,
