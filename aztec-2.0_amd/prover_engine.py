@@ -114,7 +114,42 @@ class Round34Engine(Round4Engine):
         b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(z_ptr), ctypes.c_void_p(z.data_ptr()), n * 32))
 
 
-class ResidentEngine(Round34Engine):
+class Round346Engine(Round34Engine):
+    """+ the two opening polynomials of execute_sixth_round / KateCommitmentScheme::batch_open (kate_commitment_scheme.cpp:133-236):
+    F = t_low + sum nu_k P_k (bbg_poly_linear_combination_device), W = (F - F(z)) / (X - z) (bbg_kate_opening_device).  Selector and
+    permutation polynomials (coefficient form) are resident per proving key; wires, z, the quotient parts and r(X) go up per proof."""
+
+    def __init__(self, bbg, srs):
+        super().__init__(bbg, srs)
+        self._coeff = {}
+
+    def _resident(self, host_ptr, n):
+        """Device copy of a coefficient-form polynomial; cached by (address, leading 256 bytes) for the per-key ones."""
+        fp = (host_ptr, ctypes.string_at(host_ptr, 256))
+        t = self._coeff.get(fp)
+        if t is None:
+            if len(self._coeff) > 64:
+                self._coeff.clear()
+            t = self._coeff[fp] = Round4Engine._upload(self, host_ptr, n)
+        return t
+
+    def round6_raw(self, polys_zeta, scalars_zeta, base, polys_omega, scalars_omega, zeta, zeta_omega, n, w_zeta, w_zeta_omega):
+        import torch
+        b = self.bbg
+        dz = [self._resident(p, n) for p in polys_zeta]
+        do = [self._resident(p, n) for p in polys_omega]
+        dbase = Round4Engine._upload(self, base, n)
+        f = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        w = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+        b.poly_linear_combination_device([t.data_ptr() for t in dz], scalars_zeta, dbase.data_ptr(), f.data_ptr(), n)
+        b.kate_opening_device(f.data_ptr(), w.data_ptr(), n, zeta)
+        b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(w_zeta), ctypes.c_void_p(w.data_ptr()), n * 32))
+        b.poly_linear_combination_device([t.data_ptr() for t in do], scalars_omega, None, f.data_ptr(), n)
+        b.kate_opening_device(f.data_ptr(), w.data_ptr(), n, zeta_omega)
+        b._ck(b.lib.bbg_dev_download(b.ctx, ctypes.c_void_p(w_zeta_omega), ctypes.c_void_p(w.data_ptr()), n * 32))
+
+
+class ResidentEngine(Round346Engine):
     """+ the coset FFTs of the work queue stay ON THE DEVICE: with rounds 3 and 4 computed there, nothing on the host reads the
     4n-point "*_fft" arrays any more, so the FFT work item neither downloads its 128 MiB result nor is it uploaded again for the
     quotient.  (The host arrays are left untouched: only valid together with round4_raw.)"""

@@ -496,6 +496,9 @@ class RefProver:
     FFT_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p)
     IFFT_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
     FFT_ITEM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    OPENING_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p)
 
     def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False):
         if not prover_available() or (gpu_linked and not os.path.exists(PROVER_GPU_SO)):
@@ -585,6 +588,8 @@ class RefProver:
                 self._round3_with(engine)
             elif k == 4 and engine is not None and hasattr(engine, "round4_raw"):
                 self._round4_with(engine, check)
+            elif k == 6 and engine is not None and hasattr(engine, "round6_raw"):
+                self._round6_with(engine)
             else:
                 self.lib.refp_execute_round(self.h, k)
             t1 = time.perf_counter()
@@ -626,6 +631,24 @@ class RefProver:
         engine.round3_raw([int(p) for p in wires], [int(p) for p in sigmas], ch, blind, log2n, z.value)
         if L.refp_round3_end(self.h) != 0:
             raise RuntimeError("refp_round3_end failed")
+
+    def _round6_with(self, engine):
+        """execute_sixth_round with the opening polynomials (accumulation + Kate division) computed by the engine."""
+        L = self.lib
+        L.refp_round6_with.argtypes = [vp, self.OPENING_CB, vp]; L.refp_round6_with.restype = cint
+
+        def cb(pz, sz_, cz, base, po, so, co, zeta, zeta_omega, n, wz, wzo, _user):
+            def ptrs(arr, cnt):
+                return [int(v) for v in ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p * cnt)).contents] if cnt else []
+
+            def limbs(ptr, cnt):
+                return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint64)), shape=(cnt, 4)).copy()
+            engine.round6_raw(ptrs(pz, cz), limbs(sz_, cz), base, ptrs(po, co), limbs(so, co), limbs(zeta, 1)[0], limbs(zeta_omega, 1)[0],
+                              n, wz, wzo)
+
+        keep = self.OPENING_CB(cb)
+        if L.refp_round6_with(self.h, keep, None) != 0:
+            raise RuntimeError("refp_round6_with failed")
 
     def _round4_with(self, engine, check):
         """execute_fourth_round with the quotient (widgets + divide_by_pseudo_vanishing + coset_ifft) computed by the engine."""

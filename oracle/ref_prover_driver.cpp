@@ -633,3 +633,61 @@ int refp_round3_end(void* h)
     }
 }
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 6 through the prover's public members (prover.cpp:380-386 + KateCommitmentScheme::batch_open,
+// kate_commitment_scheme.cpp:133-236): Fiat-Shamir "nu", then the two opening polynomials
+//     F(X)  = t_low(X) + sum_k nu_k P_k(X) + zeta^n t_mid + zeta^2n t_high + zeta^3n t_higher + nu_r r(X)       -> W_zeta       = (F - F(zeta)) / (X - zeta)
+//     F'(X) = sum_k nu'_k P'_k(X)  over the polynomials with a shifted evaluation                              -> W_zeta_omega
+// whose accumulation and Kate division are delegated; the commitments to W_zeta / W_zeta_omega are queued as the reference
+// does ("PI_Z", "PI_Z_OMEGA").  TurboPLONK settings (4 wires, linearisation on).
+extern "C" {
+typedef void (*refp_opening_cb)(const uint64_t* const* polys_zeta, const uint64_t* scalars_zeta, size_t count_zeta, const uint64_t* base,
+                                const uint64_t* const* polys_omega, const uint64_t* scalars_omega, size_t count_omega,
+                                const uint64_t* zeta, const uint64_t* zeta_omega, size_t n, uint64_t* w_zeta, uint64_t* w_zeta_omega, void* user);
+int refp_round6_with(void* h, refp_opening_cb cb, void* user)
+{
+    try {
+        auto* s = (Session*)h;
+        auto& p = *s->prover;
+        auto* key = p.key.get();
+        auto* witness = p.witness.get();
+        p.queue.flush_queue();
+        p.transcript.apply_fiat_shamir("nu");
+        const size_t n = key->n;
+        std::vector<const uint64_t*> at_zeta, at_omega;
+        std::vector<fr> nu_zeta, nu_omega;
+        for (const auto& info : key->polynomial_manifest) {
+            const std::string label(info.polynomial_label);
+            fr* poly = nullptr;
+            if (info.source == waffle::PolynomialSource::WITNESS) poly = &witness->wires.at(label)[0];
+            else if (info.source == waffle::PolynomialSource::SELECTOR) poly = &key->constraint_selectors.at(label)[0];
+            else poly = &key->permutation_selectors.at(label)[0];
+            if (!info.is_linearised) { // turbo_settings::use_linearisation: linearised polynomials enter through r(X) only
+                at_zeta.push_back((const uint64_t*)poly);
+                nu_zeta.push_back(p.transcript.get_challenge_field_element_from_map("nu", label));
+            }
+            if (info.requires_shifted_evaluation) {
+                at_omega.push_back((const uint64_t*)poly);
+                nu_omega.push_back(p.transcript.get_challenge_field_element_from_map("nu", label + "_omega"));
+            }
+        }
+        const fr zeta = p.transcript.get_challenge_field_element("z");
+        for (size_t i = 1; i < 4; ++i) { // t_mid, t_high, t_higher with zeta^(i n); t_low is the base of the sum
+            at_zeta.push_back((const uint64_t*)&key->quotient_large[i * n]);
+            nu_zeta.push_back(zeta.pow(static_cast<uint64_t>(i * n)));
+        }
+        at_zeta.push_back((const uint64_t*)&key->linear_poly[0]);
+        nu_zeta.push_back(p.transcript.get_challenge_field_element_from_map("nu", "r"));
+        const fr zeta_omega = zeta * key->small_domain.root;
+        cb(at_zeta.data(), (const uint64_t*)nu_zeta.data(), at_zeta.size(), (const uint64_t*)&key->quotient_large[0], at_omega.data(),
+           (const uint64_t*)nu_omega.data(), at_omega.size(), (const uint64_t*)&zeta, (const uint64_t*)&zeta_omega, n,
+           (uint64_t*)&key->opening_poly[0], (uint64_t*)&key->shifted_opening_poly[0], user);
+        p.queue.add_to_queue({ waffle::work_queue::WorkType::SCALAR_MULTIPLICATION, &key->opening_poly[0], "PI_Z", fr(0), 0 });
+        p.queue.add_to_queue({ waffle::work_queue::WorkType::SCALAR_MULTIPLICATION, &key->shifted_opening_poly[0], "PI_Z_OMEGA", fr(0), 0 });
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+} // extern "C"

@@ -725,7 +725,8 @@ def test_reference_prover_round4_on_gpu(pkg, oracle, bbg):
     x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
     P = RefProver(1 << 12, 13, oracle.srs_powers(x, (2 << 12) + 1), x)
     srs = bbg.srs_register(P.monomials())
-    proof = P.prove(pkg.prover_engine.Round34Engine(bbg, srs), check=True)  # + round 3's z (grand product, blinding, ifft)
+    # + round 3's z (grand product, blinding, ifft) and round 6's opening polynomials (accumulation + Kate division)
+    proof = P.prove(pkg.prover_engine.Round346Engine(bbg, srs), check=True)
     assert P.round4_mismatch == 0 and P.mismatches == 0
     assert len(proof) > 0 and P.verify() == 1
     srs.free()

@@ -75,7 +75,7 @@ def main():
            "mismatching_items": P.mismatches if args.check else None}
     # + round 4's quotient (five widgets, divide_by_pseudo_vanishing, coset_ifft) on the device; selectors resident per key
     P4 = RefProver(gates, 11, pts, x)
-    eng4 = pkg.prover_engine.Round34Engine(bbg, srs)
+    eng4 = pkg.prover_engine.Round346Engine(bbg, srs)
     P4.prove(eng4, check=False)  # warm-up proof: uploads the per-key arrays
     P4.free()
     P4 = RefProver(gates, 11, pts, x)
@@ -97,7 +97,7 @@ def main():
         PL.prove()
         t_l = time.perf_counter() - t0
         # shim-linked prover (queue + inline helpers through --wrap) AND round 4 taken over by the engine
-        eng5 = pkg.prover_engine.Round34Engine(bbg, None)
+        eng5 = pkg.prover_engine.Round346Engine(bbg, None)
         eng5.queue_via_reference = True
         PB = RefProver(gates, 11, pts, x, gpu_linked=True)
         PB.prove(eng5, check=False)  # warm-up: uploads the per-key arrays
@@ -126,7 +126,7 @@ def main():
         PL.free()
     out = {"workload": f"reference TurboProver, arithmetic circuit, n = 2^{args.log2n} gates after padding",
            "host_threads": P.threads, "srs_setup_s": round(t_srs, 2),
-           "cpu_engine": cpu, "gpu_engine": gpu, "gpu_engine_plus_rounds34": gpu4, "gpu_shim_linked": linked, "gpu_shim_linked_plus_rounds34": both, "gpu_shim_linked_rounds34_resident_ffts": resident, "proof_bytes": len(proof_gpu),
+           "cpu_engine": cpu, "gpu_engine": gpu, "gpu_engine_plus_rounds346": gpu4, "gpu_shim_linked": linked, "gpu_shim_linked_plus_rounds346": both, "gpu_shim_linked_rounds346_resident_ffts": resident, "proof_bytes": len(proof_gpu),
            "verified": {"cpu": ok_cpu == 1, "gpu": ok_gpu == 1},
            "queue_speedup": round(cpu["queue_ms"] / max(gpu["queue_ms"], 1e-9), 1),
            "end_to_end_speedup": round(cpu["total_ms"] / max(gpu["total_ms"], 1e-9), 2)}
