@@ -138,6 +138,44 @@ class BbgNttOps:
     def cross_dft(self, d_in, d_out, log2g, length, log2n, inverse):
         self.bbg.cross_dft_device(d_in.data_ptr(), d_out.data_ptr(), log2g, length, log2n, inverse)
 
+    def coset_fft_shift(self, d_x, log2m, shift):
+        self.bbg.ntt_device(d_x.data_ptr(), log2m, 6, 0, shift)  # BBG_COSET_FFT_WITH_GENERATOR_SHIFT
+
+
+def coset_fft_split_sharded(ops, dist, x, log2n, ext):
+    """The prover's 4n-point coset FFT of a polynomial with only n non-zero coefficients (large_domain.generator_size = n,
+    SURVEY.md 8e row 3; reference polynomial_arithmetic.cpp:401-456 and the WASM SMALL_FFT items, work_queue.hpp:166-199):
+    ext fully independent size-n coset FFTs with shifts g * w_{ext n}^k, k < ext -- NO arithmetic exchange between ranks.
+
+    In : every rank holds the same n = 2^log2n coefficients x (int64 tensor of 4*n words; not modified).
+    Out: every rank holds the ext*n interleaved evaluations, out[ext*i + k] = Y_k[i]  (what coset_fft(coeffs, small, large, ext) leaves).
+    Rank g computes the cosets k = g, g + G, ... ; one all-gather of the results; the interleave is a local copy.
+    ops.coset_fft_shift(d_x, log2n, shift) = coset_fft_with_generator_shift in place."""
+    import torch
+    G = dist.get_world_size() if dist is not None else 1
+    g = dist.get_rank() if dist is not None else 0
+    if ext % G:
+        raise ValueError("the number of cosets must be a multiple of the world size")
+    n = 1 << log2n
+    log2ext = ext.bit_length() - 1
+    if (1 << log2ext) != ext or x.numel() != 4 * n:
+        raise ValueError("ext must be a power of two and x must hold n elements")
+    per = ext // G
+    local = x.new_empty((per, 4 * n))
+    for j in range(per):
+        k = g + G * j
+        local[j].copy_(x)
+        ops.coset_fft_shift(local[j], log2n, ops.root_pow(log2n + log2ext, k, False))
+    if G > 1:
+        flat = x.new_empty((G * per, 4 * n))  # rank-major concatenation along dim 0
+        dist.all_gather_into_tensor(flat, local)
+        gathered = flat.view(G, per, 4 * n)
+    else:
+        gathered = local.view(1, per, 4 * n)
+    # gathered[g, j] = Y_{g + G j}  ->  out[i, k] with k = g + G j
+    y = gathered.permute(1, 0, 2).reshape(ext, n, 4)  # index k = j*G + g
+    return y.permute(1, 0, 2).contiguous().view(-1)
+
 
 def ntt_sharded(ops, dist, x_local, log2n, inverse=False, coset_shift=None, new_like=None):
     """One size-n = 2^log2n (coset) NTT over G = world ranks (G a power of two <= 8, G^2 | n).

@@ -86,6 +86,8 @@ class CpuNttOps:
         if inverse: w = O.fe_inv(0, w)[0]
         return self._pow(w, e)
     def fr_pow(self, base, e): return self._pow(base, e)
+    def coset_fft_shift(self, t, log2m, shift):
+        a = self._np(t); a[:] = O.ntt(a.copy(), 6, 0, np.array(shift, dtype=np.uint64))
     def cross_dft(self, tin, tout, log2g, length, log2n, inverse):
         Gn = 1 << log2g
         a, o = self._np(tin).reshape(Gn, length, 4), self._np(tout).reshape(Gn, length, 4)
@@ -108,6 +110,13 @@ for inverse, shift, op in ((False, None, 0), (True, None, 1), (False, five, 2)):
     for t_ in range(world):
         for q_ in range(lenq):
             assert np.array_equal(got[t_, q_], whole[(rank * lenq + q_) + mm * t_]), ("sharded ntt", op, t_, q_)
+# the prover's 4n coset FFT with n non-zero coefficients: ext independent size-n coset FFTs, no arithmetic exchange (8e row 3)
+for lg6, ext in ((6, 4), (5, 8), (6, 2)):
+    c6 = O.canon(0, pkg.synthetic_scalars(778 + ext, 1 << lg6))
+    xt = torch.from_numpy(c6.copy().view(np.int64).reshape(-1))
+    res = par.coset_fft_split_sharded(CpuNttOps(), dist, xt, lg6, ext)
+    want = O.coset_fft_split(c6, ext)
+    assert np.array_equal(O.canon(0, res.numpy().view(np.uint64).reshape(-1, 4)), O.canon(0, want)), ("coset split sharded", lg6, ext)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

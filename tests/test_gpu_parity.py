@@ -563,6 +563,22 @@ def test_permutation_grand_product_in_a_real_proof(pkg, oracle, bbg):
     P.free()
 
 
+def test_coset_fft_split_sharded_device_ops(pkg, oracle, bbg):
+    """parallel.coset_fft_split_sharded with the real device ops on one rank (the multi-rank exchange -- a plain all-gather -- is
+    covered by the gloo test): ext independent coset FFTs with generator shifts g * w_{ext n}^k, interleaved, equal the
+    reference's coset_fft(coeffs, small, large, ext) as restated by the oracle."""
+    import importlib
+    import torch
+    par = importlib.import_module("aztec_amd.parallel")
+    for lg, ext in ((10, 4), (12, 8), (11, 2)):
+        c = oracle.canon(0, pkg.synthetic_scalars(1200 + lg, 1 << lg))
+        x = torch.from_numpy(c.copy().view(np.int64).reshape(-1)).cuda()
+        out = par.coset_fft_split_sharded(par.BbgNttOps(bbg), None, x, lg, ext)
+        bbg.sync()
+        got = oracle.canon(0, out.cpu().numpy().view(np.uint64).reshape(-1, 4))
+        assert np.array_equal(got, oracle.canon(0, oracle.coset_fft_split(c, ext))), (lg, ext)
+
+
 # ---------------------------------------------------------------------------------------------- quotient widgets (8f-2)
 def _widget_inputs(pkg, m):
     from oracle.oracle import RefWidgets
