@@ -719,14 +719,25 @@ def test_reference_prover_linked_against_shim(pkg, oracle, bbg):
     pts = oracle.srs_powers(x, (2 << 13) + 1)
     P = RefProver(1 << 13, 12, pts, x, gpu_linked=True)
     proof = P.prove()  # engine=None: the reference's own process_queue -> __wrap_* -> libbbg.so
-    assert len(proof) > 0 and P.verify() == 1
+    ok = P.verify()
+    assert len(proof) > 0 and ok == 1, ("shim-linked", len(proof), ok)
     P.free()
-    # the same shim-linked prover with the work queue through the callbacks, rounds 3 and 4 on the device and the coset FFT
-    # outputs kept resident for the quotient (prover_engine.ResidentEngine): the fastest configuration measured
+
+
+def test_reference_prover_resident_engine(pkg, oracle, bbg):
+    """The fastest configuration measured (profiles/r01_real_prover.txt): the shim-linked prover (inline helpers through --wrap),
+    the work queue through the callbacks, rounds 3, 4 and 6 on the device and the coset-FFT outputs kept resident for the
+    quotient (prover_engine.ResidentEngine).  The reference's TurboVerifier must accept the proof."""
+    from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
+    if not prover_available() or not os.path.exists(PROVER_GPU_SO):
+        pytest.skip("oracle/_ref/libbbprover_gpu.so absent on this machine")
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    pts = oracle.srs_powers(x, (2 << 13) + 1)
     P = RefProver(1 << 13, 12, pts, x, gpu_linked=True)
     srs = bbg.srs_register(P.monomials())
     proof = P.prove(pkg.prover_engine.ResidentEngine(bbg, srs), check=False)  # (per-item check needs the host copies)
-    assert len(proof) > 0 and P.verify() == 1
+    ok = P.verify()
+    assert len(proof) > 0 and ok == 1, ("resident engine", len(proof), ok, P.counts)
     srs.free()
     P.free()
 
