@@ -519,7 +519,7 @@ class RefProver:
         L.refp_set_threads.argtypes = [cint]
         L.refp_max_threads.restype = cint
         # small circuits: cap the reference's OpenMP team (see refp_set_threads in ref_prover_driver.cpp)
-        self.threads = min(os.cpu_count() or 1, 16 if num_gates < (1 << 17) else 64)
+        self.threads = min(os.cpu_count() or 1, 8 if num_gates < (1 << 15) else 16 if num_gates < (1 << 17) else 64)
         L.refp_set_threads(self.threads)
         pts = _arr(points, 8)
         x = np.ascontiguousarray(x_mont, dtype=np.uint64)
