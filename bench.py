@@ -228,6 +228,8 @@ def cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, gpu_val
     points = srs.read()
     if ref_available():
         ref = Ref()
+        if lg < 18:  # the reference's CPU pippenger is unsafe with a large OpenMP team on small inputs
+            ref.set_threads(min(os.cpu_count() or 1, 16))
         ctx = ref.msm(points)
         best = 1e9
         for _ in range(2):

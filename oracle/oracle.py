@@ -301,6 +301,10 @@ class Ref:
 
     def num_threads(self): return int(self.lib.ref_num_threads())
 
+    def set_threads(self, n):
+        self.lib.ref_set_threads.argtypes = [cint]
+        self.lib.ref_set_threads(int(n))
+
     def fe_op(self, which, op, a, b=None):
         a = _arr(a, 4)
         r = np.empty_like(a)

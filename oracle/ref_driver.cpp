@@ -91,9 +91,14 @@ struct NttCtx {
 };
 } // namespace
 
+#include <omp.h>
+
 extern "C" {
 
 int ref_num_threads() { return (int)max_threads::compute_num_threads(); }
+// OpenMP team size of everything the reference runs afterwards.  Its compute_wnaf_states misbehaves when the team is large
+// relative to the input (SIGSEGV seen with 128 threads at n = 2^14), so callers cap it for small inputs.
+void ref_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
 
 // op: 0 mul 1 add 2 sub 3 invert 4 to_mont 5 from_mont 6 sqr ; which: 0 Fr 1 Fq
 void ref_fe_op(int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* r, size_t n)
