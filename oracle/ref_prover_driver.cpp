@@ -691,3 +691,19 @@ int refp_round6_with(void* h, refp_opening_cb cb, void* user)
     }
 }
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Diagnostics for the shim-linked build: polynomial_arithmetic::evaluate as the prover sees it (wrapped -> GPU) against the
+// reference's own body (__real_...), on caller-supplied coefficients.  Returns 1 if equal, 0 if not, -1 if this build has no wrap.
+namespace barretenberg { namespace polynomial_arithmetic {
+fr real_evaluate_for_diag(const fr* coeffs, const fr& z, const size_t n)
+    asm("__real__ZN12barretenberg21polynomial_arithmetic8evaluateEPKNS_5fieldINS_13Bn254FrParamsEEERS4_m") __attribute__((weak));
+} }
+extern "C" int refp_diag_evaluate(const uint64_t* coeffs, size_t n, const uint64_t* z)
+{
+    if (!barretenberg::polynomial_arithmetic::real_evaluate_for_diag) return -1;
+    fr zz{ z[0], z[1], z[2], z[3] };
+    fr a = polynomial_arithmetic::evaluate((const fr*)coeffs, zz, n);
+    fr b = barretenberg::polynomial_arithmetic::real_evaluate_for_diag((const fr*)coeffs, zz, n);
+    return a == b ? 1 : 0;
+}

@@ -25,6 +25,9 @@
 // FFTs are in place on coeffs[domain.size]; `pippenger_runtime_state` is accepted and ignored (the scratch arena lives
 // on the device); a failing call throws std::runtime_error like throw_or_abort (common/throw_or_abort.hpp:5-13).
 #include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -49,6 +52,16 @@ struct ShimState {
         const g1::affine_element* base;
         size_t n;
         bbg_srs* srs;
+        // The cache is keyed by the table's ADDRESS, so an entry must notice when that table has been freed and its memory
+        // reused (a later, different table may start inside the old range): 64 evenly spaced points are remembered at
+        // registration and compared with host memory on every lookup (4 KiB of memcmp); any difference drops the entry.
+        std::vector<std::pair<size_t, g1::affine_element>> samples;
+        bool still_valid() const
+        {
+            for (const auto& sm : samples)
+                if (std::memcmp((const void*)&base[2 * sm.first], (const void*)&sm.second, sizeof(g1::affine_element)) != 0) return false;
+            return true;
+        }
     };
     std::map<const g1::affine_element*, Entry> tables; // keyed by table base pointer (get_monomials() identity)
     ~ShimState()
@@ -83,19 +96,29 @@ bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t&
         --it;
         ShimState::Entry& e = it->second;
         const size_t off = (size_t)(points - e.base);
-        if (off % 2 == 0 && off / 2 + num_points <= e.n) {
-            from = off / 2;
-            return e.srs;
-        }
-        if (off == 0) { // same table, longer prefix requested: re-register
+        const bool inside = off < 2 * e.n;
+        if (inside && !e.still_valid()) { // the table this entry described is gone: forget it
             bbg_srs_free(e.srs);
             s.tables.erase(it);
+        } else {
+            if (off % 2 == 0 && off / 2 + num_points <= e.n) {
+                from = off / 2;
+                return e.srs;
+            }
+            if (off == 0) { // same table, longer prefix requested: re-register
+                bbg_srs_free(e.srs);
+                s.tables.erase(it);
+            }
         }
     }
     bbg_srs* srs = nullptr;
     if (bbg_srs_register(ctx, reinterpret_cast<const uint64_t*>(points), num_points, sizeof(g1::affine_element) * 2, &srs) != BBG_OK)
         fail("bbg_srs_register");
-    s.tables[points] = ShimState::Entry{ points, num_points, srs };
+    ShimState::Entry entry{ points, num_points, srs, {} };
+    const size_t step = num_points > 64 ? num_points / 64 : 1;
+    for (size_t i = 0; i < num_points; i += step) entry.samples.emplace_back(i, points[2 * i]);
+    entry.samples.emplace_back(num_points - 1, points[2 * (num_points - 1)]);
+    s.tables[points] = std::move(entry);
     from = 0;
     return srs;
 }
