@@ -20,6 +20,13 @@ import numpy as np
 from . import binding
 
 
+def _fingerprint(host_ptr, count):
+    """64 bytes at each of 16 evenly spaced elements of a host array of `count` field elements: recognises an array that has
+    already been uploaded (per proving key) without hashing the whole thing, and notices reused memory."""
+    step = max(count // 16, 1)
+    return b"".join(ctypes.string_at(host_ptr + 32 * i, 64) for i in range(0, max(count - 1, 1), step))
+
+
 class WorkQueueEngine:
     """MSM / coset FFT / iFFT items through the host entry points (the FFT item as copy + coset_fft + 4 appended values on the
     prover's side, exactly as work_queue::process_queue does it)."""
@@ -70,8 +77,8 @@ class Round4Engine(FusedFftEngine):
         b = self.bbg
         m = 4 << log2n
         # sigma_1..4, q_*, L_1 on the coset are fixed per proving key (= per circuit): uploaded once and recognised by a
-        # fingerprint of their leading 256 bytes, the way an SRS is registered once
-        key = (log2n,) + tuple(ctypes.string_at(p, 256) for p in poly_ptrs[5:])
+        # sampled fingerprint, the way an SRS is registered once
+        key = (log2n,) + tuple(_fingerprint(p, m) for p in poly_ptrs[5:])
         if key not in self._static:
             self._static = {key: [self._upload(p, m) for p in poly_ptrs[5:]]}
         wires = [self._upload(p, m) for p in poly_ptrs[:5]]  # w_1..4, z: new for every proof
@@ -99,7 +106,7 @@ class Round34Engine(Round4Engine):
         import torch
         b = self.bbg
         n = 1 << log2n
-        key = (log2n,) + tuple(ctypes.string_at(p, 256) for p in sigma_ptrs)
+        key = (log2n,) + tuple(_fingerprint(p, n) for p in sigma_ptrs)
         if key not in self._sigma:
             self._sigma = {key: [self._upload(p, n) for p in sigma_ptrs]}
         wires = [self._upload(p, n) for p in wire_ptrs]
@@ -125,7 +132,7 @@ class Round346Engine(Round34Engine):
 
     def _resident(self, host_ptr, n):
         """Device copy of a coefficient-form polynomial; cached by (address, leading 256 bytes) for the per-key ones."""
-        fp = (host_ptr, ctypes.string_at(host_ptr, 256))
+        fp = (host_ptr, _fingerprint(host_ptr, n))
         t = self._coeff.get(fp)
         if t is None:
             if len(self._coeff) > 64:
