@@ -336,6 +336,29 @@ class Bbg:
                                                   out.ctypes.data))
         return out
 
+    # host-buffer forms (what the C++ shim binds evaluate / compute_kate_opening_coefficients / divide_by_pseudo_vanishing_polynomial to)
+    def poly_evaluate(self, coeffs, z):
+        a = _u64(coeffs, 4)
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.bbg_poly_evaluate(self.ctx, a.ctypes.data, a.shape[0], zz.ctypes.data, out.ctypes.data))
+        return out
+
+    def kate_opening(self, src, z, in_place=False):
+        """Returns (dest, F(z)); in_place=True passes dest == src the way KateCommitmentScheme::batch_open does."""
+        a = _u64(src, 4).copy()
+        d = a if in_place else np.empty_like(a)
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        f = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.bbg_kate_opening(self.ctx, a.ctypes.data, d.ctypes.data, a.shape[0], zz.ctypes.data, f.ctypes.data))
+        return d, f
+
+    def divide_by_pseudo_vanishing(self, evals, log2_src, num_roots_cut=4):
+        a = _u64(evals, 4).copy()
+        log2_target = a.shape[0].bit_length() - 1
+        self._ck(self.lib.bbg_divide_by_pseudo_vanishing(self.ctx, a.ctypes.data, log2_src, log2_target, num_roots_cut))
+        return a
+
     def divide_by_pseudo_vanishing_device(self, d_evals, log2_src, log2_target, num_roots_cut=4):
         self._ck(self.lib.bbg_divide_by_pseudo_vanishing_device(self.ctx, ctypes.c_void_p(d_evals), log2_src, log2_target, num_roots_cut))
 

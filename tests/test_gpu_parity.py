@@ -890,6 +890,17 @@ def test_poly_helpers_vs_reference_golden(pkg, oracle, bbg, golden):
         assert sha(oracle.canon(0, host(e, n))) == rec["sha256"], rec
     with pytest.raises(pkg.BbgError):
         bbg.divide_by_pseudo_vanishing_device(1, 10, 8, 4)
+    # the host-buffer forms the shim binds (upload, compute, download), incl. the in-place Kate call of batch_open
+    for n in (1, 17, 4097, 70000):
+        a_np = pkg.synthetic_scalars(40 + n, n)
+        assert np.array_equal(bbg.poly_evaluate(a_np, kc), oracle.poly_eval(a_np, kc)), n
+        want_d, want_f = oracle.kate_opening(a_np, kc)
+        for in_place in (False, True):
+            d, f = bbg.kate_opening(a_np, kc, in_place=in_place)
+            assert np.array_equal(f, want_f) and np.array_equal(oracle.canon(0, d), want_d), (n, in_place)
+    for rec in golden["poly"]["dpv"][:3]:
+        e = pkg.synthetic_scalars(rec["seed"], 1 << rec["log2_target"])
+        assert sha(oracle.canon(0, bbg.divide_by_pseudo_vanishing(e, rec["log2_src"], rec["cut"]))) == rec["sha256"], rec
 
 
 def test_quotient_identity_full_size(pkg, oracle, bbg):
