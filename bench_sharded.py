@@ -21,6 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one JSON line on stdout: native libraries (RCCL) print to fd 1 behind Python's back, so fd 1 is pointed at stderr for the run
+REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
 
 
 def main():
@@ -91,10 +94,11 @@ def main():
     t_msm = timed(msm_step)
     t_ntt = timed(ntt_step)
     if rank == 0:
-        print(json.dumps({"workload": "one 2^%d MSM + one 2^%d coset-NTT sharded over %d GPUs (strong scaling)" % (lg, lg, world),
+        sys.stdout.flush()
+        os.write(REAL_STDOUT, (json.dumps({"workload": "one 2^%d MSM + one 2^%d coset-NTT sharded over %d GPUs (strong scaling)" % (lg, lg, world),
                           "n_gpus": world, "msm_ms": round(t_msm * 1e3, 3), "msm_mscalar_per_s": round(n / t_msm / 1e6, 2),
                           "ntt_ms": round(t_ntt * 1e3, 3), "ntt_gfield_ops_per_s": round(1.5 * n * lg / t_ntt / 1e9, 2),
-                          "exchange": {"msm": "all_gather %d x 96 B" % world, "ntt": "all_to_all %.1f MiB per rank" % (32.0 * m * (world - 1) / world / 2**20)}}))
+                          "exchange": {"msm": "all_gather %d x 96 B" % world, "ntt": "all_to_all %.1f MiB per rank" % (32.0 * m * (world - 1) / world / 2**20)}}) + "\n").encode())
     srs.free()
     bbg.close()
     dist.destroy_process_group()
