@@ -316,3 +316,51 @@ def test_quotient_widgets_oracle_vs_reference_golden(oracle):
             qc = oracle.canon(0, quot)
             assert np.array_equal(qc[:2], unhex(rec["quotient_first2"], 4)), rec["widget"]
             assert sha(qc) == rec["quotient_sha256"], rec["widget"]
+
+
+def test_quotient_widgets_and_grand_product_oracle_vs_reference_live(oracle):
+    """Where the reference build is present: the oracle's widget restatement against the reference's widget OBJECTS on fresh
+    seeds (TurboPLONK five + StandardPLONK pair), and oracle_permutation_z against the z of a real proof's round 3."""
+    import ctypes
+    from oracle.oracle import RefProver, RefWidgets, prover_available
+    import __graft_entry__ as ge
+    if not prover_available():
+        pytest.skip("oracle/_ref/libbbprover.so absent (built from /root/reference by `make -C oracle prover`)")
+    pkg = ge.load_package()
+    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    n = 1 << 8
+    pts = oracle.srs_powers(x, n + 1)
+    P = RefProver(n - 24, 21, pts, x)
+    for standard, order in ((None, ((0, 0), (1, 1), (2, 2), (3, 3), (4, 4))), ((n - 24, pts, x), ((0, 5), (1, 6)))):
+        W = RefWidgets(P, standard=standard)
+        m = W.m
+        polys = [pkg.synthetic_scalars(31337 + 7 * k, m) for k in range(len(RefWidgets.LABELS))]
+        for label, a in zip(RefWidgets.LABELS, polys):
+            if W.has_poly(label):
+                W.set_poly(label, a)
+        ch = W.challenges()
+        ch9 = np.stack([ch[0], ch[0], ch[1], ch[2], ch[3], ch[7], ch[4], ch[5], ch[6]])
+        quot = np.zeros((m, 4), dtype=np.uint64)
+        alpha_ref = alpha_or = ch[0]
+        for ref_widget, lib_widget in order:
+            alpha_ref = W.run(ref_widget, alpha_ref)
+            c = ch9.copy()
+            c[0] = alpha_or
+            alpha_or = oracle.quotient_widget(lib_widget, polys, m.bit_length() - 1, c, quot)
+            assert np.array_equal(alpha_or, oracle.canon(0, alpha_ref.reshape(1, 4))[0]), lib_widget
+            assert np.array_equal(oracle.canon(0, quot), oracle.canon(0, W.get_poly("quotient_large", m))), lib_widget
+        W.free()
+    # round 3 of a real proof: rows 0 .. n-4 of the reference's z
+    for k in range(3):
+        P.lib.refp_execute_round(P.h, k)
+        P.lib.refp_process_queue_reference(P.h)
+    wires = np.zeros((4, n, 4), dtype=np.uint64)
+    sigmas = np.zeros((4, n, 4), dtype=np.uint64)
+    ch5 = np.zeros((5, 4), dtype=np.uint64)
+    zref = np.zeros((n, 4), dtype=np.uint64)
+    P.lib.refp_round3_probe.restype = ctypes.c_int
+    assert P.lib.refp_round3_probe(ctypes.c_void_p(P.h), ctypes.c_void_p(wires.ctypes.data), ctypes.c_void_p(sigmas.ctypes.data),
+                                   ctypes.c_void_p(ch5.ctypes.data), ctypes.c_void_p(zref.ctypes.data)) == 0
+    got = oracle.permutation_z(wires, sigmas, ch5[0], ch5[1], ch5[2:5])
+    assert np.array_equal(got[: n - 3], oracle.canon(0, zref)[: n - 3])
+    P.free()
