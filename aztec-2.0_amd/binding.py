@@ -62,6 +62,8 @@ def load_library():
         "bbg_srs_synth_linear": (cint, [vp, ctypes.c_uint64, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
         "bbg_srs_synth_hashed": (cint, [vp, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
         "bbg_srs_load_transcript": (cint, [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_write_transcript": (cint, [vp, ctypes.c_char_p, sz, vp]),
+        "bbg_transcript_checksum": (cint, [vp, sz, vp]),
         "bbg_srs_num_points": (sz, [vp]),
         "bbg_srs_read": (cint, [vp, sz, sz, vp]),
         "bbg_srs_free": (None, [vp]),
@@ -98,6 +100,17 @@ def load_library():
         "bbg_field_op": (cint, [vp, cint, cint, vp, vp, vp, sz]),
         "bbg_profile_enable": (cint, [vp, cint]),
         "bbg_profile_get": (cint, [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]),
+        "bbg_prover_create": (cint, [vp, vp, ctypes.c_uint, cint, vp, ctypes.POINTER(vp)]),
+        "bbg_prover_destroy": (None, [vp]),
+        "bbg_prover_set_key_poly": (cint, [vp, cint, cint, vp]),
+        "bbg_prover_finalize_key": (cint, [vp]),
+        "bbg_prover_round1": (cint, [vp, vp, vp]),
+        "bbg_prover_round3": (cint, [vp, vp, vp, vp, vp]),
+        "bbg_prover_round4": (cint, [vp, vp, vp, vp]),
+        "bbg_prover_evaluate": (cint, [vp, sz, vp, vp, vp, vp]),
+        "bbg_prover_linearise": (cint, [vp, sz, vp, vp, vp, vp]),
+        "bbg_prover_round6": (cint, [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
+        "bbg_prover_read_poly": (cint, [vp, cint, cint, vp, sz]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here == a symbol declared in bbg.h is not exported
@@ -115,6 +128,9 @@ EXPORTED_SYMBOLS = [
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
+    "bbg_srs_write_transcript", "bbg_transcript_checksum",
+    "bbg_prover_create", "bbg_prover_destroy", "bbg_prover_set_key_poly", "bbg_prover_finalize_key", "bbg_prover_round1", "bbg_prover_round3",
+    "bbg_prover_round4", "bbg_prover_evaluate", "bbg_prover_linearise", "bbg_prover_round6", "bbg_prover_read_poly",
 ]
 
 
@@ -140,6 +156,11 @@ class Srs:
         out = np.empty((count, 8), dtype=np.uint64)
         self._owner._ck(self._owner.lib.bbg_srs_read(self.handle, start, count, out.ctypes.data))
         return out
+
+    def write_transcript(self, directory, points_per_file=0, g2_x_raw=None):
+        """Ignition-format files directory/transcriptNN.dat holding points 1 .. n-1 (bbg_srs_write_transcript)."""
+        g2 = None if g2_x_raw is None else ctypes.create_string_buffer(bytes(g2_x_raw), 128)
+        self._owner._ck(self._owner.lib.bbg_srs_write_transcript(self.handle, str(directory).encode(), points_per_file, g2))
 
     def free(self):
         if self.handle:

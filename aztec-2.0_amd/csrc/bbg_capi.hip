@@ -396,6 +396,145 @@ int bbg_srs_load_transcript(bbg_ctx* ctx, const char* dir, size_t num_points, bb
     return rc;
 }
 
+// BLAKE2b-512 (RFC 7693, unkeyed), the checksum an Ignition transcript carries after its points (srs/io.cpp:21-29 accounts for its
+// 64 bytes; the reference reader skips it).  Host-side byte hashing, no field arithmetic.
+namespace {
+struct Blake2b {
+    uint64_t h[8], t = 0;
+    uint8_t buf[128];
+    size_t fill = 0;
+    static uint64_t rotr(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
+    Blake2b()
+    {
+        static const uint64_t IV[8] = { 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                        0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL };
+        for (int i = 0; i < 8; i++) h[i] = IV[i];
+        h[0] ^= 0x01010040ULL; // digest length 64, no key, fanout 1, depth 1
+    }
+    void compress(const uint8_t* block, bool last)
+    {
+        static const uint64_t IV[8] = { 0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                        0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL };
+        static const uint8_t SIGMA[12][16] = {
+            { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 }, { 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3 },
+            { 11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4 }, { 7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8 },
+            { 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13 }, { 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9 },
+            { 12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11 }, { 13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10 },
+            { 6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5 }, { 10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0 },
+            { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 }, { 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3 } };
+        uint64_t m[16], v[16];
+        memcpy(m, block, 128); // little-endian host
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= t;
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];     v[b] = rotr(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t* sg = SIGMA[r];
+            G(0, 4, 8, 12, m[sg[0]], m[sg[1]]);   G(1, 5, 9, 13, m[sg[2]], m[sg[3]]);
+            G(2, 6, 10, 14, m[sg[4]], m[sg[5]]);  G(3, 7, 11, 15, m[sg[6]], m[sg[7]]);
+            G(0, 5, 10, 15, m[sg[8]], m[sg[9]]);  G(1, 6, 11, 12, m[sg[10]], m[sg[11]]);
+            G(2, 7, 8, 13, m[sg[12]], m[sg[13]]); G(3, 4, 9, 14, m[sg[14]], m[sg[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void update(const void* data, size_t len)
+    {
+        const uint8_t* p = (const uint8_t*)data;
+        while (len) {
+            if (fill == 128) { // only compress a full buffer when more input follows: the last block is flagged
+                t += 128;
+                compress(buf, false);
+                fill = 0;
+            }
+            const size_t take = std::min(len, (size_t)128 - fill);
+            memcpy(buf + fill, p, take);
+            fill += take;
+            p += take;
+            len -= take;
+        }
+    }
+    void final(uint8_t out[64])
+    {
+        t += fill;
+        memset(buf + fill, 0, 128 - fill);
+        compress(buf, true);
+        memcpy(out, h, 64);
+    }
+};
+} // namespace
+
+// the checksum of a transcript file body (host only: usable without a GPU, e.g. to validate a downloaded transcript)
+int bbg_transcript_checksum(const void* data, size_t len, uint8_t out[64])
+{
+    if ((!data && len) || !out) { set_error("bbg_transcript_checksum: null argument"); return BBG_E_INVALID; }
+    Blake2b hash;
+    hash.update(data, len);
+    hash.final(out);
+    return BBG_OK;
+}
+
+// Ignition transcript WRITER, the inverse of bbg_srs_load_transcript / io::read_transcript_g1 (srs/io.cpp:11-45 manifest, :47-67 point
+// encoding, :123-162 file sequence): files dir/transcript00.dat, 01, ... hold points 1 .. n-1 of the SRS (point 0 is the generator,
+// which every reader supplies itself, :137), points_per_file each (0 = all in one file).  Each point is x || y, every 8-byte limb
+// big-endian, limbs least-significant first, values in standard (non-Montgomery) form -- the conversion runs on the device.
+// g2_x_raw (may be NULL): 128 bytes appended to file 00 as its single G2 point, written as given.  The 64-byte BLAKE2b-512 checksum
+// of everything before it closes each file.
+int bbg_srs_write_transcript(bbg_srs* srs, const char* dir, size_t points_per_file, const uint8_t* g2_x_raw)
+{
+    if (!srs || !dir) { set_error("bbg_srs_write_transcript: null argument"); return BBG_E_INVALID; }
+    CHECK_CTX(srs->ctx);
+    const size_t n = srs->s.n;
+    if (n < 2) { set_error("bbg_srs_write_transcript: nothing to write (an SRS of fewer than 2 points)"); return BBG_E_INVALID; }
+    const size_t total = n - 1;
+    if (points_per_file == 0 || points_per_file > total) points_per_file = total;
+    const size_t files = (total + points_per_file - 1) / points_per_file;
+    if (files > 100) { set_error("bbg_srs_write_transcript: more than 100 files (transcriptNN.dat)"); return BBG_E_INVALID; }
+    std::vector<uint64_t> plain(total * 8);
+    {
+        std::lock_guard<std::mutex> lk(srs->ctx->mu);
+        void* d_plain = nullptr;
+        BBG_HIP(hipMalloc(&d_plain, total * 64));
+        int rc = field_op_device(1, 4 /* from_montgomery */, (const char*)srs->s.points + 64, nullptr, d_plain, total * 2, srs->ctx->stream);
+        hipError_t e = hipSuccess;
+        if (rc == BBG_OK) e = hipMemcpyAsync(plain.data(), d_plain, total * 64, hipMemcpyDeviceToHost, srs->ctx->stream);
+        if (rc == BBG_OK && e == hipSuccess) e = hipStreamSynchronize(srs->ctx->stream);
+        (void)hipFree(d_plain);
+        if (rc) return rc;
+        if (e != hipSuccess) return hip_fail(e, "transcript download", __FILE__, __LINE__);
+    }
+    for (auto& limb : plain) limb = __builtin_bswap64(limb);
+    auto be32 = [](uint8_t* out, uint32_t v) { out[0] = (uint8_t)(v >> 24); out[1] = (uint8_t)(v >> 16); out[2] = (uint8_t)(v >> 8); out[3] = (uint8_t)v; };
+    for (size_t k = 0; k < files; k++) {
+        const size_t first = k * points_per_file, count = std::min(points_per_file, total - first);
+        const uint32_t num_g2 = (k == 0 && g2_x_raw) ? 1 : 0;
+        uint8_t manifest[28];
+        const uint32_t fields[7] = { (uint32_t)k, (uint32_t)files, (uint32_t)total, g2_x_raw ? 1u : 0u, (uint32_t)count, num_g2, (uint32_t)first };
+        for (int i = 0; i < 7; i++) be32(manifest + 4 * i, fields[i]);
+        Blake2b hash;
+        hash.update(manifest, 28);
+        hash.update(&plain[first * 8], count * 64);
+        if (num_g2) hash.update(g2_x_raw, 128);
+        uint8_t digest[64];
+        hash.final(digest);
+        char name[64];
+        snprintf(name, sizeof(name), "/transcript%02zu.dat", k);
+        const std::string path = std::string(dir) + name;
+        std::ofstream f(path, std::ofstream::binary | std::ofstream::trunc);
+        if (!f.good()) { set_error("bbg_srs_write_transcript: cannot open " + path); return BBG_E_INVALID; }
+        f.write((const char*)manifest, 28);
+        f.write((const char*)&plain[first * 8], (std::streamsize)(count * 64));
+        if (num_g2) f.write((const char*)g2_x_raw, 128);
+        f.write((const char*)digest, 64);
+        if (!f.good()) { set_error("bbg_srs_write_transcript: short write to " + path); return BBG_E_INVALID; }
+    }
+    return BBG_OK;
+}
+
 size_t bbg_srs_num_points(const bbg_srs* srs) { return srs ? srs->s.n : 0; }
 
 int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points)
@@ -410,7 +549,7 @@ int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points)
 void bbg_srs_free(bbg_srs* srs)
 {
     if (!srs) return;
-    (void)hipSetDevice(srs->ctx->device);
+    (void)hipSetDevice(srs->s.device); // the handle's own record: the context may already be gone (bbg_destroy before bbg_srs_free)
     (void)hipDeviceSynchronize();
     if (srs->s.table16) (void)hipFree(srs->s.table16);
     if (srs->s.table20) (void)hipFree(srs->s.table20);

@@ -86,6 +86,7 @@ struct bbg_ctx {
     unsigned long msm_seq = 0;
     size_t msm_layout_n = 0; // (n, window width) of the layout the scratch arena currently holds: a change of either moves
     int msm_layout_c = 0;    // every region, so pending reduce phases are joined first (msm_run_c)
+    int msm_layout_sort = 1; // (the sort path is part of the layout: the library-sort path reserves rocPRIM's temporary storage)
     bool msm_async_reduce = false;
     void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
     size_t gp_totals_bytes = 0;
@@ -97,6 +98,7 @@ struct bbg_ctx {
     int ntt_max_logr = 7;
     int ntt_kernel = 2;      // 2 = k_ntt_pass8 where applicable (n >= 2^11), 1 = k_ntt_pass only
     int ntt_max_logr8 = 10;  // max log-radix per pass for k_ntt_pass8
+    bool ntt_attr8_set = false, ntt_attr_set = false; // dynamic-LDS attributes of the pass kernels set on this context's device
 };
 
 struct bbg_srs {

@@ -882,16 +882,18 @@ static uint32_t msm_seg_len(size_t entries, size_t buckets)
     return (uint32_t)seg;
 }
 
-template <int C> static int msm_layout(size_t n, MsmLayout& L)
+template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L)
 {
     using K = MsmCfg<C>;
     L.entries = n * K::windows;
     L.seg = msm_seg_len(L.entries, K::buckets);
     L.lanes = (L.entries + L.seg - 1) / L.seg;
     size_t tmp = 0;
-    rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)C);
-    if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs(size query)", __FILE__, __LINE__);
+    if (library_sort) { // only the A/B path (msm_sort = 0) needs rocPRIM's temporary storage: the default path neither queries nor reserves it
+        rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)C);
+        if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs(size query)", __FILE__, __LINE__);
+    }
     L.sort_bytes = tmp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -961,7 +963,7 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
 {
     using K = MsmCfg<C>;
     MsmLayout L;
-    int rc = msm_layout<C>(n, L);
+    int rc = msm_layout<C>(n, ctx->msm_sort == 0, L);
     if (rc) return rc;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
@@ -972,13 +974,14 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
             BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
         }
     }
-    if (ctx->msm_layout_n != n || ctx->msm_layout_c != C) {
+    if (ctx->msm_layout_n != n || ctx->msm_layout_c != C || ctx->msm_layout_sort != ctx->msm_sort) {
         // a different (n, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
         // regions this call is about to overwrite, so the main stream first waits for both slots (no host sync)
         for (int k = 0; k < 2; k++)
             if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
         ctx->msm_layout_n = n;
         ctx->msm_layout_c = C;
+        ctx->msm_layout_sort = ctx->msm_sort;
     }
     const int slot = (int)(ctx->msm_seq++ & 1);
     char* base = (char*)ctx->msm.buf;
@@ -1097,7 +1100,11 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
             return hip_fail(e, "hipMalloc(SRS window tables)", __FILE__, __LINE__);
         }
         int rc = srs_build_tables(srs.points, srs.n, table, c, st);
-        if (rc) return rc;
+        if (rc) { // never keep a table whose contents were not built: later MSMs of this width would read garbage
+            (void)hipFree(table);
+            table = nullptr;
+            return rc;
+        }
     }
     if (c == 20) return msm_run_c<20>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st);
     return msm_run_c<16>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st);

@@ -22,6 +22,8 @@
 // Roofline note: one Fr multiplication is ~136 v_mad_u64_u32; the pass kernels are integer-ALU bound,
 // not HBM bound -- the 64n algorithmic bytes cross HBM p (2..3) times plus one twiddle-table read.
 #include "bbg_internal.h"
+
+#include <cstring>
 #include "field.hip.h"
 #include "ntt_consts.hip.h"
 
@@ -78,6 +80,19 @@ __global__ void k_domain_init(DomainConsts* c, unsigned log2n)
         a = fe_reduce_once(fe_sqr(a));
         b = fe_reduce_once(fe_sqr(b));
     }
+}
+
+// *dst = v: small host constants reach the device as kernel arguments, never through an asynchronous copy out of the caller's
+// (pageable) memory, which the caller could reuse or free before the copy has run
+__global__ void k_set_fr(Fr* dst, Fr v)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+static Fr fr_arg(const uint64_t* limbs)
+{
+    Fr v;
+    memcpy(&v, limbs, 32);
+    return v;
 }
 
 // pow2[b] = base^(2^b)
@@ -477,7 +492,7 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     const size_t lds_bytes = ((size_t)2 * W * (R + 1) + R) * 16 + 64;
     const size_t tiles = ((size_t)1 << d.log2n) >> (p.logR + p.logW);
     if (d.use_pass8) {
-        static bool attr8 = false;
+        bool& attr8 = ctx->ntt_attr8_set; // hipFuncSetAttribute is per device: the flag lives in the context, not in a process-wide static
         if (!attr8) {
             BBG_HIP(p8_attr<3>()); BBG_HIP(p8_attr<4>()); BBG_HIP(p8_attr<5>()); BBG_HIP(p8_attr<6>()); BBG_HIP(p8_attr<7>());
             BBG_HIP(p8_attr<8>()); BBG_HIP(p8_attr<9>()); BBG_HIP(p8_attr<10>()); BBG_HIP(p8_attr<11>());
@@ -498,7 +513,7 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
         }
         return BBG_OK;
     }
-    static bool attr_set = false;
+    bool& attr_set = ctx->ntt_attr_set;
     if (!attr_set) {
         BBG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -524,10 +539,10 @@ static int ntt_core(bbg_ctx* ctx, NttDomain& d, Fr* a, int inverse, const Fr* po
     if (rc) return rc;
     Fr* scratch = (Fr*)ctx->ntt_scratch;
     // pass 0: a -> scratch (same positions); middle passes in place on scratch; last pass scratch -> a (transposing)
-    launch_pass(ctx, d, 0, inverse, a, scratch, nullptr, st);
-    for (int q = 1; q < d.passes - 1; q++) launch_pass(ctx, d, q, inverse, scratch, scratch, nullptr, st);
-    launch_pass(ctx, d, d.passes - 1, inverse, scratch, a, post, st);
-    return BBG_OK;
+    rc = launch_pass(ctx, d, 0, inverse, a, scratch, nullptr, st);
+    for (int q = 1; q < d.passes - 1 && !rc; q++) rc = launch_pass(ctx, d, q, inverse, scratch, scratch, nullptr, st);
+    if (!rc) rc = launch_pass(ctx, d, d.passes - 1, inverse, scratch, a, post, st);
+    return rc;
 }
 
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
@@ -548,7 +563,7 @@ int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generat
     Fr* cst = nullptr;
     if (constant) {
         cst = &dc->constant;
-        BBG_HIP(hipMemcpyAsync(cst, constant, 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_set_fr, dim3(1), dim3(1), 0, st, cst, fr_arg(constant));
     }
     switch (op) {
     case BBG_FFT:
@@ -695,8 +710,8 @@ int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* star
     int rc = build_domain(ctx, 0, &dp); // the size-1 domain only lends its scratch constants block
     if (rc) return rc;
     DomainConsts* dc = (DomainConsts*)dp->consts;
-    BBG_HIP(hipMemcpyAsync(&dc->gk, base, 32, hipMemcpyHostToDevice, st));
-    if (start) BBG_HIP(hipMemcpyAsync(&dc->constant, start, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_set_fr, dim3(1), dim3(1), 0, st, &dc->gk, fr_arg(base));
+    if (start) hipLaunchKernelGGL(k_set_fr, dim3(1), dim3(1), 0, st, &dc->constant, fr_arg(start));
     hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, (const Fr*)&dc->gk, (const Fr*)nullptr);
     hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((count + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d_a, dc->pow2_tmp,
                        start ? (const Fr*)&dc->constant : (const Fr*)nullptr, count);
@@ -724,7 +739,7 @@ int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hi
     int rc = build_domain(ctx, 0, &dp);
     if (rc) return rc;
     DomainConsts* dc = (DomainConsts*)dp->consts;
-    BBG_HIP(hipMemcpyAsync(&dc->constant, base, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_set_fr, dim3(1), dim3(1), 0, st, &dc->constant, fr_arg(base));
     hipLaunchKernelGGL(k_fr_pow, dim3(1), dim3(64), 0, st, &dc->gk, (const Fr*)&dc->constant, e);
     BBG_HIP(hipMemcpyAsync(out, &dc->gk, 32, hipMemcpyDeviceToHost, st));
     BBG_HIP(hipStreamSynchronize(st));

@@ -77,23 +77,54 @@ int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t cou
 }
 
 // ---------------------------------------------------------------------------------------------- shared pieces
-constexpr int PV_E = 16;     // consecutive coefficients per thread
+constexpr int PV_E = 16;     // consecutive coefficients per thread (Kate quotient, division by Z*_H)
 constexpr int PV_LOG_E = 4;
+constexpr int EV_CHUNK = 4096; // coefficients per block of the evaluation kernels (256 threads x 16, lane-interleaved)
+constexpr int MEV_MAX = 32;    // polynomials per multi-evaluation call
 struct PolyScratch {
-    Fr z;          // staged evaluation point
+    Fr z;          // evaluation point
     Fr pow2z[48];  // z^(2^b)
     Fr result;     // F(z)
     Fr tmp[8];
+    Fr ztid[256];  // z^t, t < 256
 };
-
-__global__ void k_poly_pow2(PolyScratch* s)
+constexpr int DPV_MAX_EXT = 16, DPV_MAX_CUT = 8;
+struct DpvConsts {
+    Fr inv_sub[DPV_MAX_EXT]; // 1 / ((g w_ext^j)^n - 1)
+    Fr numer[DPV_MAX_CUT];   // -w_src^-(k+1)
+};
+// context scratch: two evaluation points (zeta, zeta * w), the Z*_H constants, MEV_MAX results, then the partial sums
+struct PolyHeader {
+    PolyScratch ps[2];
+    DpvConsts dpv;
+    Fr results[MEV_MAX];
+};
+static int poly_scratch(bbg_ctx* ctx, size_t partials, PolyHeader** hdr, Fr** part)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Fr a = fe_reduce_once(fe_reduce_once(s->z));
-    for (int i = 0; i < 48; i++) {
-        s->pow2z[i] = a;
-        a = fe_reduce_once(fe_sqr(a));
+    const size_t head = (sizeof(PolyHeader) + 255) / 256 * 256;
+    int rc = ensure_buffer(&ctx->poly_scratch, &ctx->poly_scratch_bytes, head + (partials + 2) * sizeof(Fr));
+    if (rc) return rc;
+    *hdr = (PolyHeader*)ctx->poly_scratch;
+    if (part) *part = (Fr*)((char*)ctx->poly_scratch + head);
+    return BBG_OK;
+}
+
+// z arrives BY VALUE (kernel argument): no pageable-memory copy whose source the caller could reuse before it ran.
+// mul_root != null: the point is z * (*mul_root) (the shifted evaluations at zeta * w of round 5).
+__global__ void __launch_bounds__(256) k_poly_pow2(PolyScratch* s, Fr z, const Fr* mul_root)
+{
+    if (threadIdx.x == 0) {
+        Fr a = fe_reduce_once(fe_reduce_once(z));
+        if (mul_root) a = fe_reduce_once(fe_mul(a, *mul_root));
+        s->z = a;
+        for (int i = 0; i < 48; i++) {
+            s->pow2z[i] = a;
+            a = fe_reduce_once(fe_sqr(a));
+        }
     }
+    __threadfence_block();
+    __syncthreads();
+    s->ztid[threadIdx.x] = fe_reduce_once(pow_from_table(s->pow2z, (uint64_t)threadIdx.x));
 }
 // LDS tree sum of one field element per thread (256 threads); result valid in thread 0
 __device__ Fr block_sum(Fr v, Fr* sm)
@@ -120,52 +151,140 @@ __device__ __forceinline__ Fr slice_horner(const Fr* __restrict__ c, size_t i0, 
 }
 
 // ---------------------------------------------------------------------------------------------- evaluate
-// block partial = sum over the block's 256 slices of S_t * z^(i0_t)
+// A block owns EV_CHUNK consecutive coefficients; lane t takes c[base + t + 256 e], e < 16 -- every load instruction of a wave
+// reads 2 KiB of consecutive memory -- and sums them by Horner in z^256; the lane results are weighted by z^t (table) and
+// tree-summed, the block result by z^base.  One product per coefficient: multiplier and HBM are balanced.
+__device__ __forceinline__ Fr chunk_eval(const Fr* __restrict__ c, size_t n, size_t base, const PolyScratch* ps, Fr* sm)
+{
+    const int tid = threadIdx.x;
+    const Fr z256 = ps->pow2z[8];
+    Fr s = Fr::zero();
+#pragma unroll 4
+    for (int e = EV_CHUNK / 256 - 1; e >= 0; e--) {
+        s = fe_mul(s, z256);
+        const size_t i = base + (size_t)e * 256 + tid;
+        if (i < n) s = fe_add(s, fe_load<FrP>(c + i));
+    }
+    s = fe_mul(s, ps->ztid[tid]);
+    s = block_sum(s, sm);
+    if (tid == 0) s = fe_mul(s, pow_from_table(ps->pow2z, base));
+    return s;
+}
 __global__ void __launch_bounds__(256) k_eval_partial(const Fr* __restrict__ c, size_t n, const PolyScratch* ps, Fr* partials)
 {
     __shared__ Fr sm[128];
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t i0 = t * PV_E;
-    Fr s = Fr::zero();
-    if (i0 < n) s = fe_mul(slice_horner(c, i0, n, ps->pow2z[0]), pow_from_table(ps->pow2z, i0));
-    s = block_sum(s, sm);
+    const Fr s = chunk_eval(c, n, (size_t)blockIdx.x * EV_CHUNK, ps, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-__global__ void __launch_bounds__(256) k_eval_final(const Fr* __restrict__ partials, size_t count, PolyScratch* ps)
+__global__ void __launch_bounds__(256) k_eval_final(const Fr* __restrict__ partials, size_t count, Fr* result)
 {
     __shared__ Fr sm[128];
     Fr s = Fr::zero();
     for (size_t i = threadIdx.x; i < count; i += 256) s = fe_add(s, partials[i]);
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) ps->result = fe_reduce_once(s);
+    if (threadIdx.x == 0) *result = fe_reduce_once(s);
+}
+// several polynomials, each at one of two points (zeta, zeta * w), in one launch: grid = (blocks of the longest, count)
+struct MultiEvalArgs {
+    const Fr* poly[MEV_MAX];
+    size_t len[MEV_MAX];
+    int point[MEV_MAX];
+    size_t stride; // partials per polynomial
+};
+__global__ void __launch_bounds__(256) k_multi_eval_partial(MultiEvalArgs a, const PolyScratch* ps, Fr* partials)
+{
+    __shared__ Fr sm[128];
+    const int k = blockIdx.y;
+    const size_t base = (size_t)blockIdx.x * EV_CHUNK;
+    if (base >= a.len[k]) { // uniform per block
+        if (threadIdx.x == 0) partials[k * a.stride + blockIdx.x] = Fr::zero();
+        return;
+    }
+    const Fr s = chunk_eval(a.poly[k], a.len[k], base, ps + a.point[k], sm);
+    if (threadIdx.x == 0) partials[k * a.stride + blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_multi_eval_final(const Fr* __restrict__ partials, size_t stride, Fr* results)
+{
+    __shared__ Fr sm[128];
+    const Fr* p = partials + (size_t)blockIdx.x * stride;
+    Fr s = Fr::zero();
+    for (size_t i = threadIdx.x; i < stride; i += 256) s = fe_add(s, p[i]);
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) results[blockIdx.x] = fe_reduce_once(s);
 }
 
-static int poly_setup(bbg_ctx* ctx, size_t n, const uint64_t* z, PolyScratch** ps, Fr** partials, size_t* nblocks, hipStream_t st)
+static Fr fr_from_host(const uint64_t* limbs)
 {
-    const size_t slices = (n + PV_E - 1) / PV_E;
-    *nblocks = (slices + 255) / 256;
-    const size_t need = sizeof(PolyScratch) + 256 + (*nblocks + 1) * 2 * sizeof(Fr);
-    int rc = ensure_buffer(&ctx->poly_scratch, &ctx->poly_scratch_bytes, need);
+    Fr z;
+    memcpy(&z, limbs, 32);
+    return z;
+}
+static int poly_setup(bbg_ctx* ctx, size_t n, const uint64_t* z, PolyHeader** hdr, Fr** partials, size_t* nblocks, hipStream_t st)
+{
+    // partial sums: one per EV_CHUNK coefficients (evaluation) and one per 256 slices (Kate block totals + carries)
+    *nblocks = ((n + PV_E - 1) / PV_E + 255) / 256;
+    int rc = poly_scratch(ctx, 2 * (*nblocks + 1), hdr, partials);
     if (rc) return rc;
-    *ps = (PolyScratch*)ctx->poly_scratch;
-    *partials = (Fr*)((char*)ctx->poly_scratch + ((sizeof(PolyScratch) + 255) / 256) * 256);
-    BBG_HIP(hipMemcpyAsync(&(*ps)->z, z, 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(64), 0, st, *ps);
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &(*hdr)->ps[0], fr_from_host(z), (const Fr*)nullptr);
     return BBG_OK;
+}
+
+// F(z) into *d_result (device), asynchronous
+static void eval_async(const Fr* d_coeffs, size_t n, const PolyScratch* ps, Fr* partials, Fr* d_result, hipStream_t st)
+{
+    const size_t blocks = (n + EV_CHUNK - 1) / EV_CHUNK;
+    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, st, d_coeffs, n, ps, partials);
+    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, (const Fr*)partials, blocks ? blocks : 1, d_result);
 }
 
 int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* z, uint64_t* out, hipStream_t st)
 {
     if ((!d_coeffs && n) || !z || !out) { set_error("bbg_poly_evaluate: null argument"); return BBG_E_INVALID; }
-    PolyScratch* ps;
+    PolyHeader* hdr;
     Fr* partials;
     size_t nblocks;
-    int rc = poly_setup(ctx, n ? n : 1, z, &ps, &partials, &nblocks, st);
+    int rc = poly_setup(ctx, n ? n : 1, z, &hdr, &partials, &nblocks, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_coeffs, n, ps, partials);
-    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, partials, nblocks, ps);
-    BBG_HIP(hipMemcpyAsync(out, &ps->result, 32, hipMemcpyDeviceToHost, st));
+    eval_async((const Fr*)d_coeffs, n, &hdr->ps[0], partials, &hdr->ps[0].result, st);
+    BBG_HIP(hipMemcpyAsync(out, &hdr->ps[0].result, 32, hipMemcpyDeviceToHost, st));
     BBG_HIP(hipStreamSynchronize(st));
+    return BBG_OK;
+}
+
+// count polynomials (device arrays of len[k] coefficients), polynomial k at zeta (shifted[k] == 0) or at zeta * w_n (the root of
+// the 2^log2n domain; the shifted evaluations of add_opening_evaluations_to_transcript, kate_commitment_scheme.cpp:375-420);
+// results (canonical Montgomery) to d_results[count] on the device, asynchronous.
+int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* lens, const int* shifted, size_t count, unsigned log2n,
+                        const uint64_t* zeta, void** d_results, hipStream_t st)
+{
+    if (count == 0 || count > (size_t)MEV_MAX || !d_polys || !lens || !zeta || !d_results) {
+        set_error("poly_multi_evaluate: bad argument (1..32 polynomials)");
+        return BBG_E_INVALID;
+    }
+    size_t longest = 1;
+    MultiEvalArgs a;
+    for (size_t k = 0; k < count; k++) {
+        if (!d_polys[k]) { set_error("poly_multi_evaluate: null polynomial"); return BBG_E_INVALID; }
+        a.poly[k] = (const Fr*)d_polys[k];
+        a.len[k] = lens[k];
+        a.point[k] = shifted && shifted[k] ? 1 : 0;
+        if (lens[k] > longest) longest = lens[k];
+    }
+    a.stride = (longest + EV_CHUNK - 1) / EV_CHUNK;
+    void* dc = nullptr;
+    int rc = ntt_domain_consts(ctx, log2n, &dc);
+    if (rc) return rc;
+    PolyHeader* hdr;
+    Fr* partials;
+    rc = poly_scratch(ctx, a.stride * count, &hdr, &partials);
+    if (rc) return rc;
+    const Fr z = fr_from_host(zeta);
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[0], z, (const Fr*)nullptr);
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[1], z, (const Fr*)&((const DomainConsts*)dc)->root);
+    hipLaunchKernelGGL(k_multi_eval_partial, dim3((unsigned)a.stride, (unsigned)count), dim3(256), 0, st, a, (const PolyScratch*)hdr->ps, partials);
+    hipLaunchKernelGGL(k_multi_eval_final, dim3((unsigned)count), dim3(256), 0, st, (const Fr*)partials, a.stride, hdr->results);
+    BBG_HIP(hipGetLastError());
+    *d_results = hdr->results;
     return BBG_OK;
 }
 
@@ -255,35 +374,39 @@ __global__ void __launch_bounds__(256) k_kate_finish(const Fr* __restrict__ f, F
     }
 }
 
-int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st)
+// asynchronous core: W(X) into d_dest, F(z) into *d_f (device; may be null).  d_dest must not alias d_src.
+int poly_kate_opening_async(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, void* d_f, hipStream_t st)
 {
-    if (!d_src || !d_dest || !z || !f_out || n == 0) { set_error("bbg_kate_opening: bad argument"); return BBG_E_INVALID; }
+    if (!d_src || !d_dest || !z || n == 0) { set_error("bbg_kate_opening: bad argument"); return BBG_E_INVALID; }
     if (d_src == d_dest) { set_error("bbg_kate_opening: src and dest must differ"); return BBG_E_INVALID; }
-    PolyScratch* ps;
+    PolyHeader* hdr;
     Fr* partials;
     size_t nblocks;
-    int rc = poly_setup(ctx, n, z, &ps, &partials, &nblocks, st);
+    int rc = poly_setup(ctx, n, z, &hdr, &partials, &nblocks, st);
     if (rc) return rc;
+    PolyScratch* ps = &hdr->ps[0];
     Fr* carry = partials + nblocks + 1;
     // F(z)
-    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, n, ps, partials);
-    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, partials, nblocks, ps);
-    BBG_HIP(hipMemcpyAsync(f_out, &ps->result, 32, hipMemcpyDeviceToHost, st));
+    eval_async((const Fr*)d_src, n, ps, partials, &ps->result, st);
+    if (d_f) BBG_HIP(hipMemcpyAsync(d_f, &ps->result, 32, hipMemcpyDeviceToDevice, st));
     // W(X)
     hipLaunchKernelGGL(k_kate_block_totals, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, n, ps, partials);
     hipLaunchKernelGGL(k_kate_block_scan, dim3(1), dim3(256), 0, st, partials, nblocks, ps, carry);
     hipLaunchKernelGGL(k_kate_finish, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, (Fr*)d_dest, n, ps, carry);
     BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st)
+{
+    if (!f_out) { set_error("bbg_kate_opening: bad argument"); return BBG_E_INVALID; }
+    int rc = poly_kate_opening_async(ctx, d_src, d_dest, n, z, nullptr, st);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(f_out, &((PolyHeader*)ctx->poly_scratch)->ps[0].result, 32, hipMemcpyDeviceToHost, st));
     BBG_HIP(hipStreamSynchronize(st));
     return BBG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- divide by Z*_H
-constexpr int DPV_MAX_EXT = 16, DPV_MAX_CUT = 8;
-struct DpvConsts {
-    Fr inv_sub[DPV_MAX_EXT]; // 1 / ((g w_ext^j)^n - 1)
-    Fr numer[DPV_MAX_CUT];   // -w_src^-(k+1)
-};
 __device__ Fr fr_inv_fermat(Fr a)
 {
     uint32_t e[8];
@@ -343,9 +466,10 @@ int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src,
     if (!rc) rc = ntt_domain_consts(ctx, log2_target, &ctgt);
     if (!rc) rc = ntt_domain_consts(ctx, log2_target - log2_src, &cext);
     if (rc) return rc;
-    rc = ensure_buffer(&ctx->poly_scratch, &ctx->poly_scratch_bytes, sizeof(PolyScratch) + 256 + sizeof(DpvConsts));
+    PolyHeader* hdr;
+    rc = poly_scratch(ctx, 0, &hdr, nullptr);
     if (rc) return rc;
-    DpvConsts* dc = (DpvConsts*)((char*)ctx->poly_scratch + ((sizeof(PolyScratch) + 255) / 256) * 256);
+    DpvConsts* dc = &hdr->dpv;
     const int ext = 1 << (log2_target - log2_src);
     const size_t n = (size_t)1 << log2_target;
     hipLaunchKernelGGL(k_dpv_setup, dim3(1), dim3(64), 0, st, dc, (const DomainConsts*)csrc, (const DomainConsts*)cext, (int)log2_src, ext, (int)roots_cut);

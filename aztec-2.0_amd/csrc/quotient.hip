@@ -51,20 +51,25 @@ __device__ __forceinline__ Fr fr_small(uint32_t k)
     }
     return acc;
 }
-// challenges arrive as Montgomery limbs from the host; everything derived from them is computed here (the product has no
-// CPU field arithmetic)
-__global__ void k_quotient_setup(QuotientSetup* s, const Fr* in /* alpha_base, alpha, beta, gamma, delta, g, k1, k2, k3 */)
+// challenges arrive as Montgomery limbs from the host, BY VALUE as a kernel argument (no pageable-memory copy whose source the
+// caller could reuse before it ran); everything derived from them is computed here (the product has no CPU field arithmetic).
+// alpha_base_dev (optional): take alpha_base from device memory instead -- the alpha_out of the previous widget's set-up block,
+// which chains the widgets of a round without a host round trip.
+struct QuotientChallenges {
+    Fr v[9]; // alpha_base, alpha, beta, gamma, delta, g, k1, k2, k3
+};
+__global__ void k_quotient_setup(QuotientSetup* s, QuotientChallenges in, const Fr* alpha_base_dev)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const Fr alpha_base = fe_load<FrP>(in + 0), alpha = fe_load<FrP>(in + 1);
+    const Fr alpha_base = alpha_base_dev ? fe_load<FrP>(alpha_base_dev) : in.v[0], alpha = in.v[1];
     s->alpha = alpha;
-    s->beta = fe_load<FrP>(in + 2);
-    s->gamma = fe_load<FrP>(in + 3);
-    s->delta = fe_load<FrP>(in + 4);
-    s->beta_g = fe_mul(s->beta, fe_load<FrP>(in + 5));
-    s->k1 = fe_load<FrP>(in + 6);
-    s->k2 = fe_load<FrP>(in + 7);
-    s->k3 = fe_load<FrP>(in + 8);
+    s->beta = in.v[2];
+    s->gamma = in.v[3];
+    s->delta = in.v[4];
+    s->beta_g = fe_mul(s->beta, in.v[5]);
+    s->k1 = in.v[6];
+    s->k2 = in.v[7];
+    s->k3 = in.v[8];
     Fr a = alpha_base;
     for (int k = 0; k < 7; k++) {
         s->ap[k] = a;
@@ -345,7 +350,7 @@ struct GpArgs {
     const QuotientSetup* s; // beta, gamma, k1..k3
     const DomainConsts* dc; // small (n) domain
 };
-__global__ void __launch_bounds__(128) k_gp_ratio(GpArgs a)
+template <int WIDTH> __global__ void __launch_bounds__(128) k_gp_ratio(GpArgs a)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t j0 = t * GP_E;
@@ -368,9 +373,11 @@ __global__ void __launch_bounds__(128) k_gp_ratio(GpArgs a)
         wpg = fe_add(fe_load<FrP>(a.w[2] + j), s.gamma);
         n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k2, rb)));
         d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[2] + j), s.beta)));
-        wpg = fe_add(fe_load<FrP>(a.w[3] + j), s.gamma);
-        n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k3, rb)));
-        d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[3] + j), s.beta)));
+        if constexpr (WIDTH == 4) { // StandardPLONK: three wire columns (ProverPermutationWidget<3,false>)
+            wpg = fe_add(fe_load<FrP>(a.w[3] + j), s.gamma);
+            n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k3, rb)));
+            d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[3] + j), s.beta)));
+        }
         num[e] = n_;
         // z is written shifted by one (z[j+1] belongs to row j); park D_j there until the backward pass
         if (j + 1 < a.n) fe_store<FrP>(a.z + j + 1, d_);
@@ -434,32 +441,42 @@ __global__ void __launch_bounds__(256) k_gp_apply(GpArgs a)
 
 int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
 
-int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
-                              void* d_z, hipStream_t st)
+// set-up blocks: one per widget of a round (the chained form keeps all of them alive until the round's kernels have run)
+constexpr int QUOT_SETUPS = 8;
+static int quot_setup_block(bbg_ctx* ctx, int slot, QuotientSetup** out)
+{
+    int rc = ensure_buffer(&ctx->quot_setup, &ctx->quot_setup_bytes, QUOT_SETUPS * sizeof(QuotientSetup));
+    if (rc) return rc;
+    *out = (QuotientSetup*)ctx->quot_setup + slot;
+    return BBG_OK;
+}
+
+// width = 4 (TurboPLONK, ProverPermutationWidget<4,false>) or 3 (StandardPLONK, <3,false>: w_4 / sigma_4 not read)
+int permutation_grand_product_w(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n,
+                                const uint64_t* challenges, void* d_z, hipStream_t st)
 {
     if (log2n > 28) { set_error("bbg_permutation_grand_product_device: log2n > 28"); return BBG_E_INVALID; }
+    if (width != 3 && width != 4) { set_error("bbg_permutation_grand_product_device: width must be 3 or 4"); return BBG_E_INVALID; }
     if (!d_wires || !d_sigmas || !challenges || !d_z) { set_error("bbg_permutation_grand_product_device: null argument"); return BBG_E_INVALID; }
     GpArgs a;
     for (int k = 0; k < 4; k++) {
-        if (!d_wires[k] || !d_sigmas[k]) { set_error("bbg_permutation_grand_product_device: null polynomial"); return BBG_E_INVALID; }
-        a.w[k] = (const Fr*)d_wires[k];
-        a.sigma[k] = (const Fr*)d_sigmas[k];
+        if (k < width && (!d_wires[k] || !d_sigmas[k])) { set_error("bbg_permutation_grand_product_device: null polynomial"); return BBG_E_INVALID; }
+        a.w[k] = k < width ? (const Fr*)d_wires[k] : nullptr;
+        a.sigma[k] = k < width ? (const Fr*)d_sigmas[k] : nullptr;
     }
     const size_t n = (size_t)1 << log2n, threads = (n + GP_E - 1) / GP_E;
-    int rc = ensure_buffer(&ctx->quot_setup, &ctx->quot_setup_bytes, sizeof(QuotientSetup) + 9 * sizeof(Fr));
+    QuotientSetup* setup = nullptr;
+    int rc = quot_setup_block(ctx, 0, &setup);
     if (rc) return rc;
     rc = ensure_buffer(&ctx->gp_totals, &ctx->gp_totals_bytes, threads * sizeof(Fr));
     if (rc) return rc;
-    QuotientSetup* setup = (QuotientSetup*)ctx->quot_setup;
-    Fr* in = (Fr*)((char*)ctx->quot_setup + sizeof(QuotientSetup));
     // same set-up kernel as the widgets: slots alpha_base, alpha, delta, g are unused here (zeros)
-    uint64_t ch[9 * 4] = { 0 };
-    memcpy(ch + 2 * 4, challenges, 32);          // beta
-    memcpy(ch + 3 * 4, challenges + 4, 32);      // gamma
-    memcpy(ch + 6 * 4, challenges + 8, 3 * 32);  // k1..k3
-    BBG_HIP(hipMemcpyAsync(in, ch, sizeof(ch), hipMemcpyHostToDevice, st));
-    BBG_HIP(hipStreamSynchronize(st)); // ch lives on this stack frame
-    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setup, (const Fr*)in);
+    QuotientChallenges ch;
+    memset(&ch, 0, sizeof(ch));
+    memcpy(&ch.v[2], challenges, 32);          // beta
+    memcpy(&ch.v[3], challenges + 4, 32);      // gamma
+    memcpy(&ch.v[6], challenges + 8, 3 * 32);  // k1..k3
+    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setup, ch, (const Fr*)nullptr);
     void* dc = nullptr;
     rc = ntt_domain_consts(ctx, log2n, &dc);
     if (rc) return rc;
@@ -469,52 +486,35 @@ int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const vo
     a.s = setup;
     a.dc = (const DomainConsts*)dc;
     ProfScope ps(ctx, "grand_product", st);
-    hipLaunchKernelGGL(k_gp_ratio, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, a);
+    if (width == 4) hipLaunchKernelGGL(k_gp_ratio<4>, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(k_gp_ratio<3>, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, a);
     hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(256), 0, st, a.totals, threads);
     hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     BBG_HIP(hipGetLastError());
     return BBG_OK;
 }
-
-// challenges: 9 Montgomery Fr on the host: alpha_base, alpha, beta, gamma, public_input_delta, g, k1, k2, k3
-int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
-                    uint64_t* alpha_out, hipStream_t st)
+int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
+                              void* d_z, hipStream_t st)
 {
-    if (widget < 0 || widget > 6) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
-    if (log2_large < 3 || log2_large > 28) { set_error("bbg_quotient_widget_device: need 3 <= log2 of the 4n domain <= 28"); return BBG_E_INVALID; }
-    if (!d_polys || !challenges || !d_quotient) { set_error("bbg_quotient_widget_device: null argument"); return BBG_E_INVALID; }
-    // which polynomials each widget reads (a null pointer for one of them is an error; the others may be null)
-    static const uint32_t NEED[7] = {
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) |
-            (1u << QP_S4) | (1u << QP_L1),
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
-            (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QARITH),
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
-            (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QECC),
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QRANGE),
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QC) | (1u << QP_QLOGIC),
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) | (1u << QP_L1),
-        (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_QM) | (1u << QP_QC),
-    };
-    QuotientArgs a;
-    for (int k = 0; k < QP_COUNT; k++) {
-        a.p[k] = (const Fr*)d_polys[k];
-        if (((NEED[widget] >> k) & 1u) && !a.p[k]) { set_error("bbg_quotient_widget_device: a polynomial this widget reads is null"); return BBG_E_INVALID; }
-    }
-    int rc = ensure_buffer(&ctx->quot_setup, &ctx->quot_setup_bytes, sizeof(QuotientSetup) + 9 * sizeof(Fr));
-    if (rc) return rc;
-    QuotientSetup* setup = (QuotientSetup*)ctx->quot_setup;
-    Fr* in = (Fr*)((char*)ctx->quot_setup + sizeof(QuotientSetup));
-    BBG_HIP(hipMemcpyAsync(in, challenges, 9 * sizeof(Fr), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setup, (const Fr*)in);
-    void* dc = nullptr;
-    rc = ntt_domain_consts(ctx, log2_large, &dc);
-    if (rc) return rc;
-    a.quotient = (Fr*)d_quotient;
-    a.mask = (uint32_t)(((size_t)1 << log2_large) - 1);
-    a.s = setup;
-    a.dc = (const DomainConsts*)dc;
-    const size_t m = (size_t)1 << log2_large;
+    return permutation_grand_product_w(ctx, 4, d_wires, d_sigmas, log2n, challenges, d_z, st);
+}
+
+// which polynomials each widget reads (a null pointer for one of them is an error; the others may be null)
+static const uint32_t WIDGET_NEEDS[7] = {
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) |
+        (1u << QP_S4) | (1u << QP_L1),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
+        (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QARITH),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
+        (1u << QP_Q5) | (1u << QP_QM) | (1u << QP_QC) | (1u << QP_QECC),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QRANGE),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QC) | (1u << QP_QLOGIC),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) | (1u << QP_L1),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_QM) | (1u << QP_QC),
+};
+
+static int launch_widget(bbg_ctx* ctx, int widget, const QuotientArgs& a, size_t m, hipStream_t st)
+{
     ProfScope ps(ctx, "quotient_widget", st);
     switch (widget) {
     case 0: hipLaunchKernelGGL(k_quotient_permutation<4>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
@@ -527,13 +527,61 @@ int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsign
         break;
     case 3: hipLaunchKernelGGL(k_quotient_turbo_range, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL(k_quotient_turbo_logic, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    default: set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID;
     }
     BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+// `count` widgets in the prover's order (execute_fourth_round, prover.cpp:304-319), each starting from the alpha_base the previous
+// one returned -- chained on the device (set-up block k reads alpha_out of block k-1), no host round trip between them.
+// challenges: 9 Montgomery Fr on the host: alpha_base, alpha, beta, gamma, public_input_delta, g, k1, k2, k3.
+int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const void* const* d_polys, unsigned log2_large,
+                           const uint64_t* challenges, void* d_quotient, uint64_t* alpha_out, hipStream_t st)
+{
+    if (count < 1 || count >= QUOT_SETUPS) { set_error("bbg_quotient_widget_device: bad widget count"); return BBG_E_INVALID; }
+    if (log2_large < 3 || log2_large > 28) { set_error("bbg_quotient_widget_device: need 3 <= log2 of the 4n domain <= 28"); return BBG_E_INVALID; }
+    if (!d_polys || !challenges || !d_quotient || !widgets) { set_error("bbg_quotient_widget_device: null argument"); return BBG_E_INVALID; }
+    QuotientArgs a;
+    for (int k = 0; k < QP_COUNT; k++) a.p[k] = (const Fr*)d_polys[k];
+    for (int w = 0; w < count; w++) {
+        if (widgets[w] < 0 || widgets[w] > 6) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
+        for (int k = 0; k < QP_COUNT; k++)
+            if (((WIDGET_NEEDS[widgets[w]] >> k) & 1u) && !a.p[k]) {
+                set_error("bbg_quotient_widget_device: a polynomial this widget reads is null");
+                return BBG_E_INVALID;
+            }
+    }
+    QuotientSetup* setups = nullptr;
+    int rc = quot_setup_block(ctx, 0, &setups);
+    if (rc) return rc;
+    void* dc = nullptr;
+    rc = ntt_domain_consts(ctx, log2_large, &dc);
+    if (rc) return rc;
+    QuotientChallenges ch;
+    memcpy(&ch, challenges, sizeof(ch));
+    a.quotient = (Fr*)d_quotient;
+    a.mask = (uint32_t)(((size_t)1 << log2_large) - 1);
+    a.dc = (const DomainConsts*)dc;
+    const size_t m = (size_t)1 << log2_large;
+    for (int w = 0; w < count; w++) {
+        const Fr* prev = w ? &setups[w - 1].alpha_out[widgets[w - 1]] : nullptr;
+        hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setups + w, ch, prev);
+        a.s = setups + w;
+        rc = launch_widget(ctx, widgets[w], a, m, st);
+        if (rc) return rc;
+    }
     if (alpha_out) {
-        BBG_HIP(hipMemcpyAsync(alpha_out, &setup->alpha_out[widget], sizeof(Fr), hipMemcpyDeviceToHost, st));
+        BBG_HIP(hipMemcpyAsync(alpha_out, &setups[count - 1].alpha_out[widgets[count - 1]], sizeof(Fr), hipMemcpyDeviceToHost, st));
         BBG_HIP(hipStreamSynchronize(st));
     }
     return BBG_OK;
+}
+
+int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
+                    uint64_t* alpha_out, hipStream_t st)
+{
+    return quotient_widgets_chain(ctx, &widget, 1, d_polys, log2_large, challenges, d_quotient, alpha_out, st);
 }
 
 } // namespace bbg

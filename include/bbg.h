@@ -76,6 +76,13 @@ int bbg_srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, bbg_srs** out);
 /* Reads an Ignition-format transcript file (manifest + big-endian points; srs/io.cpp:11-162): result is
  * monomials[0] = G followed by the file's points, num_points in total -- exactly read_transcript_g1. */
 int bbg_srs_load_transcript(bbg_ctx* ctx, const char* path, size_t num_points, bbg_srs** out);
+/* The inverse: writes the SRS as Ignition-format files dir/transcript00.dat, 01, ... holding points 1 .. n-1 (point 0 is the
+ * generator every reader supplies itself, srs/io.cpp:137), points_per_file per file (0 = one file); manifest and point encoding of
+ * srs/io.cpp:11-67.  g2_x_raw (may be NULL): 128 bytes stored as file 00's single G2 point, as given.  Each file ends with the
+ * BLAKE2b-512 checksum of what precedes it. */
+int bbg_srs_write_transcript(bbg_srs* srs, const char* dir, size_t points_per_file, const uint8_t* g2_x_raw);
+/* BLAKE2b-512 (RFC 7693) of a byte string: the checksum that closes a transcript file.  Host only, needs no GPU. */
+int bbg_transcript_checksum(const void* data, size_t len, uint8_t out[64]);
 size_t bbg_srs_num_points(const bbg_srs* srs);
 /* Copies points [from, from+count) back to the host (64-byte Montgomery affine each). */
 int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points);
@@ -202,6 +209,65 @@ int bbg_quotient_widget_device(bbg_ctx* ctx, int widget, const void* const d_pol
  * values.  Asynchronous on the context stream. */
 int bbg_permutation_grand_product_device(bbg_ctx* ctx, const void* const d_wires[4], const void* const d_sigmas[4], unsigned log2n,
                                          const uint64_t* challenges, void* d_z);
+
+/* ---- resident prover rounds (SURVEY 8f-1 with 8f-2 / 8f-4 inside): the native, handle-based form of a PLONK prover's O(n) work.
+ *      The host keeps the transcript (Fiat-Shamir hashing) and the O(1) challenge algebra -- in a barretenberg build that is
+ *      shim/bbg_resident_prover.hpp, which drives these entry points from ProverBase's own public members in place of
+ *      ProverBase::construct_proof (prover.cpp:420-436) and work_queue::process_queue (work_queue.hpp:208-282).
+ *      One handle per proving key; selector / permutation polynomials are registered ONCE (explicit lifetime, no content
+ *      fingerprints), wires go up per proof, 11 commitments and the opening evaluations come down.  All values Montgomery Fr /
+ *      Montgomery affine g1 in the reference's layouts.  Rounds must be called in order; each returns after ONE host sync. ---- */
+typedef struct bbg_prover bbg_prover;
+enum bbg_poly_form {
+    BBG_FORM_COEFF = 0,    /* n coefficients (monomial form)                                   */
+    BBG_FORM_LAGRANGE = 1, /* n values on the small domain                                     */
+    BBG_FORM_COSET = 2     /* 4n values on the coset g * <w_4n> (the key's "*_fft" arrays)      */
+};
+enum bbg_prover_poly { /* continues enum bbg_quotient_poly: the polynomials a proof creates */
+    BBG_PP_QUOTIENT = BBG_QP_COUNT, /* all 4n coefficients of t(X)                                                      */
+    BBG_PP_T_1, BBG_PP_T_2, BBG_PP_T_3, BBG_PP_T_4, /* t_low, t_mid, t_high, t_higher: slices of n coefficients of t(X) */
+    BBG_PP_LINEAR,                  /* r(X), the linearisation polynomial                                               */
+    BBG_PP_OPENING, BBG_PP_SHIFTED_OPENING, /* W_zeta(X), W_zeta_omega(X)                                               */
+    BBG_PP_COUNT
+};
+/* program_width: 4 = TurboPLONK (ProverPermutationWidget<4> + turbo arithmetic / fixed base / range / logic widgets,
+ * turbo_composer.cpp:735-752), 3 = StandardPLONK (ProverPermutationWidget<3> + arithmetic widget, standard_composer.cpp:562-582).
+ * generators: 4 Montgomery Fr -- the small domain's coset generator g and fr::coset_generator(0..2) = k1, k2, k3.
+ * srs must hold n points (n + 1 for StandardPLONK).  The srs and the context must outlive the handle. */
+int bbg_prover_create(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int program_width, const uint64_t* generators, bbg_prover** out);
+void bbg_prover_destroy(bbg_prover* p);
+/* Per proving key.  id: BBG_QP_SIGMA_1 .. BBG_QP_LAGRANGE_1.  form BBG_FORM_COEFF (n values; what proving_key::constraint_selectors /
+ * permutation_selectors hold) is sufficient: bbg_prover_finalize_key derives sigma's Lagrange form, every 4n-coset form and L_1 on the
+ * device.  A caller may instead hand over its own BBG_FORM_LAGRANGE (sigma) / BBG_FORM_COSET arrays.  The array is copied before
+ * the call returns.  Re-registering a polynomial replaces it (call finalize again). */
+int bbg_prover_set_key_poly(bbg_prover* p, int id, int form, const uint64_t* values);
+int bbg_prover_finalize_key(bbg_prover* p);
+/* Preamble + round 1 (prover.cpp:139-190, :66-84): wires_lagrange[k], k < program_width: the n values of wire k INCLUDING the blinding
+ * rows n-4 .. n-2 the host has drawn.  Uploads them (kept for round 3), iffts to coefficient form (resident), commits.
+ * commitments: program_width x 8 limbs, affine W_1 .. W_w. */
+int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint64_t* commitments);
+/* Round 3 (permutation_widget_impl.hpp:48-312, prover.cpp:239-268): grand product z over the resident wires and sigmas, rows
+ * n-3 .. n-1 <- blind[3][4], ifft, commitment Z, and the 4n-coset forms of z and the wires (resident, for round 4). */
+int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* blind, uint64_t z_commitment[8]);
+/* Round 4 (prover.cpp:275-363): the flavour's widgets in the prover's order, division by Z*_H, coset_ifft(4n) -> t(X) resident;
+ * commitments T_1 .. T_w (the last one over n + 1 coefficients for StandardPLONK, prover.cpp:117-137). */
+int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t public_input_delta[4], uint64_t* t_commitments);
+/* Round 5a (add_opening_evaluations_to_transcript, kate_commitment_scheme.cpp:362-420; quotient_large.evaluate, prover.cpp:397):
+ * out[k] = P_ids[k](zeta), or P(zeta * w_n) where shifted[k] != 0 (shifted may be NULL); ids from bbg_quotient_poly /
+ * bbg_prover_poly (coefficient forms; BBG_PP_QUOTIENT evaluates all 4n coefficients).  count <= 32. */
+int bbg_prover_evaluate(bbg_prover* p, size_t count, const int* ids, const int* shifted, const uint64_t zeta[4], uint64_t* out);
+/* Round 5b (compute_linear_contribution of every widget, prover.cpp:399-407): r(X) = sum_k scalars[k] * P_ids[k](X) (resident as
+ * BBG_PP_LINEAR), r_eval = r(zeta). */
+int bbg_prover_linearise(bbg_prover* p, size_t count, const int* ids, const uint64_t* scalars, const uint64_t zeta[4], uint64_t r_eval[4]);
+/* Round 6 (KateCommitmentScheme::batch_open, kate_commitment_scheme.cpp:133-236): F = t_low + sum scalars_zeta[k] P_ids_zeta[k],
+ * F' = sum scalars_omega[k] P_ids_omega[k]; W_zeta = (F - F(zeta)) / (X - zeta), W_zeta_omega likewise at zeta_omega; commitments
+ * PI_Z and PI_Z_OMEGA.  t_high_top_scalar: StandardPLONK only (else NULL) -- the scalar zeta^(2n) of t's (3n+1)-th coefficient, which
+ * enters F as its coefficient n (:196-205). */
+int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, const uint64_t* scalars_zeta, size_t count_omega,
+                      const int* ids_omega, const uint64_t* scalars_omega, const uint64_t zeta[4], const uint64_t zeta_omega[4],
+                      const uint64_t* t_high_top_scalar, uint64_t pi_z[8], uint64_t pi_z_omega[8]);
+/* Copies a resident polynomial back (tests; a host that wants the reference's post-proof state): id / form as above. */
+int bbg_prover_read_poly(bbg_prover* p, int id, int form, uint64_t* out, size_t count);
 
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),

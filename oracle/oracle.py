@@ -504,13 +504,21 @@ class RefProver:
                                   ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_void_p)
 
-    def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False):
+    def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False, flavour=0):
+        """flavour 0 = TurboPLONK (TurboComposer / TurboProver), 1 = StandardPLONK (StandardComposer / Prover) over the same circuit."""
         if not prover_available() or (gpu_linked and not os.path.exists(PROVER_GPU_SO)):
             raise RuntimeError("oracle/_ref/libbbprover[_gpu].so not available on this machine")
         L = self.lib = ctypes.CDLL(PROVER_GPU_SO if gpu_linked else PROVER_SO, mode=os.RTLD_NOW)
         L.refp_gpu_linked.restype = cint
         assert bool(L.refp_gpu_linked()) == bool(gpu_linked)
-        L.refp_new.argtypes = [sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new.restype = vp
+        L.refp_new_flavour.argtypes = [cint, sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new_flavour.restype = vp
+        L.refp_program_width.argtypes = [vp]; L.refp_program_width.restype = sz
+        L.refp_construct_proof_recording.argtypes = [vp, vp]; L.refp_construct_proof_recording.restype = cint
+        L.refp_construct_proof_reference.argtypes = [vp]; L.refp_construct_proof_reference.restype = cint
+        L.refp_resident_key_create.argtypes = [vp]; L.refp_resident_key_create.restype = ctypes.c_double
+        L.refp_construct_proof_resident.argtypes = [vp, vp, sz]; L.refp_construct_proof_resident.restype = ctypes.c_double
+        L.refp_last_error.argtypes = [vp]; L.refp_last_error.restype = ctypes.c_char_p
+        L.refio_read_transcript_g1.argtypes = [ctypes.c_char_p, sz, vp]; L.refio_read_transcript_g1.restype = cint
         L.refp_circuit_size.argtypes = [vp]; L.refp_circuit_size.restype = sz
         L.refp_get_monomials.argtypes = [vp, vp, sz]
         L.refp_execute_round.argtypes = [vp, cint]; L.refp_execute_round.restype = sz
@@ -527,12 +535,68 @@ class RefProver:
         L.refp_set_threads(self.threads)
         pts = _arr(points, 8)
         x = np.ascontiguousarray(x_mont, dtype=np.uint64)
-        self.h = L.refp_new(num_gates, circuit_seed, pts.ctypes.data, pts.shape[0], x.ctypes.data)
+        self.h = L.refp_new_flavour(flavour, num_gates, circuit_seed, pts.ctypes.data, pts.shape[0], x.ctypes.data)
         if not self.h:
             raise RuntimeError("refp_new failed (circuit larger than the SRS?)")
         self.n = int(L.refp_circuit_size(self.h))
         self.counts = [0, 0, 0]
         self.mismatches = 0
+
+    # ---- whole proofs
+    def _proof(self):
+        size = self.lib.refp_export_proof(self.h, None, 0)
+        buf = (ctypes.c_uint8 * size)()
+        self.lib.refp_export_proof(self.h, buf, size)
+        return bytes(buf)
+
+    def prove_recording(self):
+        """ProverBase::construct_proof round by round, recording the blinding scalars it draws: (proof bytes, (3w + 3, 4) limbs)."""
+        w = int(self.lib.refp_program_width(self.h))
+        blind = np.zeros((3 * w + 3, 4), dtype=np.uint64)
+        rc = self.lib.refp_construct_proof_recording(self.h, blind.ctypes.data)
+        if rc != 3 * w + 3:
+            raise RuntimeError(f"refp_construct_proof_recording failed ({rc})")
+        return self._proof(), blind
+
+    def prove_reference(self):
+        """ProverBase::construct_proof() as shipped, one call (shim-linked build: MSM / FFT entry points on the GPU)."""
+        if self.lib.refp_construct_proof_reference(self.h) != 0:
+            raise RuntimeError("refp_construct_proof_reference failed")
+        return self._proof()
+
+    def resident_key_create(self):
+        """bbg_shim::ResidentKey for this circuit's proving key (shim-linked build only); seconds."""
+        t = self.lib.refp_resident_key_create(self.h)
+        if t < 0:
+            raise RuntimeError("resident key: " + (self.lib.refp_last_error(self.h) or b"not a shim-linked build").decode())
+        return t
+
+    def resident_check_key(self):
+        """Number of key polynomials whose device-derived form (sigma Lagrange, 4n coset, L_1) differs from the reference's own array."""
+        self.lib.refp_resident_check_key.argtypes = [vp]; self.lib.refp_resident_check_key.restype = cint
+        rc = self.lib.refp_resident_check_key(self.h)
+        if rc < 0:
+            raise RuntimeError("resident key check: " + (self.lib.refp_last_error(self.h) or b"not a shim-linked build").decode())
+        return rc
+
+    def prove_resident(self, replay=None):
+        """bbg_shim::construct_proof (shim/bbg_resident_prover.hpp): every O(n) step on the device.  replay: blinding scalars to
+        use instead of fr::random_element() (what prove_recording returned).  Returns (proof bytes, seconds)."""
+        if replay is None:
+            t = self.lib.refp_construct_proof_resident(self.h, None, 0)
+        else:
+            r = _arr(replay, 4)
+            t = self.lib.refp_construct_proof_resident(self.h, r.ctypes.data, r.shape[0])
+        if t < 0:
+            raise RuntimeError("resident proof: " + (self.lib.refp_last_error(self.h) or b"not a shim-linked build").decode())
+        return self._proof(), t
+
+    def read_transcript_g1(self, directory, degree):
+        """The reference's own io::read_transcript_g1 (srs/io.cpp:134-162)."""
+        out = np.zeros((degree, 8), dtype=np.uint64)
+        if self.lib.refio_read_transcript_g1(str(directory).encode(), degree, out.ctypes.data) != 0:
+            raise RuntimeError("io::read_transcript_g1 threw")
+        return out
 
     def monomials(self, count=None):
         count = self.n + 1 if count is None else count

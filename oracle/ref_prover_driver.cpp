@@ -35,6 +35,12 @@
 #include <plonk/proof_system/public_inputs/public_inputs.hpp>
 #include <plonk/reference_string/reference_string.hpp>
 #include <polynomials/polynomial_arithmetic.hpp>
+#include <srs/io.hpp>
+#include <chrono>
+#include <type_traits>
+#ifdef BBG_DRIVER_WITH_SHIM
+#include "../shim/bbg_resident_prover.hpp"
+#endif
 
 using namespace barretenberg;
 
@@ -98,15 +104,38 @@ class DriverCrsFactory : public waffle::ReferenceStringFactory {
     fr x_;
 };
 
+// What the entry points below need of a prover, independent of its flavour (ProverBase<turbo_settings> / <standard_settings> are
+// different types with the same public members).
+struct ProverView {
+    std::shared_ptr<waffle::proving_key>& key;
+    std::shared_ptr<waffle::program_witness>& witness;
+    waffle::work_queue& queue;
+    transcript::StandardTranscript& transcript;
+    std::vector<std::unique_ptr<waffle::ProverRandomWidget>>& random_widgets;
+    std::vector<std::unique_ptr<waffle::widget::TransitionWidgetBase<fr>>>& transition_widgets;
+};
 struct Session {
-    std::unique_ptr<waffle::TurboComposer> composer;
-    std::unique_ptr<waffle::TurboProver> prover;
+    virtual ~Session() {}
+    virtual ProverView view() = 0;
+    virtual void execute_round(int k) = 0;
+    virtual void compute_quotient_pre_commitment() = 0;
+    virtual void construct_proof_reference() = 0; // ProverBase::construct_proof as shipped (CPU, or the shim's wrapped entry points)
+    virtual std::vector<uint8_t> export_proof() = 0;
+    virtual int verify(const std::vector<uint8_t>& proof_data) = 0;
+    virtual size_t program_width() const = 0;
+    // resident proof through shim/bbg_resident_prover.hpp (only in the build linked with the shim); returns seconds, < 0 on error
+    virtual double resident_key_create() { return -1; }
+    virtual double construct_proof_resident(const uint64_t*, size_t) { return -1; }
+    // device-derived forms of the key's polynomials (sigma in Lagrange base, every 4n-coset form, L_1) against the arrays the
+    // reference's compute_proving_key produced: number of differing arrays, < 0 without the shim
+    virtual int resident_check_key() { return -1; }
     std::vector<uint8_t> proof;
+    std::string error;
 };
 
 // A satisfiable arithmetic circuit of ~num_gates gates: a chain x_{k+1} = x_k * y_k + x_k with fresh y_k, laid out as one
 // multiplication gate and one addition gate per step (TurboComposer::create_mul_gate / create_add_gate).
-void build_circuit(waffle::TurboComposer& c, size_t num_gates, uint64_t seed)
+template <typename Composer> void build_circuit(Composer& c, size_t num_gates, uint64_t seed)
 {
     auto next = [&seed]() {
         seed += 0x9E3779B97F4A7C15ULL;
@@ -132,8 +161,129 @@ void build_circuit(waffle::TurboComposer& c, size_t num_gates, uint64_t seed)
     }
 }
 
+
+#ifdef BBG_DRIVER_WITH_SHIM
+struct Replay { // blinding scalars recorded from a reference proof, handed out in the order the prover draws them
+    const uint64_t* values;
+    size_t count, next;
+    static fr draw(void* user)
+    {
+        auto* r = (Replay*)user;
+        if (r->next >= r->count) throw std::runtime_error("replay: the prover drew more blinding scalars than were recorded");
+        fr v;
+        std::memcpy(&v, r->values + 4 * r->next++, 32);
+        return v;
+    }
+};
+#endif
+
+template <typename Composer, typename Prover, typename Verifier> struct SessionT : Session {
+    std::unique_ptr<Composer> composer;
+    std::unique_ptr<Prover> prover;
+    ProverView view() override
+    {
+        return ProverView{ prover->key, prover->witness, prover->queue, prover->transcript, prover->random_widgets, prover->transition_widgets };
+    }
+    void execute_round(int k) override
+    {
+        auto& p = *prover;
+        switch (k) {
+        case 0: p.execute_preamble_round(); break;
+        case 1: p.execute_first_round(); break;
+        case 2: p.execute_second_round(); break;
+        case 3: p.execute_third_round(); break;
+        case 4: p.execute_fourth_round(); break;
+        case 5: p.execute_fifth_round(); break;
+        case 6: p.execute_sixth_round(); break;
+        default: break;
+        }
+    }
+    void compute_quotient_pre_commitment() override { prover->compute_quotient_pre_commitment(); }
+    void construct_proof_reference() override { prover->construct_proof(); }
+    std::vector<uint8_t> export_proof() override { return prover->export_proof().proof_data; }
+    int verify(const std::vector<uint8_t>& proof_data) override
+    {
+        Verifier verifier = composer->create_verifier();
+        waffle::plonk_proof pr{ proof_data };
+        return verifier.verify_proof(pr) ? 1 : 0;
+    }
+    size_t program_width() const override { return width_of(); }
+    static constexpr size_t width_of() { return std::is_same<Prover, waffle::TurboProver>::value ? 4 : 3; }
+#ifdef BBG_DRIVER_WITH_SHIM
+    std::unique_ptr<bbg_shim::ResidentKey> resident_key;
+    double resident_key_create() override
+    {
+        auto t0 = std::chrono::steady_clock::now();
+        resident_key = std::make_unique<bbg_shim::ResidentKey>(prover->key, width_of());
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    int resident_check_key() override
+    {
+        if (!resident_key) resident_key_create();
+        auto* key = prover->key.get();
+        const size_t n = key->n;
+        std::vector<fr> got(4 * n);
+        int bad = 0;
+        auto differs = [&](int id, int form, const fr* want, size_t count) {
+            if (bbg_prover_read_poly(resident_key->handle(), id, form, (uint64_t*)got.data(), count) != BBG_OK) return true;
+            for (size_t i = 0; i < count; i++)
+                if (!(got[i] == want[i])) return true;
+            return false;
+        };
+        for (const auto& info : key->polynomial_manifest) {
+            if (info.source == waffle::PolynomialSource::WITNESS) continue;
+            const std::string label(info.polynomial_label);
+            const int id = bbg_shim::device_poly_id(info.index);
+            if (info.source == waffle::PolynomialSource::SELECTOR) {
+                bad += differs(id, BBG_FORM_COSET, &key->constraint_selector_ffts.at(label + "_fft")[0], 4 * n);
+            } else {
+                bad += differs(id, BBG_FORM_COSET, &key->permutation_selector_ffts.at(label + "_fft")[0], 4 * n);
+                bad += differs(id, BBG_FORM_LAGRANGE, &key->permutation_selectors_lagrange_base.at(label)[0], n);
+            }
+        }
+        bad += differs(BBG_QP_LAGRANGE_1, BBG_FORM_COSET, &key->lagrange_1[0], 4 * n);
+        return bad;
+    }
+    double construct_proof_resident(const uint64_t* replay, size_t count) override
+    {
+        if (!resident_key) resident_key_create();
+        Replay r{ replay, count, 0 };
+        bbg_shim::ResidentOptions opt;
+        if (replay) {
+            opt.random = &Replay::draw;
+            opt.user = &r;
+        }
+        prover->reset(); // a fresh transcript: the same session may prove again (the host witness stays in Lagrange form)
+        auto t0 = std::chrono::steady_clock::now();
+        bbg_shim::construct_proof(*prover, *resident_key, opt);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+#endif
+};
+using TurboSession = SessionT<waffle::TurboComposer, waffle::TurboProver, waffle::TurboVerifier>;
+using StandardSession = SessionT<waffle::StandardComposer, waffle::Prover, waffle::Verifier>;
+
 } // namespace
 
+extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num_points) __attribute__((weak));
+
+// points: num_points affine Montgomery points [x^i]G (64 B each); x_mont: the secret as a Montgomery Fr (4 limbs).
+// flavour 0 = TurboPLONK (TurboComposer::create_prover, turbo_composer.cpp:727), 1 = StandardPLONK (StandardComposer::create_prover,
+// standard_composer.cpp:562): the same arithmetic circuit through the other composer.
+template <typename S, typename Composer> static Session* new_session(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const fr& x)
+{
+    auto s = std::make_unique<S>();
+    if constexpr (std::is_same<Composer, waffle::TurboComposer>::value)
+        s->composer = std::make_unique<Composer>(std::shared_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
+    else
+        s->composer = std::make_unique<Composer>(std::unique_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
+    build_circuit(*s->composer, num_gates, circuit_seed);
+    using ProverT = typename std::remove_reference<decltype(*s->prover)>::type;
+    s->prover = std::make_unique<ProverT>(s->composer->create_prover());
+    if (bbg_shim_register_point_table) // the Pippenger-constructor hook of INTEGRATION.md: upload the SRS once, up front
+        bbg_shim_register_point_table(s->prover->key->reference_string->get_monomials(), s->prover->get_circuit_size() + 1);
+    return s.release();
+}
 // Present only in the variant of this library that is linked with the drop-in shim (libbbprover_gpu.so)
 extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num_points) __attribute__((weak));
 
@@ -149,25 +299,24 @@ typedef void (*refp_ifft_cb)(uint64_t* coeffs, size_t log2n, void* user);
 // the whole FFT work item: n coefficients of the wire -> the 4n + 4 entries of wire_fft (coset FFT + 4 wrapped values)
 typedef void (*refp_fft_item_cb)(const uint64_t* wire, size_t log2n, uint64_t* wire_fft, size_t log2_domain, void* user);
 
-// points: num_points affine Montgomery points [x^i]G (64 B each); x_mont: the secret as a Montgomery Fr (4 limbs).
-void* refp_new(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const uint64_t* x_mont)
+void* refp_new_flavour(int flavour, size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const uint64_t* x_mont)
 {
     try {
         fr x{ x_mont[0], x_mont[1], x_mont[2], x_mont[3] };
-        auto factory = std::make_shared<DriverCrsFactory>(points, num_points, x);
-        auto* s = new Session;
-        s->composer = std::make_unique<waffle::TurboComposer>(std::static_pointer_cast<waffle::ReferenceStringFactory>(factory), num_gates);
-        build_circuit(*s->composer, num_gates, circuit_seed);
-        s->prover = std::make_unique<waffle::TurboProver>(s->composer->create_prover());
-        if (bbg_shim_register_point_table) // the Pippenger-constructor hook of INTEGRATION.md: upload the SRS once, up front
-            bbg_shim_register_point_table(s->prover->key->reference_string->get_monomials(), s->prover->get_circuit_size() + 1);
-        return s;
+        if (flavour == 0) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
+        if (flavour == 1) return new_session<StandardSession, waffle::StandardComposer>(num_gates, circuit_seed, points, num_points, x);
+        return nullptr;
     } catch (...) {
         return nullptr;
     }
 }
+void* refp_new(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const uint64_t* x_mont)
+{
+    return refp_new_flavour(0, num_gates, circuit_seed, points, num_points, x_mont);
+}
 
-size_t refp_circuit_size(void* h) { return ((Session*)h)->prover->get_circuit_size(); }
+size_t refp_circuit_size(void* h) { return ((Session*)h)->view().key->n; }
+size_t refp_program_width(void* h) { return ((Session*)h)->program_width(); }
 
 // OpenMP team size for everything the reference runs on the host.  The reference's compute_wnaf_states mis-indexes its
 // per-thread scratch when the team is large relative to the input (observed: intermittent SIGSEGV with 128 threads at
@@ -178,29 +327,20 @@ int refp_max_threads(void) { return omp_get_max_threads(); }
 // the monomials the prover's MSMs run over: plain points 0 .. n (the interleaved endomorphism twins skipped), 64 B each
 void refp_get_monomials(void* h, uint64_t* out, size_t count)
 {
-    g1::affine_element* t = ((Session*)h)->prover->key->reference_string->get_monomials();
+    g1::affine_element* t = ((Session*)h)->view().key->reference_string->get_monomials();
     for (size_t i = 0; i < count; i++) std::memcpy(out + i * 8, (const void*)&t[2 * i], 64);
 }
 
 // round k = 0 (preamble) .. 6; returns the number of queued work items afterwards
 size_t refp_execute_round(void* h, int k)
 {
-    auto& p = *((Session*)h)->prover;
-    switch (k) {
-    case 0: p.execute_preamble_round(); break;
-    case 1: p.execute_first_round(); break;
-    case 2: p.execute_second_round(); break;
-    case 3: p.execute_third_round(); break;
-    case 4: p.execute_fourth_round(); break;
-    case 5: p.execute_fifth_round(); break;
-    case 6: p.execute_sixth_round(); break;
-    default: break;
-    }
-    return p.queue.get_queue().size();
+    auto* s = (Session*)h;
+    s->execute_round(k);
+    return s->view().queue.get_queue().size();
 }
 
 // the reference's own CPU path for the queued items (work_queue::process_queue)
-void refp_process_queue_reference(void* h) { ((Session*)h)->prover->queue.process_queue(); }
+void refp_process_queue_reference(void* h) { ((Session*)h)->view().queue.process_queue(); }
 
 // Same items, same order, same data movement as work_queue::process_queue (work_queue.hpp:208-282), with the three
 // compute calls replaced by the callbacks.  When check != 0 every callback result is compared with the reference CPU
@@ -218,7 +358,7 @@ int refp_process_queue_with2(void* h, refp_msm_cb msm, refp_coset_fft_cb coset_f
                              void* user, int check, uint32_t* counts)
 {
     try {
-        auto& p = *((Session*)h)->prover;
+        auto p = ((Session*)h)->view();
         auto* key = p.key.get();
         auto* witness = p.witness.get();
         int mismatches = 0;
@@ -306,7 +446,7 @@ int refp_process_queue_with2(void* h, refp_msm_cb msm, refp_coset_fft_cb coset_f
 size_t refp_export_proof(void* h, uint8_t* out, size_t cap)
 {
     auto* s = (Session*)h;
-    s->proof = s->prover->export_proof().proof_data;
+    s->proof = s->export_proof();
     if (out) std::memcpy(out, s->proof.data(), s->proof.size() < cap ? s->proof.size() : cap);
     return s->proof.size();
 }
@@ -316,15 +456,108 @@ int refp_verify(void* h)
 {
     try {
         auto* s = (Session*)h;
-        auto verifier = s->composer->create_verifier();
-        waffle::plonk_proof proof{ s->proof };
-        return verifier.verify_proof(proof) ? 1 : 0;
+        return s->verify(s->proof);
     } catch (...) {
         return -1;
     }
 }
 
 void refp_delete(void* h) { delete (Session*)h; }
+
+// ProverBase::construct_proof() (prover.cpp:420-436) round by round, RECORDING the blinding scalars the reference draws with its
+// unseeded fr::random_element(): three per wire (rows n-4 .. n-2 of the wire's Lagrange form, read after execute_preamble_round and
+// before its IFFT items run) and three for z (rows n-3 .. n-1 of z, recovered from its coefficients with the reference's own fft).
+// blind_out: (3 * program_width + 3) x 4 limbs, in the order the prover draws them.  Returns that count, or -1.
+int refp_construct_proof_recording(void* h, uint64_t* blind_out)
+{
+    try {
+        auto* s = (Session*)h;
+        auto p = s->view();
+        const size_t n = p.key->n, w = s->program_width();
+        s->execute_round(0);
+        for (size_t i = 0; i < w; i++)
+            for (size_t k = 0; k < 3; k++)
+                std::memcpy(blind_out + 4 * (3 * i + k), (const void*)&p.witness->wires.at("w_" + std::to_string(i + 1))[n - 4 + k], 32);
+        p.queue.process_queue();
+        for (int k = 1; k <= 3; k++) {
+            s->execute_round(k);
+            if (k == 3) { // z was blinded and iffted inside the round
+                polynomial zc(p.witness->wires.at("z"), n);
+                polynomial_arithmetic::fft(&zc[0], p.key->small_domain);
+                for (size_t r = 0; r < 3; r++) std::memcpy(blind_out + 4 * (3 * w + r), (const void*)&zc[n - 3 + r], 32);
+            }
+            p.queue.process_queue();
+        }
+        s->execute_round(4);
+        p.queue.process_queue();
+        s->execute_round(5);
+        s->execute_round(6);
+        p.queue.process_queue();
+        s->proof = s->export_proof();
+        return (int)(3 * w + 3);
+    } catch (...) {
+        return -1;
+    }
+}
+// ProverBase::construct_proof() as shipped, in one call (in the shim-linked build: MSM / FFT on the GPU through --wrap)
+int refp_construct_proof_reference(void* h)
+{
+    try {
+        auto* s = (Session*)h;
+        s->construct_proof_reference();
+        s->proof = s->export_proof();
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+// bbg_shim::ResidentKey for this session's proving key (once per circuit); seconds, or < 0 without the shim
+double refp_resident_key_create(void* h)
+{
+    try {
+        return ((Session*)h)->resident_key_create();
+    } catch (const std::exception& e) {
+        ((Session*)h)->error = e.what();
+        return -2;
+    }
+}
+// bbg_shim::construct_proof: the whole proof with every O(n) step on the device.  replay (may be NULL): count x 4 limbs of blinding
+// scalars to use instead of fr::random_element().  Returns seconds, < 0 on error (refp_last_error).
+double refp_construct_proof_resident(void* h, const uint64_t* replay, size_t count)
+{
+    auto* s = (Session*)h;
+    try {
+        const double t = s->construct_proof_resident(replay, count);
+        if (t >= 0) s->proof = s->export_proof();
+        return t;
+    } catch (const std::exception& e) {
+        s->error = e.what();
+        return -2;
+    }
+}
+int refp_resident_check_key(void* h)
+{
+    try {
+        return ((Session*)h)->resident_check_key();
+    } catch (const std::exception& e) {
+        ((Session*)h)->error = e.what();
+        return -2;
+    }
+}
+const char* refp_last_error(void* h) { return ((Session*)h)->error.c_str(); }
+
+// io::read_transcript_g1 (srs/io.cpp:134-162), the reference's own transcript reader: out = degree x 8 limbs
+int refio_read_transcript_g1(const char* dir, size_t degree, uint64_t* out)
+{
+    try {
+        std::vector<g1::affine_element> monomials(degree);
+        barretenberg::io::read_transcript_g1(monomials.data(), degree, dir);
+        std::memcpy(out, (const void*)monomials.data(), degree * 64);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
 
 } // extern "C"
 
@@ -365,9 +598,9 @@ struct WidgetHarness {
         return t;
     }
     WidgetHarness(Session* s)
-        : key(s->prover->key.get())
-        , random_widgets(&s->prover->random_widgets)
-        , transition_widgets(&s->prover->transition_widgets)
+        : key(s->view().key.get())
+        , random_widgets(&s->view().random_widgets)
+        , transition_widgets(&s->view().transition_widgets)
         , transcript(dummy_transcript(waffle::TurboComposer::create_manifest(0), waffle::turbo_settings::hash_type,
                                       waffle::turbo_settings::num_challenge_bytes, 4, true))
     {}
@@ -502,12 +735,12 @@ int refp_round4_begin(void* h, const uint64_t** poly_ptrs, uint64_t* challenges,
 {
     try {
         auto* s = (Session*)h;
-        auto& p = *s->prover;
+        auto p = s->view();
         auto* key = p.key.get();
         p.queue.flush_queue();
         p.transcript.apply_fiat_shamir("alpha");
         for (int k = 0; k < 21; k++) {
-            polynomial* poly = find_poly(s->prover->key.get(), ROUND4_LABELS[k]);
+            polynomial* poly = find_poly(p.key.get(), ROUND4_LABELS[k]);
             if (!poly) return -1;
             poly_ptrs[k] = (const uint64_t*)&(*poly)[0];
         }
@@ -529,7 +762,7 @@ int refp_round4_begin(void* h, const uint64_t** poly_ptrs, uint64_t* challenges,
 int refp_round4_reference_quotient(void* h)
 {
     try {
-        auto& p = *((Session*)h)->prover;
+        auto p = ((Session*)h)->view();
         auto* key = p.key.get();
         fr alpha_base = fr::serialize_from_buffer(p.transcript.get_challenge("alpha").begin());
         for (auto& widget : p.random_widgets) alpha_base = widget->compute_quotient_contribution(alpha_base, p.transcript);
@@ -545,7 +778,7 @@ int refp_round4_reference_quotient(void* h)
 int refp_round4_end(void* h)
 {
     try {
-        ((Session*)h)->prover->compute_quotient_pre_commitment();
+        ((Session*)h)->compute_quotient_pre_commitment();
         return 0;
     } catch (...) {
         return -1;
@@ -564,7 +797,7 @@ extern "C" int refp_round3_probe(void* h, uint64_t* wires /* 4 x n x 4 */, uint6
 {
     try {
         auto* s = (Session*)h;
-        auto& p = *s->prover;
+        auto p = s->view();
         auto* key = p.key.get();
         const size_t n = key->n;
         for (int k = 0; k < 4; k++) {
@@ -572,7 +805,7 @@ extern "C" int refp_round3_probe(void* h, uint64_t* wires /* 4 x n x 4 */, uint6
             std::memcpy(wires + (size_t)k * n * 4, (const void*)&key->wire_ffts.at("w_" + idx + "_fft")[0], n * 32);
             std::memcpy(sigmas + (size_t)k * n * 4, (const void*)&key->permutation_selectors_lagrange_base.at("sigma_" + idx)[0], n * 32);
         }
-        p.execute_third_round(); // applies Fiat-Shamir "beta" first, then the widgets' compute_round_commitments
+        s->execute_round(3); // applies Fiat-Shamir "beta" first, then the widgets' compute_round_commitments
         fr beta = fr::serialize_from_buffer(p.transcript.get_challenge("beta").begin());
         fr gamma = fr::serialize_from_buffer(p.transcript.get_challenge("beta", 1).begin());
         fr vals[5] = { beta, gamma, fr::coset_generator(0), fr::coset_generator(1), fr::coset_generator(2) };
@@ -597,7 +830,7 @@ int refp_round3_begin(void* h, const uint64_t** wire_ptrs, const uint64_t** sigm
 {
     try {
         auto* s = (Session*)h;
-        auto& p = *s->prover;
+        auto p = s->view();
         auto* key = p.key.get();
         p.queue.flush_queue();
         p.transcript.apply_fiat_shamir("beta");
@@ -621,7 +854,7 @@ int refp_round3_begin(void* h, const uint64_t** wire_ptrs, const uint64_t** sigm
 int refp_round3_end(void* h)
 {
     try {
-        auto& p = *((Session*)h)->prover;
+        auto p = ((Session*)h)->view();
         polynomial& z = p.witness->wires.at("z");
         p.queue.add_to_queue({ waffle::work_queue::WorkType::SCALAR_MULTIPLICATION, z.get_coefficients(), "Z", fr(0), 0 });
         p.queue.add_to_queue({ waffle::work_queue::WorkType::FFT, nullptr, "z", fr(0), 0 });
@@ -649,7 +882,7 @@ int refp_round6_with(void* h, refp_opening_cb cb, void* user)
 {
     try {
         auto* s = (Session*)h;
-        auto& p = *s->prover;
+        auto p = s->view();
         auto* key = p.key.get();
         auto* witness = p.witness.get();
         p.queue.flush_queue();

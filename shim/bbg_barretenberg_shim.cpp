@@ -45,25 +45,40 @@ using barretenberg::fr;
 using barretenberg::g1;
 using barretenberg::scalar_multiplication::pippenger_runtime_state;
 
+// Device copies of Pippenger point tables, keyed by the table's ADDRESS.  Two kinds of entry:
+//   registered  by bbg_shim_register_point_table from the place that owns the table (Pippenger / ReferenceString construction,
+//               pippenger.cpp:7-25) and dropped by bbg_shim_unregister_point_table from its destructor (:33-36): the owner vouches
+//               for the lifetime, lookups never touch host memory.
+//   implicit    a table first seen inside pippenger*() of a build that calls neither hook.  Nothing announces its death, so an entry
+//               remembers sampled points and is reused only when every sample INSIDE THE RANGE THE CURRENT CALL PASSES (memory the
+//               caller guarantees readable right now -- freed or unmapped memory is never probed) still matches; at most
+//               MAX_IMPLICIT of them are kept (least recently used goes first), and tables below MIN_CACHED_POINTS -- the
+//               verifier's per-proof element table, verifier.cpp:165-170 -- are uploaded, used and freed within the call.
 struct ShimState {
+    static constexpr size_t MAX_IMPLICIT = 4, MIN_CACHED_POINTS = 4096, SAMPLES = 1024;
     std::mutex mu;
     bbg_ctx* ctx = nullptr;
     struct Entry {
-        const g1::affine_element* base;
-        size_t n;
-        bbg_srs* srs;
-        // The cache is keyed by the table's ADDRESS, so an entry must notice when that table has been freed and its memory
-        // reused (a later, different table may start inside the old range): 64 evenly spaced points are remembered at
-        // registration and compared with host memory on every lookup (4 KiB of memcmp); any difference drops the entry.
-        std::vector<std::pair<size_t, g1::affine_element>> samples;
-        bool still_valid() const
+        const g1::affine_element* base = nullptr;
+        size_t n = 0;
+        bbg_srs* srs = nullptr;
+        bool registered = false;
+        uint64_t last_use = 0;
+        std::vector<std::pair<size_t, g1::affine_element>> samples; // implicit entries only
+        // true iff at least one sample lies in [from, from + count) and all of those match the host table
+        bool range_still_matches(size_t from, size_t count) const
         {
-            for (const auto& sm : samples)
+            bool any = false;
+            for (const auto& sm : samples) {
+                if (sm.first < from || sm.first >= from + count) continue;
                 if (std::memcmp((const void*)&base[2 * sm.first], (const void*)&sm.second, sizeof(g1::affine_element)) != 0) return false;
-            return true;
+                any = true;
+            }
+            return any;
         }
     };
     std::map<const g1::affine_element*, Entry> tables; // keyed by table base pointer (get_monomials() identity)
+    uint64_t clock = 0;
     ~ShimState()
     {
         for (auto& kv : tables) bbg_srs_free(kv.second.srs);
@@ -85,56 +100,103 @@ bbg_ctx* context()
     if (!s.ctx && bbg_init(0, &s.ctx) != BBG_OK) fail("bbg_init");
     return s.ctx;
 }
-// Finds (or uploads) the device copy of the point table that `points` points into; returns the SRS handle and the
-// index of points[0] in it.  The table is uploaded once per base pointer and grown if a later call reaches further.
-bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t& from)
+bbg_srs* upload(const g1::affine_element* points, size_t num_points)
+{
+    bbg_srs* srs = nullptr;
+    if (bbg_srs_register(context(), reinterpret_cast<const uint64_t*>(points), num_points, sizeof(g1::affine_element) * 2, &srs) != BBG_OK)
+        fail("bbg_srs_register");
+    return srs;
+}
+// the entry whose table contains `points`, or end()
+std::map<const g1::affine_element*, ShimState::Entry>::iterator containing(const g1::affine_element* points)
 {
     ShimState& s = state();
-    bbg_ctx* ctx = context();
     auto it = s.tables.upper_bound(points);
-    if (it != s.tables.begin()) {
-        --it;
+    if (it == s.tables.begin()) return s.tables.end();
+    --it;
+    return (size_t)(points - it->second.base) < 2 * it->second.n ? it : s.tables.end();
+}
+void drop(std::map<const g1::affine_element*, ShimState::Entry>::iterator it)
+{
+    bbg_srs_free(it->second.srs);
+    state().tables.erase(it);
+}
+// owner-announced table: uploaded once, valid until bbg_shim_unregister_point_table
+bbg_srs* register_table(const g1::affine_element* table, size_t num_points)
+{
+    ShimState& s = state();
+    auto it = s.tables.find(table);
+    if (it != s.tables.end()) {
+        if (it->second.registered && it->second.n >= num_points) return it->second.srs;
+        drop(it); // an implicit entry at this address, or a shorter registration: replace
+    }
+    ShimState::Entry e;
+    e.base = table;
+    e.n = num_points;
+    e.srs = upload(table, num_points);
+    e.registered = true;
+    s.tables[table] = std::move(e);
+    return s.tables[table].srs;
+}
+// Device SRS for an MSM over points[0 .. 2 num_points); *from = index of points[0] in it; *transient = the caller frees it after use.
+bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t& from, bool& transient)
+{
+    ShimState& s = state();
+    transient = false;
+    auto it = containing(points);
+    bool registered_but_short = false;
+    if (it != s.tables.end()) {
         ShimState::Entry& e = it->second;
         const size_t off = (size_t)(points - e.base);
-        const bool inside = off < 2 * e.n;
-        if (inside && !e.still_valid()) { // the table this entry described is gone: forget it
-            bbg_srs_free(e.srs);
-            s.tables.erase(it);
-        } else {
-            if (off % 2 == 0 && off / 2 + num_points <= e.n) {
-                from = off / 2;
-                return e.srs;
-            }
-            if (off == 0) { // same table, longer prefix requested: re-register
-                bbg_srs_free(e.srs);
-                s.tables.erase(it);
-            }
+        if (off % 2 == 0 && off / 2 + num_points <= e.n && (e.registered || e.range_still_matches(off / 2, num_points))) {
+            e.last_use = ++s.clock;
+            from = off / 2;
+            return e.srs;
         }
+        // an implicit entry that no longer describes this memory, or that is too short: forget it.  A REGISTERED table that is
+        // asked for more points than were announced is the owner's contract broken -- serve the call from a transient copy.
+        registered_but_short = e.registered;
+        if (!e.registered) drop(it);
     }
-    bbg_srs* srs = nullptr;
-    if (bbg_srs_register(ctx, reinterpret_cast<const uint64_t*>(points), num_points, sizeof(g1::affine_element) * 2, &srs) != BBG_OK)
-        fail("bbg_srs_register");
-    ShimState::Entry entry{ points, num_points, srs, {} };
-    const size_t step = num_points > 64 ? num_points / 64 : 1;
-    for (size_t i = 0; i < num_points; i += step) entry.samples.emplace_back(i, points[2 * i]);
-    entry.samples.emplace_back(num_points - 1, points[2 * (num_points - 1)]);
-    s.tables[points] = std::move(entry);
     from = 0;
-    return srs;
+    if (num_points < ShimState::MIN_CACHED_POINTS || registered_but_short) {
+        transient = true;
+        return upload(points, num_points);
+    }
+    size_t implicit = 0;
+    auto oldest = s.tables.end();
+    for (auto jt = s.tables.begin(); jt != s.tables.end(); ++jt) {
+        if (jt->second.registered) continue;
+        implicit++;
+        if (oldest == s.tables.end() || jt->second.last_use < oldest->second.last_use) oldest = jt;
+    }
+    if (implicit >= ShimState::MAX_IMPLICIT) drop(oldest);
+    ShimState::Entry e;
+    e.base = points;
+    e.n = num_points;
+    e.srs = upload(points, num_points);
+    e.last_use = ++s.clock;
+    const size_t step = num_points > ShimState::SAMPLES ? num_points / ShimState::SAMPLES : 1;
+    for (size_t i = 0; i < num_points; i += step) e.samples.emplace_back(i, points[2 * i]);
+    e.samples.emplace_back(num_points - 1, points[2 * (num_points - 1)]);
+    s.tables[points] = std::move(e);
+    return s.tables[points].srs;
 }
 g1::element msm(fr* scalars, g1::affine_element* points, size_t n)
 {
     std::lock_guard<std::mutex> lk(state().mu);
     g1::element out;
-    size_t from = 0;
-    bbg_srs* srs = n ? lookup_srs(points, n, from) : nullptr;
     if (n == 0) {
         out = g1::one;
         out.self_set_infinity();
         return out;
     }
-    if (bbg_msm(context(), srs, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out)) != BBG_OK)
-        fail("bbg_msm");
+    size_t from = 0;
+    bool transient = false;
+    bbg_srs* srs = lookup_srs(points, n, from, transient);
+    const int rc = bbg_msm(context(), srs, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out));
+    if (transient) bbg_srs_free(srs);
+    if (rc != BBG_OK) fail("bbg_msm");
     return out;
 }
 void ntt(fr* coeffs, const evaluation_domain& d, int op, const fr* constant)
@@ -152,13 +214,36 @@ void ntt(fr* coeffs, const evaluation_domain& d, int op, const fr* constant)
 #define SHIM_NAME(mangled) asm("__wrap_" mangled)
 #endif
 
-// Explicit registration hook for the place that owns the table (Pippenger / FileReferenceString construction,
-// pippenger.cpp:7-25): uploads once, before the first proof.
+// Lifetime hooks for the place that owns the table (Pippenger / ReferenceString construction and destruction,
+// pippenger.cpp:7-25, :33-36): upload once before the first proof, release with the table.
 extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num_points)
 {
     std::lock_guard<std::mutex> lk(state().mu);
-    size_t from;
-    (void)lookup_srs(static_cast<const g1::affine_element*>(endo_table), num_points, from);
+    (void)register_table(static_cast<const g1::affine_element*>(endo_table), num_points);
+}
+extern "C" void bbg_shim_unregister_point_table(const void* endo_table)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    auto it = state().tables.find(static_cast<const g1::affine_element*>(endo_table));
+    if (it != state().tables.end()) drop(it);
+}
+// For the resident prover (shim/bbg_resident_prover.hpp): the shim's device context, and the device SRS of a table its owner has
+// announced (registers it if it has not been: the caller -- a ResidentKey -- holds the proving key and with it the reference string).
+extern "C" bbg_ctx* bbg_shim_context(void)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    return context();
+}
+extern "C" bbg_srs* bbg_shim_srs_for(const void* endo_table, size_t num_points)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    return register_table(static_cast<const g1::affine_element*>(endo_table), num_points);
+}
+// number of cached device tables (tests: bounded cache, transient tables not retained)
+extern "C" size_t bbg_shim_cached_tables(void)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    return state().tables.size();
 }
 
 namespace bbg_shim {
