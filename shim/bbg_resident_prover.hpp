@@ -137,6 +137,15 @@ class ResidentKey {
 
 namespace detail {
 
+// scalars[id] += c.  (barretenberg's field has a user-provided default constructor that leaves the limbs UNINITIALISED, so
+// std::map::operator[] must not be used to create an entry.)
+inline void accumulate(std::map<int, fr>& scalars, int id, const fr& c)
+{
+    auto it = scalars.find(id);
+    if (it == scalars.end()) scalars.emplace(id, c);
+    else it->second += c;
+}
+
 template <typename T> const uint64_t* limbs(const T& v)
 {
     return reinterpret_cast<const uint64_t*>(&v);
@@ -175,7 +184,7 @@ bool linear_scalars_of(waffle::widget::TransitionWidgetBase<fr>* base, Prover& p
         const fr c = MonomialKernel::sum_linear_terms(probe, challenges, linear_terms, 0);
         probe.coefficients[info.index] = &zero;
         if (c == fr::zero()) continue;
-        scalars[device_poly_id(info.index)] += c;
+        accumulate(scalars, device_poly_id(info.index), c);
     }
     alpha_base = MonomialGetter::update_alpha(challenges, FFTKernel::num_independent_relations);
     return true;
@@ -202,8 +211,8 @@ template <size_t program_width, typename Prover> fr permutation_linear_scalars(P
     for (size_t i = 0; i + 1 < program_width; ++i)
         sigma_term *= (w[i] + gamma + beta * fr::serialize_from_buffer(&t.get_element("sigma_" + std::to_string(i + 1))[0]));
     const fr m_sigma = -(sigma_term * alpha) * beta;
-    scalars[BBG_QP_Z] += m_z;
-    scalars[BBG_QP_SIGMA_1 + (int)program_width - 1] += m_sigma;
+    accumulate(scalars, BBG_QP_Z, m_z);
+    accumulate(scalars, BBG_QP_SIGMA_1 + (int)program_width - 1, m_sigma);
     return alpha.sqr().sqr();
 }
 
