@@ -111,6 +111,17 @@ def load_library():
         "bbg_prover_linearise": (cint, [vp, sz, vp, vp, vp, vp]),
         "bbg_prover_round6": (cint, [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
         "bbg_prover_read_poly": (cint, [vp, cint, cint, vp, sz]),
+        "bbg_multi_create": (cint, [vp, cint, ctypes.POINTER(vp)]),
+        "bbg_multi_destroy": (None, [vp]),
+        "bbg_multi_count": (cint, [vp]),
+        "bbg_multi_ctx": (vp, [vp, cint]),
+        "bbg_multi_sync": (cint, [vp]),
+        "bbg_multi_srs_register": (cint, [vp, vp, sz, sz]),
+        "bbg_multi_srs_synth_hashed": (cint, [vp, ctypes.c_uint64, sz]),
+        "bbg_multi_srs_num_points": (sz, [vp]),
+        "bbg_multi_msm": (cint, [vp, vp, sz, sz, vp]),
+        "bbg_multi_ntt_device": (cint, [vp, vp, ctypes.c_uint, cint]),
+        "bbg_multi_ntt": (cint, [vp, vp, ctypes.c_uint, cint]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here == a symbol declared in bbg.h is not exported
@@ -131,6 +142,8 @@ EXPORTED_SYMBOLS = [
     "bbg_srs_write_transcript", "bbg_transcript_checksum",
     "bbg_prover_create", "bbg_prover_destroy", "bbg_prover_set_key_poly", "bbg_prover_finalize_key", "bbg_prover_round1", "bbg_prover_round3",
     "bbg_prover_round4", "bbg_prover_evaluate", "bbg_prover_linearise", "bbg_prover_round6", "bbg_prover_read_poly",
+    "bbg_multi_create", "bbg_multi_destroy", "bbg_multi_count", "bbg_multi_ctx", "bbg_multi_sync", "bbg_multi_srs_register",
+    "bbg_multi_srs_synth_hashed", "bbg_multi_srs_num_points", "bbg_multi_msm", "bbg_multi_ntt_device", "bbg_multi_ntt",
 ]
 
 

@@ -139,6 +139,8 @@ int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* 
 int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st);
 int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t roots_cut, hipStream_t st);
 int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base, hipStream_t stream);
+int ntt_scale_geometric(bbg_ctx* ctx, void* d_a, size_t count, unsigned log2n, int which_base, uint64_t step, uint64_t e0, int mul_inv_log2,
+                        hipStream_t st);
 int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t* out, hipStream_t stream);
 int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hipStream_t stream);
 int ntt_cross_dft(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse, hipStream_t stream);

@@ -1,0 +1,378 @@
+// Multi-GPU inside the library (include/bbg.h, "bbg_multi_*"): one MSM or one (coset) NTT spread over several contexts of ONE
+// process -- one context per GPU of the node (several contexts may share a device, which is how this is tested on a one-GPU box).
+// SURVEY.md 8e:
+//
+//   MSM   point-range shards, the reference's own decomposition for large MSMs (Pippenger::pippenger_unsafe(scalars, from, range)
+//         + g1_sum, pippenger.cpp:27-31, c_bind.cpp:31-46): context g holds SRS points [g*per, (g+1)*per) with their window tables
+//         resident, runs the full bucket MSM over its slice of the scalars; the G 96-byte partials are collected and summed on
+//         context 0.  No arithmetic exchange: the only traffic between GPUs is G x 96 bytes.
+//   NTT   residue classes + ONE all-to-all (the reference's precedent is the 4-way coset split, polynomial_arithmetic.cpp:401-456):
+//         context g transforms a_{g + G j} (size m = n / G), multiplies by w_n^(g q); chunk r of every context goes to context r
+//         (peer copies over xGMI: (G-1)/G^2 of the data leaves each GPU); context r finishes with size-G DFTs across the chunks.
+//
+// The process-per-GPU form of the same split (torch.distributed / RCCL, what bench.py --gpus N runs) is aztec-2.0_amd/parallel.py;
+// both call the same kernels.  Peer copies (hipMemcpyPeerAsync) are the natural primitive for 96-byte partials and for an
+// all-to-all inside one process; they are ordered with events, never with host synchronisation between the phases.
+#include "bbg_internal.h"
+
+#include <cstring>
+#include <thread>
+
+using namespace bbg;
+
+struct bbg_multi {
+    int G = 0;
+    std::vector<bbg_ctx*> ctx;
+    std::vector<bbg_srs*> srs;
+    std::vector<size_t> shard_from, shard_n;
+    size_t srs_n = 0;
+    // per context scratch
+    std::vector<void*> d_scal;   // MSM: this context's slice of the scalars
+    std::vector<size_t> d_scal_bytes;
+    std::vector<void*> d_part;   // MSM: 96-byte partial
+    std::vector<void*> d_x, d_recv, d_out; // NTT: shard, received chunks, cross-DFT output
+    std::vector<size_t> ntt_bytes;
+    std::vector<char*> h_stage;  // NTT host path: pinned residue-class staging
+    std::vector<size_t> h_stage_bytes;
+    std::vector<hipEvent_t> ev_sent, ev_done;
+    std::vector<bool> ev_done_valid;
+    char* h_parts = nullptr;     // pinned: G x 96 bytes
+    std::mutex mu;
+};
+
+namespace {
+
+int set_dev(bbg_ctx* c)
+{
+    BBG_HIP(hipSetDevice(c->device));
+    return BBG_OK;
+}
+// runs fn(g) for every context on its own host thread (uploads from pageable memory block their caller; one thread per GPU keeps
+// every PCIe link busy); returns the first error with its message
+template <typename F> int for_each_ctx(bbg_multi* m, F fn)
+{
+    std::vector<int> rc((size_t)m->G, BBG_OK);
+    std::vector<std::string> msg((size_t)m->G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < m->G; g++)
+        th.emplace_back([&, g]() {
+            rc[(size_t)g] = fn(g);
+            if (rc[(size_t)g]) msg[(size_t)g] = bbg_last_error();
+        });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < m->G; g++)
+        if (rc[(size_t)g]) {
+            set_error("context " + std::to_string(g) + ": " + msg[(size_t)g]);
+            return rc[(size_t)g];
+        }
+    return BBG_OK;
+}
+int log2_exact(size_t v)
+{
+    int l = 0;
+    while (((size_t)1 << l) < v) l++;
+    return ((size_t)1 << l) == v ? l : -1;
+}
+void free_srs(bbg_multi* m)
+{
+    for (auto& s : m->srs) {
+        if (s) bbg_srs_free(s);
+        s = nullptr;
+    }
+    m->srs_n = 0;
+}
+int ensure_ntt_buffers(bbg_multi* m, size_t bytes)
+{
+    for (int g = 0; g < m->G; g++) {
+        if (m->ntt_bytes[(size_t)g] >= bytes) continue;
+        int rc = set_dev(m->ctx[(size_t)g]);
+        if (rc) return rc;
+        BBG_HIP(hipDeviceSynchronize());
+        for (void** b : { &m->d_x[(size_t)g], &m->d_recv[(size_t)g], &m->d_out[(size_t)g] }) {
+            if (*b) BBG_HIP(hipFree(*b));
+            *b = nullptr;
+            BBG_HIP(hipMalloc(b, bytes));
+        }
+        m->ntt_bytes[(size_t)g] = bytes;
+    }
+    return BBG_OK;
+}
+
+// The device-resident transform: d_shards[g] = residue class g (a_{g + G j}, j < m) on context g, in place.
+// After the call shard r holds A[t*m + r*len + q] at index t*len + q (t < G, q < len = m / G): G contiguous runs of the natural-order
+// result, run t starting at natural index t*m + r*len.
+int multi_ntt_core(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
+{
+    const int G = m->G, log2G = log2_exact((size_t)G);
+    if (log2G < 0 || log2G > 3) { set_error("bbg_multi_ntt: the number of contexts must be 1, 2, 4 or 8"); return BBG_E_INVALID; }
+    if (op < BBG_FFT || op > BBG_COSET_IFFT) { set_error("bbg_multi_ntt: op must be fft, ifft, coset_fft or coset_ifft"); return BBG_E_INVALID; }
+    if (log2n > 28 || log2n < (unsigned)(2 * log2G)) { set_error("bbg_multi_ntt: need 2 log2(G) <= log2n <= 28"); return BBG_E_INVALID; }
+    const bool inverse = (op == BBG_IFFT || op == BBG_COSET_IFFT), coset = (op == BBG_COSET_FFT || op == BBG_COSET_IFFT);
+    const unsigned log2m = log2n - (unsigned)log2G;
+    const size_t mm = (size_t)1 << log2m, len = mm >> log2G;
+    if (G == 1) { // one context: the plain transform
+        int rc = set_dev(m->ctx[0]);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(m->ctx[0]->mu);
+        return ntt_run(m->ctx[0], d_shards[0], log2n, op, 0, nullptr, m->ctx[0]->stream);
+    }
+    int rc = ensure_ntt_buffers(m, mm * 32);
+    if (rc) return rc;
+    // phase 1 (every context, asynchronous): coset factors, local transform, twiddles, peer copies of the chunks
+    for (int g = 0; g < G; g++) {
+        bbg_ctx* c = m->ctx[(size_t)g];
+        rc = set_dev(c);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(c->mu);
+        hipStream_t st = c->stream;
+        void* x = d_shards[g];
+        // the receive buffers of the previous transform must have been consumed before anything is sent again
+        for (int r = 0; r < G; r++)
+            if (m->ev_done_valid[(size_t)r]) BBG_HIP(hipStreamWaitEvent(st, m->ev_done[(size_t)r], 0));
+        if (coset && !inverse) rc = ntt_scale_geometric(c, x, mm, log2n, 0 /* g */, (uint64_t)G, (uint64_t)g, -1, st); // a_{g+Gj} *= gen^(g+Gj)
+        if (!rc) rc = ntt_run(c, x, log2m, inverse ? BBG_IFFT : BBG_FFT, 0, nullptr, st);
+        // x[q] *= w_n^(+-g q); the inverse also owes the factor 1/G (the local ifft divided by m only)
+        if (!rc && (g != 0 || inverse)) rc = ntt_scale_geometric(c, x, mm, log2n, inverse ? 3 : 2, (uint64_t)g, 0, inverse ? log2G : -1, st);
+        if (rc) return rc;
+        for (int r = 0; r < G; r++) // chunk r -> context r, slot g
+            BBG_HIP(hipMemcpyPeerAsync((char*)m->d_recv[(size_t)r] + (size_t)g * len * 32, m->ctx[(size_t)r]->device, (const char*)x + (size_t)r * len * 32,
+                                       c->device, len * 32, st));
+        BBG_HIP(hipEventRecord(m->ev_sent[(size_t)g], st));
+    }
+    // phase 2: size-G DFT across the received chunks, the coset_ifft post-scaling, result back into the shard
+    for (int r = 0; r < G; r++) {
+        bbg_ctx* c = m->ctx[(size_t)r];
+        rc = set_dev(c);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(c->mu);
+        hipStream_t st = c->stream;
+        for (int g = 0; g < G; g++) BBG_HIP(hipStreamWaitEvent(st, m->ev_sent[(size_t)g], 0));
+        rc = ntt_cross_dft(c, m->d_recv[(size_t)r], m->d_out[(size_t)r], (unsigned)log2G, len, log2n, inverse ? 1 : 0, st);
+        if (rc) return rc;
+        BBG_HIP(hipEventRecord(m->ev_done[(size_t)r], st));
+        m->ev_done_valid[(size_t)r] = true;
+        if (coset && inverse) // coset_ifft: a_j *= g^-j over the natural index j = t*m + r*len + q (polynomial_arithmetic.cpp:480-484)
+            for (int t = 0; t < G && !rc; t++)
+                rc = ntt_scale_geometric(c, (char*)m->d_out[(size_t)r] + (size_t)t * len * 32, len, log2n, 1 /* g^-1 */, 1, (uint64_t)t * mm + (uint64_t)r * len, -1, st);
+        if (rc) return rc;
+        BBG_HIP(hipMemcpyAsync(d_shards[r], m->d_out[(size_t)r], mm * 32, hipMemcpyDeviceToDevice, st));
+    }
+    return BBG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int bbg_multi_create(const int* devices, int count, bbg_multi** out)
+{
+    if (!devices || !out || count < 1 || count > 64) { set_error("bbg_multi_create: bad argument"); return BBG_E_INVALID; }
+    bbg_multi* m = new bbg_multi;
+    m->G = count;
+    const size_t G = (size_t)count;
+    m->ctx.assign(G, nullptr);
+    m->srs.assign(G, nullptr);
+    m->shard_from.assign(G, 0);
+    m->shard_n.assign(G, 0);
+    m->d_scal.assign(G, nullptr);
+    m->d_scal_bytes.assign(G, 0);
+    m->d_part.assign(G, nullptr);
+    m->d_x.assign(G, nullptr);
+    m->d_recv.assign(G, nullptr);
+    m->d_out.assign(G, nullptr);
+    m->ntt_bytes.assign(G, 0);
+    m->h_stage.assign(G, nullptr);
+    m->h_stage_bytes.assign(G, 0);
+    m->ev_sent.assign(G, nullptr);
+    m->ev_done.assign(G, nullptr);
+    m->ev_done_valid.assign(G, false);
+    int rc = BBG_OK;
+    for (int g = 0; g < count && !rc; g++) {
+        rc = bbg_init(devices[g], &m->ctx[(size_t)g]);
+        hipError_t e = hipSuccess;
+        if (!rc) e = hipMalloc(&m->d_part[(size_t)g], 96);
+        if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_sent[(size_t)g], hipEventDisableTiming);
+        if (!rc && e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_done[(size_t)g], hipEventDisableTiming);
+        if (!rc && e != hipSuccess) rc = hip_fail(e, "bbg_multi_create", __FILE__, __LINE__);
+    }
+    // direct peer access between distinct devices (xGMI); failure is not fatal: peer copies then stage through the host
+    for (int a = 0; a < count && !rc; a++)
+        for (int b = 0; b < count; b++)
+            if (devices[a] != devices[b]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[a]);
+                    (void)hipDeviceEnablePeerAccess(devices[b], 0);
+                    (void)hipGetLastError(); // "already enabled" is fine
+                }
+            }
+    if (!rc && hipHostMalloc((void**)&m->h_parts, G * 96, hipHostMallocDefault) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipHostMalloc", __FILE__, __LINE__);
+    if (rc) {
+        bbg_multi_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return BBG_OK;
+}
+
+void bbg_multi_destroy(bbg_multi* m)
+{
+    if (!m) return;
+    free_srs(m);
+    for (int g = 0; g < m->G; g++) {
+        bbg_ctx* c = m->ctx[(size_t)g];
+        if (!c) continue;
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        for (void* b : { m->d_scal[(size_t)g], m->d_part[(size_t)g], m->d_x[(size_t)g], m->d_recv[(size_t)g], m->d_out[(size_t)g] })
+            if (b) (void)hipFree(b);
+        if (m->h_stage[(size_t)g]) (void)hipHostFree(m->h_stage[(size_t)g]);
+        if (m->ev_sent[(size_t)g]) (void)hipEventDestroy(m->ev_sent[(size_t)g]);
+        if (m->ev_done[(size_t)g]) (void)hipEventDestroy(m->ev_done[(size_t)g]);
+        bbg_destroy(c);
+    }
+    if (m->h_parts) (void)hipHostFree(m->h_parts);
+    delete m;
+}
+
+int bbg_multi_count(const bbg_multi* m) { return m ? m->G : 0; }
+bbg_ctx* bbg_multi_ctx(bbg_multi* m, int k) { return (m && k >= 0 && k < m->G) ? m->ctx[(size_t)k] : nullptr; }
+
+int bbg_multi_srs_register(bbg_multi* m, const uint64_t* points, size_t n, size_t stride_bytes)
+{
+    if (!m || (!points && n)) { set_error("bbg_multi_srs_register: null argument"); return BBG_E_INVALID; }
+    if (stride_bytes != 64 && stride_bytes != 128) { set_error("bbg_multi_srs_register: stride_bytes must be 64 or 128"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    free_srs(m);
+    const size_t per = (n + (size_t)m->G - 1) / (size_t)m->G;
+    int rc = for_each_ctx(m, [&](int g) {
+        const size_t from = std::min(n, (size_t)g * per), cnt = std::min(per, n - from);
+        m->shard_from[(size_t)g] = from;
+        m->shard_n[(size_t)g] = cnt;
+        return bbg_srs_register(m->ctx[(size_t)g], (const uint64_t*)((const char*)points + from * stride_bytes), cnt, stride_bytes, &m->srs[(size_t)g]);
+    });
+    if (rc) {
+        free_srs(m);
+        return rc;
+    }
+    m->srs_n = n;
+    return BBG_OK;
+}
+
+int bbg_multi_srs_synth_hashed(bbg_multi* m, uint64_t seed, size_t n)
+{
+    if (!m) { set_error("bbg_multi_srs_synth_hashed: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    free_srs(m);
+    const size_t per = (n + (size_t)m->G - 1) / (size_t)m->G;
+    int rc = for_each_ctx(m, [&](int g) {
+        const size_t from = std::min(n, (size_t)g * per), cnt = std::min(per, n - from);
+        m->shard_from[(size_t)g] = from;
+        m->shard_n[(size_t)g] = cnt;
+        return bbg_srs_synth_hashed(m->ctx[(size_t)g], seed + from, cnt, &m->srs[(size_t)g]); // P_i = mix64(seed + i) G: a shard is the same generator offset
+    });
+    if (rc) {
+        free_srs(m);
+        return rc;
+    }
+    m->srs_n = n;
+    return BBG_OK;
+}
+
+size_t bbg_multi_srs_num_points(const bbg_multi* m) { return m ? m->srs_n : 0; }
+
+int bbg_multi_msm(bbg_multi* m, const uint64_t* scalars, size_t from, size_t n, uint64_t out_jacobian[12])
+{
+    if (!m || (!scalars && n) || !out_jacobian) { set_error("bbg_multi_msm: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (from > m->srs_n || n > m->srs_n - from) { set_error("bbg_multi_msm: range [from, from+n) exceeds the registered SRS"); return BBG_E_INVALID; }
+    int rc = for_each_ctx(m, [&](int g) {
+        bbg_ctx* c = m->ctx[(size_t)g];
+        int r = set_dev(c);
+        if (r) return r;
+        const size_t sf = m->shard_from[(size_t)g], sn = m->shard_n[(size_t)g];
+        const size_t lo = std::max(from, sf), hi = std::min(from + n, sf + sn);
+        const size_t cnt = hi > lo ? hi - lo : 0;
+        std::lock_guard<std::mutex> lkc(c->mu);
+        hipStream_t st = c->stream;
+        if (cnt) {
+            r = ensure_buffer(&m->d_scal[(size_t)g], &m->d_scal_bytes[(size_t)g], cnt * 32);
+            if (r) return r;
+            BBG_HIP(hipMemcpyAsync(m->d_scal[(size_t)g], scalars + (lo - from) * 4, cnt * 32, hipMemcpyHostToDevice, st));
+        }
+        r = msm_run(c, m->srs[(size_t)g]->s, m->d_scal[(size_t)g], cnt ? lo - sf : 0, cnt, m->d_part[(size_t)g], st); // cnt == 0 -> infinity
+        if (!r) r = msm_join(c, st);
+        if (r) return r;
+        BBG_HIP(hipMemcpyAsync(m->h_parts + (size_t)g * 96, m->d_part[(size_t)g], 96, hipMemcpyDeviceToHost, st));
+        BBG_HIP(hipStreamSynchronize(st));
+        return (int)BBG_OK;
+    });
+    if (rc) return rc;
+    return bbg_g1_sum(m->ctx[0], (const uint64_t*)m->h_parts, (size_t)m->G, out_jacobian); // g1_sum of the partials (c_bind.cpp:39-46)
+}
+
+int bbg_multi_ntt_device(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
+{
+    if (!m || !d_shards) { set_error("bbg_multi_ntt_device: null argument"); return BBG_E_INVALID; }
+    for (int g = 0; g < m->G; g++)
+        if (!d_shards[g]) { set_error("bbg_multi_ntt_device: null shard"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    return multi_ntt_core(m, d_shards, log2n, op);
+}
+
+int bbg_multi_sync(bbg_multi* m)
+{
+    if (!m) { set_error("bbg_multi_sync: null argument"); return BBG_E_INVALID; }
+    for (int g = 0; g < m->G; g++) {
+        int rc = bbg_sync(m->ctx[(size_t)g]);
+        if (rc) return rc;
+    }
+    return BBG_OK;
+}
+
+int bbg_multi_ntt(bbg_multi* m, uint64_t* coeffs, unsigned log2n, int op)
+{
+    if (!m || !coeffs) { set_error("bbg_multi_ntt: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    const int G = m->G, log2G = log2_exact((size_t)G);
+    if (log2G < 0 || log2G > 3 || log2n > 28 || log2n < (unsigned)(2 * log2G)) { set_error("bbg_multi_ntt: need 1, 2, 4 or 8 contexts and 2 log2(G) <= log2n <= 28"); return BBG_E_INVALID; }
+    const size_t n = (size_t)1 << log2n, mm = n >> log2G, len = mm >> log2G;
+    int rc = ensure_ntt_buffers(m, mm * 32);
+    if (rc) return rc;
+    // residue class g, gathered on the host into pinned staging by context g's thread, then one upload per context
+    rc = for_each_ctx(m, [&](int g) {
+        bbg_ctx* c = m->ctx[(size_t)g];
+        int r = set_dev(c);
+        if (r) return r;
+        if (m->h_stage_bytes[(size_t)g] < mm * 32) {
+            if (m->h_stage[(size_t)g]) BBG_HIP(hipHostFree(m->h_stage[(size_t)g]));
+            m->h_stage[(size_t)g] = nullptr;
+            BBG_HIP(hipHostMalloc((void**)&m->h_stage[(size_t)g], mm * 32, hipHostMallocDefault));
+            m->h_stage_bytes[(size_t)g] = mm * 32;
+        }
+        uint64_t* stage = (uint64_t*)m->h_stage[(size_t)g];
+        for (size_t j = 0; j < mm; j++) memcpy(stage + 4 * j, coeffs + 4 * ((size_t)g + (size_t)G * j), 32);
+        BBG_HIP(hipMemcpyAsync(m->d_x[(size_t)g], stage, mm * 32, hipMemcpyHostToDevice, c->stream));
+        return (int)BBG_OK;
+    });
+    if (rc) return rc;
+    rc = multi_ntt_core(m, m->d_x.data(), log2n, op);
+    if (rc) return rc;
+    // G contiguous runs of the natural-order result per context
+    return for_each_ctx(m, [&](int r_) {
+        bbg_ctx* c = m->ctx[(size_t)r_];
+        int r = set_dev(c);
+        if (r) return r;
+        if (G == 1) {
+            BBG_HIP(hipMemcpyAsync(coeffs, m->d_x[0], n * 32, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            for (int t = 0; t < G; t++)
+                BBG_HIP(hipMemcpyAsync(coeffs + 4 * ((size_t)t * mm + (size_t)r_ * len), (const char*)m->d_x[(size_t)r_] + (size_t)t * len * 32, len * 32,
+                                       hipMemcpyDeviceToHost, c->stream));
+        }
+        BBG_HIP(hipStreamSynchronize(c->stream));
+        return (int)BBG_OK;
+    });
+}
+
+} // extern "C"

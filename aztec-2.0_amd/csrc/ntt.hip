@@ -719,6 +719,52 @@ int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* star
     return BBG_OK;
 }
 
+// pow2[b] = (base^step)^(2^b) and *start = (mul ? *mul : 1) * base^e0: set-up of a geometric scaling whose base and offsets are
+// device-resident domain constants (the sharded NTT's coset factors g^(r + G j) and twiddles w_n^(r q), multi.hip)
+__global__ void k_geometric_setup(Fr* pow2, Fr* start, const Fr* base, uint64_t step, uint64_t e0, const Fr* mul)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Fr b = *base;
+    auto pw = [&](uint64_t e) {
+        Fr acc = Fr::one(), x = b;
+        while (e) {
+            if (e & 1) acc = fe_mul(acc, x);
+            x = fe_sqr(x);
+            e >>= 1;
+        }
+        return acc;
+    };
+    Fr s = pw(e0);
+    if (mul) s = fe_mul(s, *mul);
+    *start = fe_reduce_once(s);
+    Fr a = fe_reduce_once(pw(step));
+    for (int i = 0; i < 32; i++) {
+        pow2[i] = a;
+        a = fe_reduce_once(fe_sqr(a));
+    }
+}
+// a[j] *= mul * base^(e0 + step * j), j < count; which_base: 0 = coset generator g, 1 = g^-1, 2 = w_n (root of the 2^log2n domain),
+// 3 = w_n^-1; mul_inv_log2 >= 0: mul = (2^mul_inv_log2)^-1, else 1.  Asynchronous on st.
+int ntt_scale_geometric(bbg_ctx* ctx, void* d_a, size_t count, unsigned log2n, int which_base, uint64_t step, uint64_t e0, int mul_inv_log2,
+                        hipStream_t st)
+{
+    if (!d_a || which_base < 0 || which_base > 3) { set_error("ntt_scale_geometric: bad argument"); return BBG_E_INVALID; }
+    if (count == 0) return BBG_OK;
+    NttDomain *dp = nullptr, *dm = nullptr, *d0 = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (!rc) rc = build_domain(ctx, 0, &d0); // lends its scratch table
+    if (!rc && mul_inv_log2 >= 0) rc = build_domain(ctx, (unsigned)mul_inv_log2, &dm);
+    if (rc) return rc;
+    DomainConsts* dc = (DomainConsts*)dp->consts;
+    DomainConsts* sc = (DomainConsts*)d0->consts;
+    const Fr* base = which_base == 0 ? &dc->gen : which_base == 1 ? &dc->gen_inv : which_base == 2 ? &dc->root : &dc->root_inv;
+    const Fr* mul = dm ? &((DomainConsts*)dm->consts)->n_inv : nullptr;
+    hipLaunchKernelGGL(k_geometric_setup, dim3(1), dim3(64), 0, st, sc->pow2_tmp, &sc->gk, base, step, e0, mul);
+    hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((count + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d_a, sc->pow2_tmp, (const Fr*)&sc->gk, count);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
 // out = w_n^e (forward root of the 2^log2n domain; inverse != 0 -> its inverse), returned to the host
 int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t* out, hipStream_t st)
 {

@@ -269,6 +269,35 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
 /* Copies a resident polynomial back (tests; a host that wants the reference's post-proof state): id / form as above. */
 int bbg_prover_read_poly(bbg_prover* p, int id, int form, uint64_t* out, size_t count);
 
+/* ---- several GPUs in one process: one MSM / one (coset) NTT spread over a group of contexts, one per device of the node
+ *      (device indices may repeat: several contexts on one GPU, which is how the split is tested on a single-GPU box).
+ *      MSM: point-range shards as in Pippenger::pippenger_unsafe(scalars, from, range) + g1_sum (pippenger.cpp:27-31, c_bind.cpp:31-46);
+ *      only G x 96 bytes cross between GPUs.  NTT: residue classes + ONE all-to-all over peer copies (xGMI) + size-G DFTs.
+ *      The process-per-GPU form of the same split (torch.distributed / RCCL) is aztec-2.0_amd/parallel.py. ---- */
+typedef struct bbg_multi bbg_multi;
+int bbg_multi_create(const int* devices, int count, bbg_multi** out);
+void bbg_multi_destroy(bbg_multi* m);
+int bbg_multi_count(const bbg_multi* m);
+bbg_ctx* bbg_multi_ctx(bbg_multi* m, int k); /* context k of the group (for the *_device entry points on its GPU) */
+int bbg_multi_sync(bbg_multi* m);
+/* Shards the SRS by point range: context g keeps points [g*ceil(n/G), (g+1)*ceil(n/G)) with their window tables resident.
+ * points / stride_bytes as bbg_srs_register.  Replaces a previously registered SRS. */
+int bbg_multi_srs_register(bbg_multi* m, const uint64_t* points, size_t n, size_t stride_bytes);
+/* The hashed synthetic SRS of bbg_srs_synth_hashed(seed, n), every shard generated on its own GPU. */
+int bbg_multi_srs_synth_hashed(bbg_multi* m, uint64_t seed, size_t n);
+size_t bbg_multi_srs_num_points(const bbg_multi* m);
+/* result = sum_{i<n} scalars[i] * P_{from+i}: every context runs the bucket MSM over its part of the range (scalars uploaded in
+ * parallel, one host thread per GPU), the 96-byte partials are summed on context 0.  Same contract as bbg_msm. */
+int bbg_multi_msm(bbg_multi* m, const uint64_t* scalars, size_t from, size_t n, uint64_t out_jacobian[12]);
+/* op: BBG_FFT, BBG_IFFT, BBG_COSET_FFT or BBG_COSET_IFFT over the whole 2^log2n domain; G = 1, 2, 4 or 8 contexts.
+ * Device-resident, asynchronous: d_shards[g] (on context g's GPU) holds the residue class a_{g + G j}, j < m = n / G; on return (after
+ * bbg_multi_sync) shard r holds A[t*m + r*len + q] at index t*len + q (t < G, q < len = m / G), i.e. G contiguous runs of the
+ * natural-order result.  One all-to-all of (G-1)/G^2 of the data per GPU, no host synchronisation between the phases. */
+int bbg_multi_ntt_device(bbg_multi* m, void* const* d_shards, unsigned log2n, int op);
+/* Host-buffer form, in place on coeffs[2^log2n] in natural order (residue classes gathered on the host by one thread per GPU; bound by
+ * that gather and PCIe, not by the GPUs -- the resident form above is the one to build a multi-GPU prover on). */
+int bbg_multi_ntt(bbg_multi* m, uint64_t* coeffs, unsigned log2n, int op);
+
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
  * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (bucket window width: 0 = automatic [20 bits from n = 2^21 terms,

@@ -25,6 +25,7 @@
 // FFTs are in place on coeffs[domain.size]; `pippenger_runtime_state` is accepted and ignored (the scratch arena lives
 // on the device); a failing call throws std::runtime_error like throw_or_abort (common/throw_or_abort.hpp:5-13).
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -79,8 +80,17 @@ struct ShimState {
     };
     std::map<const g1::affine_element*, Entry> tables; // keyed by table base pointer (get_monomials() identity)
     uint64_t clock = 0;
+    // Several GPUs: an MSM of at least multi_min points over a cached table is sharded by point range over the device group
+    // (bbg_multi_msm).  BBG_SHIM_DEVICES = comma-separated device indices (repeats allowed) or "all" (default when more than
+    // one device is visible); BBG_SHIM_MULTI_MIN_POINTS = threshold (default 2^22: below it one GPU finishes before the others start).
+    bbg_multi* multi = nullptr;
+    bool multi_probed = false;
+    size_t multi_min = (size_t)1 << 22;
+    const g1::affine_element* multi_table = nullptr; // the table whose shards the group currently holds
+    size_t multi_points = 0;
     ~ShimState()
     {
+        if (multi) bbg_multi_destroy(multi);
         for (auto& kv : tables) bbg_srs_free(kv.second.srs);
         if (ctx) bbg_destroy(ctx);
     }
@@ -100,6 +110,30 @@ bbg_ctx* context()
     if (!s.ctx && bbg_init(0, &s.ctx) != BBG_OK) fail("bbg_init");
     return s.ctx;
 }
+bbg_multi* device_group()
+{
+    ShimState& s = state();
+    if (s.multi_probed) return s.multi;
+    s.multi_probed = true;
+    std::vector<int> devices;
+    const char* env = std::getenv("BBG_SHIM_DEVICES");
+    if (env && std::string(env) != "all") {
+        for (const char* p = env; *p;) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+    } else {
+        const int n = bbg_device_count();
+        if (n > 1 || env)
+            for (int d = 0; d < n; d++) devices.push_back(d);
+    }
+    if (const char* mn = std::getenv("BBG_SHIM_MULTI_MIN_POINTS")) s.multi_min = (size_t)std::strtoull(mn, nullptr, 10);
+    if (devices.size() > 1 && bbg_multi_create(devices.data(), (int)devices.size(), &s.multi) != BBG_OK) fail("bbg_multi_create");
+    return s.multi;
+}
 bbg_srs* upload(const g1::affine_element* points, size_t num_points)
 {
     bbg_srs* srs = nullptr;
@@ -118,6 +152,7 @@ std::map<const g1::affine_element*, ShimState::Entry>::iterator containing(const
 }
 void drop(std::map<const g1::affine_element*, ShimState::Entry>::iterator it)
 {
+    if (state().multi_table == it->second.base) state().multi_table = nullptr; // its shards are re-uploaded if the address is seen again
     bbg_srs_free(it->second.srs);
     state().tables.erase(it);
 }
@@ -194,6 +229,22 @@ g1::element msm(fr* scalars, g1::affine_element* points, size_t n)
     size_t from = 0;
     bool transient = false;
     bbg_srs* srs = lookup_srs(points, n, from, transient);
+    if (!transient) {
+        bbg_multi* group = device_group();
+        if (group && n >= state().multi_min) { // large MSM over a cached table: every GPU of the group takes a point range
+            ShimState& s = state();
+            auto it = containing(points);
+            const ShimState::Entry& e = it->second;
+            if (s.multi_table != e.base || s.multi_points != e.n) {
+                if (bbg_multi_srs_register(group, reinterpret_cast<const uint64_t*>(e.base), e.n, sizeof(g1::affine_element) * 2) != BBG_OK)
+                    fail("bbg_multi_srs_register");
+                s.multi_table = e.base;
+                s.multi_points = e.n;
+            }
+            if (bbg_multi_msm(group, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out)) != BBG_OK) fail("bbg_multi_msm");
+            return out;
+        }
+    }
     const int rc = bbg_msm(context(), srs, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out));
     if (transient) bbg_srs_free(srs);
     if (rc != BBG_OK) fail("bbg_msm");

@@ -22,6 +22,10 @@
 
 using namespace barretenberg;
 
+extern "C" size_t bbg_shim_cached_tables(void);
+extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num_points);
+extern "C" void bbg_shim_unregister_point_table(const void* endo_table);
+
 #define REAL(m) asm("__real_" m)
 namespace real {
 g1::element pippenger_unsafe(fr*, g1::affine_element*, const size_t, scalar_multiplication::pippenger_runtime_state&)
@@ -193,6 +197,53 @@ int main(int argc, char** argv)
         polynomial_arithmetic::divide_by_pseudo_vanishing_polynomial(a.data(), small, large, 4);
         real::divide_by_pseudo_vanishing_polynomial(b.data(), small, large, 4);
         expect(same(a, b), "divide_by_pseudo_vanishing_polynomial(4n coset, 4 roots cut)");
+    }
+    { // lifetime of the device copies of point tables (shim/bbg_barretenberg_shim.cpp: registered / implicit / transient)
+        expect(bbg_shim_cached_tables() == 1, "the table seen inside pippenger is cached once (implicit entry)");
+        const size_t small_n = 64; // a verifier-sized table: uploaded, used and freed within the call
+        g1::affine_element* small_table = scalar_multiplication::point_table_alloc<g1::affine_element>(small_n);
+        for (size_t i = 0; i < small_n; i++) small_table[i] = table[2 * (i + 5)];
+        scalar_multiplication::generate_pippenger_point_table(small_table, small_table, small_n);
+        scalar_multiplication::pippenger_runtime_state small_rs(small_n);
+        g1::element g = scalar_multiplication::pippenger(scalars.data(), small_table, small_n, small_rs, true);
+        g1::element c = real::pippenger(scalars.data(), small_table, small_n, small_rs, true);
+        expect(g1::affine_element(g) == g1::affine_element(c) && bbg_shim_cached_tables() == 1, "a small table is served from a transient copy (not retained)");
+        aligned_free(small_table);
+        // owner-announced lifetime: register, use (also through a sub-range), unregister
+        const size_t reg_n = n / 2;
+        g1::affine_element* reg_table = scalar_multiplication::point_table_alloc<g1::affine_element>(reg_n);
+        for (size_t i = 0; i < reg_n; i++) reg_table[i] = table[2 * (n - 1 - i)];
+        scalar_multiplication::generate_pippenger_point_table(reg_table, reg_table, reg_n);
+        bbg_shim_register_point_table(reg_table, reg_n);
+        expect(bbg_shim_cached_tables() == 2, "registered table cached");
+        scalar_multiplication::pippenger_runtime_state reg_rs(reg_n);
+        g = scalar_multiplication::pippenger_unsafe(scalars.data(), reg_table + 2 * 7, reg_n - 7, reg_rs);
+        c = real::pippenger_unsafe(scalars.data(), reg_table + 2 * 7, reg_n - 7, reg_rs);
+        expect(g1::affine_element(g) == g1::affine_element(c), "MSM over a sub-range of a registered table");
+        bbg_shim_unregister_point_table(reg_table);
+        expect(bbg_shim_cached_tables() == 1, "unregister drops the device copy");
+        // the same memory, new contents, nobody told the shim: the stale implicit entry must not be used
+        for (size_t i = 0; i < reg_n; i++) reg_table[i] = table[2 * i];
+        scalar_multiplication::generate_pippenger_point_table(reg_table, reg_table, reg_n);
+        g = scalar_multiplication::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs); // implicit entry #2
+        for (size_t i = 0; i < reg_n; i++) reg_table[i] = table[2 * (i + 1 < n ? i + 1 : i)];
+        scalar_multiplication::generate_pippenger_point_table(reg_table, reg_table, reg_n);
+        g = scalar_multiplication::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs);
+        c = real::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs);
+        expect(g1::affine_element(g) == g1::affine_element(c), "a table rewritten in place is re-uploaded (sampled validation inside the call's own range)");
+        // many tables without hooks: the implicit cache stays bounded
+        std::vector<g1::affine_element*> many;
+        for (int t = 0; t < 7; t++) {
+            g1::affine_element* tb = scalar_multiplication::point_table_alloc<g1::affine_element>(reg_n);
+            for (size_t i = 0; i < reg_n; i++) tb[i] = table[2 * ((i + 3 * (size_t)t + 2) % n)];
+            scalar_multiplication::generate_pippenger_point_table(tb, tb, reg_n);
+            g = scalar_multiplication::pippenger_unsafe(scalars.data(), tb, reg_n, reg_rs);
+            many.push_back(tb);
+        }
+        c = real::pippenger_unsafe(scalars.data(), many.back(), reg_n, reg_rs);
+        expect(g1::affine_element(g) == g1::affine_element(c) && bbg_shim_cached_tables() <= 4, "implicit cache bounded (least recently used entries go)");
+        for (auto* tb : many) aligned_free(tb);
+        aligned_free(reg_table);
     }
     aligned_free(table);
     std::printf(failures ? "shim_check FAILED (%d)\n" : "shim_check PASS\n", failures);

@@ -776,6 +776,12 @@ def test_shim_reference_api_on_gpu():
     r = subprocess.run([exe, "14"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and "shim_check PASS" in out, out
+    # the same binary with the device group switched on: four contexts (all on device 0 here; one per GPU on a node), every MSM of
+    # >= 1000 points over a cached table is sharded by point range through bbg_multi_msm behind pippenger_unsafe
+    env = dict(os.environ, BBG_SHIM_DEVICES="0,0,0,0", BBG_SHIM_MULTI_MIN_POINTS="1000")
+    r = subprocess.run([exe, "14"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "shim_check PASS" in out, out
 
 
 def test_bench_contract_and_dist_path():
@@ -1117,3 +1123,109 @@ def test_prover_handle_error_paths(pkg, bbg):
     assert lib.bbg_prover_evaluate(h, 2, ids, None, ch[0].ctypes.data, ev.ctypes.data) != 0                 # unknown polynomial id
     lib.bbg_prover_destroy(h)
     srs.free()
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU inside the library
+class _Multi:
+    def __init__(self, pkg, devices):
+        self.lib = pkg.load_library()
+        self.pkg = pkg
+        arr = (ctypes.c_int * len(devices))(*devices)
+        self.h = ctypes.c_void_p()
+        rc = self.lib.bbg_multi_create(arr, len(devices), ctypes.byref(self.h))
+        if rc != 0:
+            raise pkg.BbgError(self.lib.bbg_last_error().decode())
+
+    def ck(self, rc):
+        if rc != 0:
+            raise self.pkg.BbgError(self.lib.bbg_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.bbg_multi_destroy(self.h)
+            self.h = None
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 4, 8])
+def test_multi_msm_point_range_shards(pkg, oracle, bbg, golden, G):
+    """bbg_multi_msm with G contexts (all on device 0 here; one per GPU on a node): point-range shards + the g1 sum of the 96-byte
+    partials reproduce the single-context MSM, the oracle, the reference's recorded results, (from, range) sub-ranges that straddle
+    shard boundaries, and the empty MSM."""
+    M = _Multi(pkg, [0] * G)
+    try:
+        n = 1 << 16
+        M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, 0xBB254, n))
+        assert M.lib.bbg_multi_srs_num_points(M.h) == n and M.lib.bbg_multi_count(M.h) == G
+        out = np.zeros(12, dtype=np.uint64)
+
+        def run(sc, start=0):
+            s = np.ascontiguousarray(sc, dtype=np.uint64)
+            M.ck(M.lib.bbg_multi_msm(M.h, s.ctypes.data, start, s.shape[0], out.ctypes.data))
+            return out.copy()
+        for rec in golden["msm"]:
+            if rec["srs"] != "hashed" or rec["from"] + rec["n"] > n or rec.get("scalar_kind") == "mixed":
+                continue
+            sc = pkg.synthetic_scalars(rec["scalar_seed"], rec["n"])
+            assert np.array_equal(oracle.jac_to_affine(run(sc, rec["from"])), unhex(rec["result"], 8)[0]), (G, rec["n"], rec["from"])
+        sc = pkg.synthetic_scalars(99, 30000)
+        srs = bbg.srs_synth_hashed(0xBB254, n)
+        for start in (0, 1, n // G - 7 if G > 1 else 5, n - 30000):
+            assert np.array_equal(oracle.jac_to_affine(run(sc, start)), oracle.jac_to_affine(bbg.msm(srs, sc, start=start))), (G, start)
+        srs.free()
+        assert int(run(sc[:0])[3]) >> 63 == 1
+        with pytest.raises(pkg.BbgError):
+            run(sc, n - 100)
+        # a caller-supplied table (the reference's interleaved endomorphism layout), ragged against G
+        pts = oracle.srs_hashed(77, 1001)
+        table = oracle.point_table(pts)  # keep the array alive across the call
+        M.ck(M.lib.bbg_multi_srs_register(M.h, table.ctypes.data, 1001, 128))
+        sc = pkg.synthetic_scalars(5, 1001)
+        assert np.array_equal(oracle.jac_to_affine(run(sc)), oracle.pippenger(sc, pts)), G
+    finally:
+        M.close()
+
+
+@pytest.mark.parametrize("G,lg", [(1, 10), (2, 11), (4, 12), (8, 13), (8, 16), (4, 4)])
+def test_multi_ntt_all_to_all(pkg, oracle, bbg, G, lg):
+    """bbg_multi_ntt (host form) and bbg_multi_ntt_device (resident residue-class shards, peer-copy all-to-all, size-G DFT) for
+    fft / ifft / coset_fft / coset_ifft against the oracle's whole transform."""
+    import torch
+    M = _Multi(pkg, [0] * G)
+    try:
+        n = 1 << lg
+        a = pkg.synthetic_scalars(3100 + lg + G, n)
+        for op in (FFT, IFFT, COSET_FFT, COSET_IFFT):
+            want = oracle.ntt(a, op)
+            buf = a.copy()
+            M.ck(M.lib.bbg_multi_ntt(M.h, buf.ctypes.data, lg, op))
+            assert np.array_equal(oracle.canon(0, buf), want), (G, lg, op, "host form")
+            # resident form: shard g = residue class g; result in G runs per shard
+            m, length = n // G, n // G // G
+            shards = [torch.from_numpy(np.ascontiguousarray(a[g::G]).view(np.int64).reshape(-1)).cuda() for g in range(G)]
+            torch.cuda.synchronize()
+            ptrs = (ctypes.c_void_p * G)(*[t.data_ptr() for t in shards])
+            M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, op))
+            M.ck(M.lib.bbg_multi_sync(M.h))
+            got = np.zeros((n, 4), dtype=np.uint64)
+            for r in range(G):
+                o = shards[r].cpu().numpy().view(np.uint64).reshape(G, length, 4) if G > 1 else shards[r].cpu().numpy().view(np.uint64).reshape(1, n, 4)
+                for t in range(G):
+                    got[t * m + r * length: t * m + (r + 1) * length] = o[t]
+            assert np.array_equal(oracle.canon(0, got), want), (G, lg, op, "resident form")
+        with pytest.raises(pkg.BbgError):
+            M.ck(M.lib.bbg_multi_ntt(M.h, a.ctypes.data, lg, 4))  # only the four whole-domain transforms
+    finally:
+        M.close()
+
+
+def test_multi_rejects_bad_groups(pkg, bbg):
+    M = _Multi(pkg, [0, 0, 0])
+    a = pkg.synthetic_scalars(1, 64)
+    with pytest.raises(pkg.BbgError):
+        M.ck(M.lib.bbg_multi_ntt(M.h, a.ctypes.data, 6, 0))  # 3 contexts: not a power of two
+    out = np.zeros(12, dtype=np.uint64)
+    with pytest.raises(pkg.BbgError):
+        M.ck(M.lib.bbg_multi_msm(M.h, a.ctypes.data, 0, 64, out.ctypes.data))  # no SRS registered
+    M.close()
+    with pytest.raises(pkg.BbgError):
+        _Multi(pkg, [99])
