@@ -9,4 +9,3 @@ Nothing in this package imports or calls anything under ``oracle/`` (the checker
 """
 from .binding import Bbg, BbgError, LIB_PATH, build_library, load_library  # noqa: F401
 from .inputs import splitmix64_limbs, synthetic_scalars  # noqa: F401
-from . import prover_engine  # noqa: F401

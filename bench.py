@@ -58,6 +58,29 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_counter(kernel, counter):
+    """Sum over the kernel's variants of one counter's average per dispatch (KiB for FETCH_SIZE / WRITE_SIZE), or None."""
+    try:
+        tot, seen = 0.0, False
+        for line in open(PMC_PROFILE):
+            f = line.split()
+            if len(f) >= 4 and any(kernel in tok for tok in f[:-3]) and f[-3] == counter:
+                tot += float(f[-1])
+                seen = True
+        return tot if seen else None
+    except OSError:
+        return None
+
+
+def pmc_traffic_ntt():
+    """HBM bytes of ONE whole NTT (both pass kernels, one launch each) from the committed PMC passes.  The passes stream wide
+    coalesced rows, the case for which MI355X_MICROARCH.md prescribes FETCH_SIZE x 2 on gfx950; WRITE_SIZE is taken as reported."""
+    fetch, write = pmc_counter("k_ntt_pass8", "FETCH_SIZE"), pmc_counter("k_ntt_pass8", "WRITE_SIZE")
+    if fetch is None or write is None:
+        return None
+    return round((2.0 * fetch + write) * 1024.0)
+
+
 # The contract is ONE JSON line on stdout.  Native libraries (RCCL prints "Librccl path : ..." when a process group comes up)
 # write to file descriptor 1 behind Python's back, so fd 1 is pointed at stderr for the whole run and the JSON line goes to
 # a saved duplicate of the original stdout.
@@ -72,6 +95,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks", type=int, default=5, help="the timed block of --steps steps is repeated this many times; the MEDIAN block is reported")
+    ap.add_argument("--no-config5", action="store_true", help="skip extra.config5 (one 2^24 MSM + one 2^24 coset NTT, strong scaling)")
+    ap.add_argument("--no-prover-shaped", action="store_true", help="skip extra.prover_shaped (BASELINE config 4 on the resident prover rounds)")
+    ap.add_argument("--config5-log2n", type=int, default=24)
     ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, 16 or 20 (A/B runs)")
     args = ap.parse_args()
 
@@ -141,20 +168,28 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if pipe is not None:
-        pipe.count = 0
-    bbg.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = {k: bbg.profile_get(k) for k in ("msm_recode", "msm_sort", "msm_offsets", "msm_accumulate", "msm_reduce", "ntt_pass")}
-    bbg.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # The timed block: EXACTLY --steps steps between two fences (barrier + synchronize), max over ranks.  It is repeated --blocks
+    # times and the MEDIAN block is the one reported (value, ms_per_step and the per-kernel event times all come from it): a single
+    # 37 ms block moves by +-4 % from run to run.
+    blocks = []
+    for _ in range(max(1, args.blocks)):
+        if pipe is not None:
+            pipe.count = 0
+        bbg.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        pr = {k: bbg.profile_get(k) for k in ("msm_recode", "msm_sort", "msm_offsets", "msm_accumulate", "msm_reduce", "ntt_pass")}
+        bbg.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        blocks.append((el, pr))
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+    elapsed, prof = blocks[order[len(order) // 2]]
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * n / (elapsed / args.steps) / 1e6
 
@@ -182,8 +217,13 @@ def main():
         "msm_phase_ms": {k: round(prof[k][0] / args.steps, 4) for k in prof if k.startswith("msm_")},
         "roofline_ntt": {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": round(ntt_alg / (pass_ms * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ntt_alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": None, "avg_launch_ms": round(pass_ms, 4), "launches_per_ntt": ntt_passes,
+                         "traffic": (pmc_traffic_ntt() / max(1.0, ntt_passes)) if pmc_traffic_ntt() else None,
+                         "traffic_whole_ntt": pmc_traffic_ntt(),
+                         "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (2 x FETCH_SIZE + WRITE_SIZE of the k_ntt_pass8 launches of one NTT: the "
+                                           "guide's gfx950 correction for wide coalesced streams)",
+                         "avg_launch_ms": round(pass_ms, 4), "launches_per_ntt": ntt_passes,
                          "whole_ntt_frac": round(ntt_alg / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        "timed_blocks_ms": [round(b[0] * 1e3, 3) for b in blocks], "reported_block": "median",
         "alu": {"unit": "T v_mad_u64_u32/s", "peak_measured": MAD_PEAK_TOPS,
                 # 16 windows x n mixed additions x 10 Fq mul x 136 mads ; n/2*(lg - passes) + n*(passes-1) Fr mul x 136
                 "msm_accumulate": round(16.0 * n * 10 * 136 / (acc_ms * 1e-3) / 1e12, 2),
@@ -206,13 +246,171 @@ def main():
     # ---- CPU baseline + bit-exact check against it (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, value)
+    # ---- BASELINE config 4 (TurboPLONK prover sequence) on the resident prover rounds, one GPU
+    if rank == 0 and world == 1 and not args.no_prover_shaped and lg >= 10:
+        extra["prover_shaped"] = prover_shaped(pkg, bbg, srs, lg)
+        if "cpu_baseline" in out and out["cpu_baseline"].get("kind") == "reference":
+            ref_ms = reference_prover_sequence(srs, scalars, coeffs, lg)
+            out["cpu_baseline"]["prover_shaped_ms"] = ref_ms
+            extra["prover_shaped"]["reference_same_sequence_ms"] = ref_ms["total_ms"]
+            extra["prover_shaped"]["speedup_vs_reference_sequence"] = round(ref_ms["total_ms"] / extra["prover_shaped"]["proof_ms"], 1)
+    # ---- BASELINE config 5: ONE 2^24 MSM + ONE 2^24 coset NTT over the N GPUs (strong scaling: total work fixed as N grows)
+    if not args.no_config5:
+        srs.free()
+        srs = None
+        c5 = config5(pkg, par, bbg, dist, dev, rank, world, args.config5_log2n)
+        if rank == 0:
+            extra["config5"] = c5
     if rank == 0:
         sys.stdout.flush()
         os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())
-    srs.free()
+    if srs is not None:
+        srs.free()
     bbg.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
+    """One 2^lg MSM (point-range shards, all-gather of the 96-byte partials + group sum) and one 2^lg coset NTT (residue-class
+    shards, one all-to-all, size-N DFT) over the N ranks; inputs resident; max over ranks; best of `steps`."""
+    import torch
+    n = 1 << lg
+    start, count = par.shard_range(n, rank, world)
+    srs = bbg.srs_synth_hashed(SEED + start, count)
+    mask = torch.tensor([-1, -1, -1, 0x0FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + 24 + rank)
+    d_scalars = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device=dev, generator=gen) & mask
+    m = n // world
+    d_x = torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, device=dev, generator=gen) & mask
+    d_scalars, d_x = d_scalars.reshape(-1), d_x.reshape(-1)
+    pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev))
+    ops = par.BbgNttOps(bbg)
+    five = np.array([[5, 0, 0, 0]], dtype=np.uint64)
+    shift = bbg.field_op(0, 5, five)[0]  # the coset generator 5 in Montgomery form (fr.hpp:44-59)
+    bbg.ntt_prepare(lg - (world.bit_length() - 1))
+    work = d_x.clone()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def msm_step():
+        pipe.count = 0
+        pipe.submit(d_scalars, count)
+        pipe.flush()
+
+    def ntt_step():
+        work.copy_(d_x)
+        if world > 1:
+            par.ntt_sharded(ops, dist, work, lg, coset_shift=shift)
+        else:
+            bbg.ntt_device(work.data_ptr(), lg, 2)
+
+    def best(fn):
+        fn()
+        fence()
+        ts = []
+        for _ in range(steps):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            fence()
+            t = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([t], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = float(tt.item())
+            ts.append(t)
+        return min(ts)
+
+    t_msm, t_ntt = best(msm_step), best(ntt_step)
+    srs.free()
+    return {"workload": "ONE 2^%d-point MSM + ONE 2^%d coset NTT over %d GPU(s), strong scaling (north_star's split: point-range MSM shards + "
+                        "all-gather of 96-B partials; residue-class NTT shards + one all-to-all)" % (lg, lg, world),
+            "n_gpus": world, "msm_ms": round(t_msm * 1e3, 3), "msm_mscalar_per_s": round(n / t_msm / 1e6, 2),
+            "ntt_ms": round(t_ntt * 1e3, 3), "ntt_gfield_ops_per_s": round(1.5 * n * lg / t_ntt / 1e9, 2),
+            "ntt_includes_input_restore_copy": True,
+            "exchange": {"msm": "all_gather %d x 96 B" % world, "ntt": "all_to_all %.1f MiB per rank" % (32.0 * m * (world - 1) / world / 2**20)}}
+
+
+def prover_shaped(pkg, bbg, srs, lg, reps=5):
+    """BASELINE config 4's sequence -- what one TurboPLONK proof asks of the hot path: 11 MSM(n) + 5 iFFT(n) + 5 coset FFT(4n) +
+    1 coset iFFT(4n) and every O(n) step between them (grand product, five quotient widgets, division by Z*_H, 16 evaluations,
+    linearisation, two opening accumulations, two Kate divisions) -- through the product's resident prover rounds (bbg_prover_*,
+    the entry points shim/bbg_resident_prover.hpp drives from the reference's TurboProver).  Synthetic key / witness polynomials and
+    challenges (timing does not depend on the values); wires go up over PCIe per proof, 11 commitments come down.
+    tests/test_gpu_parity.py runs the same rounds under the reference's real prover and checks the proof byte for byte."""
+    import ctypes
+    lib, n = bbg.lib, 1 << lg
+    to_mont = lambda k: bbg.field_op(0, 5, np.array([[k, 0, 0, 0]], dtype=np.uint64))[0]
+    gens = np.stack([to_mont(5), to_mont(5), to_mont(6), to_mont(7)])
+    h = ctypes.c_void_p()
+    bbg._ck(lib.bbg_prover_create(bbg.ctx, srs.handle, lg, 4, gens.ctypes.data, ctypes.byref(h)))
+    try:
+        for pid in range(5, 20):  # sigma_1..4, q_1..q_5, q_m, q_c, q_arith, q_fixed_base, q_range, q_logic (coefficient forms)
+            a = pkg.synthetic_scalars(SEED + 500 + pid, n)
+            bbg._ck(lib.bbg_prover_set_key_poly(h, pid, 0, a.ctypes.data))
+        t0 = time.perf_counter()
+        bbg._ck(lib.bbg_prover_finalize_key(h))
+        t_key = time.perf_counter() - t0
+        wires = [pkg.synthetic_scalars(SEED + 600 + k, n) for k in range(4)]
+        wp = (ctypes.c_void_p * 4)(*[w.ctypes.data for w in wires])
+        ch = pkg.synthetic_scalars(SEED + 700, 40)
+        com = np.zeros((4, 8), dtype=np.uint64)
+        ev = np.zeros((32, 4), dtype=np.uint64)
+        ids16 = (ctypes.c_int * 16)(0, 0, 1, 1, 2, 2, 3, 3, 4, 15, 16, 17, 5, 6, 7, 21)  # manifest order: w_i, w_i_omega, z_omega, q_c, q_arith, q_ecc_1, sigma_1..3, t
+        sh16 = (ctypes.c_int * 16)(0, 1, 0, 1, 0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0)
+        lin = (ctypes.c_int * 12)(4, 8, 9, 10, 11, 12, 13, 14, 15, 18, 19, 16)
+        at_zeta = (ctypes.c_int * 14)(0, 1, 2, 3, 15, 16, 17, 5, 6, 7, 23, 24, 25, 26)
+        at_omega = (ctypes.c_int * 5)(0, 1, 2, 3, 4)
+        rounds = []
+        for _ in range(reps + 1):
+            t = [time.perf_counter()]
+            bbg._ck(lib.bbg_prover_round1(h, wp, com.ctypes.data)); t.append(time.perf_counter())
+            bbg._ck(lib.bbg_prover_round3(h, ch[0].ctypes.data, ch[1].ctypes.data, ch[2:5].ctypes.data, com.ctypes.data)); t.append(time.perf_counter())
+            bbg._ck(lib.bbg_prover_round4(h, ch[5].ctypes.data, ch[6].ctypes.data, com.ctypes.data)); t.append(time.perf_counter())
+            bbg._ck(lib.bbg_prover_evaluate(h, 16, ids16, sh16, ch[7].ctypes.data, ev.ctypes.data))
+            bbg._ck(lib.bbg_prover_linearise(h, 12, lin, ch[8:20].ctypes.data, ch[7].ctypes.data, ev.ctypes.data)); t.append(time.perf_counter())
+            bbg._ck(lib.bbg_prover_round6(h, 14, at_zeta, ch[20:34].ctypes.data, 5, at_omega, ch[34:39].ctypes.data, ch[7].ctypes.data,
+                                          ch[39].ctypes.data, None, com.ctypes.data, com[1:].ctypes.data)); t.append(time.perf_counter())
+            rounds.append([t[i + 1] - t[i] for i in range(5)])
+        rounds = rounds[1:]  # the first pass allocates scratch and builds tables
+        tot = sorted(sum(r) for r in rounds)
+        med = [sorted(r[i] for r in rounds)[len(rounds) // 2] for i in range(5)]
+        return {"workload": "TurboPLONK prover sequence at n = 2^%d on the resident prover rounds (11 MSM + 5 iFFT + 5 coset FFT(4n) + coset iFFT(4n) + "
+                            "all O(n) round arithmetic); wires uploaded per proof (PCIe-inclusive), commitments downloaded" % lg,
+                "proof_ms": round(tot[len(tot) // 2] * 1e3, 3), "proof_ms_min": round(tot[0] * 1e3, 3), "reps": len(rounds),
+                "round_ms": {"round1_wires_ifft_commit": round(med[0] * 1e3, 3), "round3_z": round(med[1] * 1e3, 3), "round4_quotient": round(med[2] * 1e3, 3),
+                             "round5_evaluate_linearise": round(med[3] * 1e3, 3), "round6_openings": round(med[4] * 1e3, 3)},
+                "key_finalize_ms_once_per_circuit": round(t_key * 1e3, 1)}
+    finally:
+        lib.bbg_prover_destroy(h)
+
+
+def reference_prover_sequence(srs, scalars, coeffs, lg):
+    """The reference binary (oracle/_ref/libbbref.so) on the same MSM / FFT sequence on the host cores, once: 11 pippenger_unsafe(n),
+    5 ifft(n), 5 coset_fft(4n, generator_size n), 1 coset_ifft(4n).  (The O(n) round arithmetic of the reference prover is NOT included:
+    this is the MSM + FFT wall-clock north_star's 10x target refers to.)  CPU baseline leg only."""
+    from oracle.oracle import Ref
+    ref = Ref()
+    n = 1 << lg
+    ctx = ref.msm(srs.read())
+    t_msm = sum(ctx.run(scalars, 0, True)[1] for _ in range(11))
+    ctx.free()
+    dom = ref.domain(lg, 0)
+    t_ifft = sum(dom.run(coeffs, 1)[1] for _ in range(5))
+    dom.free()
+    big = np.zeros((4 * n, 4), dtype=np.uint64)
+    big[:n] = coeffs
+    dom = ref.domain(lg + 2, n)
+    t_cfft = sum(dom.run(big, 2)[1] for _ in range(5))
+    t_cifft = dom.run(big, 3)[1]
+    dom.free()
+    return {"total_ms": round((t_msm + t_ifft + t_cfft + t_cifft) * 1e3, 1), "msm_x11_ms": round(t_msm * 1e3, 1), "ifft_x5_ms": round(t_ifft * 1e3, 1),
+            "coset_fft_4n_x5_ms": round(t_cfft * 1e3, 1), "coset_ifft_4n_ms": round(t_cifft * 1e3, 1), "threads": ref.num_threads()}
 
 
 def cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, gpu_value):

@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+TOOLS = os.path.join(ROOT, "tests", "tools")
+if TOOLS not in sys.path:
+    sys.path.insert(0, TOOLS)
+
 import __graft_entry__ as ge  # noqa: E402
 
 

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import limbs, sha, unhex
+import callback_engines  # tests/tools: Python stand-ins for work-queue callbacks (test tooling)
 
 pytestmark = pytest.mark.gpu
 
@@ -735,7 +736,7 @@ def test_reference_prover_resident_engine(pkg, oracle, bbg):
     pts = oracle.srs_powers(x, (2 << 13) + 1)
     P = RefProver(1 << 13, 12, pts, x, gpu_linked=True)
     srs = bbg.srs_register(P.monomials())
-    proof = P.prove(pkg.prover_engine.ResidentEngine(bbg, srs), check=False)  # (per-item check needs the host copies)
+    proof = P.prove(callback_engines.ResidentEngine(bbg, srs), check=False)  # (per-item check needs the host copies)
     ok = P.verify()
     assert len(proof) > 0 and ok == 1, ("resident engine", len(proof), ok, P.counts)
     srs.free()
@@ -753,7 +754,7 @@ def test_reference_prover_round4_on_gpu(pkg, oracle, bbg):
     P = RefProver(1 << 12, 13, oracle.srs_powers(x, (2 << 12) + 1), x)
     srs = bbg.srs_register(P.monomials())
     # + round 3's z (grand product, blinding, ifft) and round 6's opening polynomials (accumulation + Kate division)
-    proof = P.prove(pkg.prover_engine.Round346Engine(bbg, srs), check=True)
+    proof = P.prove(callback_engines.Round346Engine(bbg, srs), check=True)
     assert P.round4_mismatch == 0 and P.mismatches == 0
     assert len(proof) > 0 and P.verify() == 1
     srs.free()
@@ -793,7 +794,7 @@ def test_bench_contract_and_dist_path():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BBG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "16"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "16", "--config5-log2n", "18"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
@@ -803,6 +804,8 @@ def test_bench_contract_and_dist_path():
         assert key in out, key
     assert out["cpu_baseline"]["gpu_bit_exact_vs_cpu"] is True
     assert out["roofline"]["frac"] > 0 and out["value"] > 0
+    assert len(out["extra"]["timed_blocks_ms"]) == 5 and abs(out["ms_per_step"] * 3 - sorted(out["extra"]["timed_blocks_ms"])[2]) < 1e-2
+    assert out["extra"]["prover_shaped"]["proof_ms"] > 0 and out["extra"]["config5"]["msm_ms"] > 0 and out["extra"]["config5"]["ntt_ms"] > 0
 
 
 @pytest.mark.parametrize("G,lg,inverse,coset", [(2, 12, False, False), (4, 12, False, True), (8, 13, False, False), (8, 12, True, False),
@@ -1064,7 +1067,7 @@ def test_turbo_prover_2_20_gates_on_gpu(pkg, oracle, bbg):
     A = RefProver(gates, 11, pts, x)
     assert A.n == n
     srs = bbg.srs_register(A.monomials())
-    proof = A.prove(pkg.prover_engine.FusedFftEngine(bbg, srs), check=True)
+    proof = A.prove(callback_engines.FusedFftEngine(bbg, srs), check=True)
     assert A.mismatches == 0 and A.counts == [11, 5, 4], (A.mismatches, A.counts)
     assert len(proof) == 1216 and A.verify() == 1
     srs.free()

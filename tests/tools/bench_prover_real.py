@@ -25,6 +25,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import callback_engines  # noqa: E402
 
 
 def main():
@@ -59,7 +61,7 @@ def main():
 
     import ctypes
 
-    eng = pkg.prover_engine.FusedFftEngine(bbg, srs)
+    eng = callback_engines.FusedFftEngine(bbg, srs)
     warm = np.zeros((4 * n, 4), dtype=np.uint64)  # warm-up: scratch allocation, twiddle tables, window tables
     wout = np.zeros(12, dtype=np.uint64)
     eng.msm_raw(warm.ctypes.data, n, wout.ctypes.data)
@@ -75,7 +77,7 @@ def main():
            "mismatching_items": P.mismatches if args.check else None}
     # + round 4's quotient (five widgets, divide_by_pseudo_vanishing, coset_ifft) on the device; selectors resident per key
     P4 = RefProver(gates, 11, pts, x)
-    eng4 = pkg.prover_engine.Round346Engine(bbg, srs)
+    eng4 = callback_engines.Round346Engine(bbg, srs)
     P4.prove(eng4, check=False)  # warm-up proof: uploads the per-key arrays
     P4.free()
     P4 = RefProver(gates, 11, pts, x)
@@ -97,7 +99,7 @@ def main():
         PL.prove()
         t_l = time.perf_counter() - t0
         # shim-linked prover (queue + inline helpers through --wrap) AND round 4 taken over by the engine
-        eng5 = pkg.prover_engine.Round346Engine(bbg, None)
+        eng5 = callback_engines.Round346Engine(bbg, None)
         eng5.queue_via_reference = True
         PB = RefProver(gates, 11, pts, x, gpu_linked=True)
         PB.prove(eng5, check=False)  # warm-up: uploads the per-key arrays
@@ -110,7 +112,7 @@ def main():
                 "round_ms": [round(t * 1e3, 1) for t in PB.t_round], "verified": PB.verify() == 1}
         PB.free()
         # shim-linked prover for the inline helpers, work queue through the callbacks, FFT results resident for round 4
-        eng6 = pkg.prover_engine.ResidentEngine(bbg, srs)
+        eng6 = callback_engines.ResidentEngine(bbg, srs)
         PR = RefProver(gates, 11, pts, x, gpu_linked=True)
         PR.prove(eng6, check=False)
         PR.free()

@@ -1,5 +1,11 @@
-"""Host-side glue that puts libbbg.so behind a PLONK prover's work queue -- the Python mirror of the callbacks a barretenberg
-maintainer writes in C++.  Works on raw host addresses of the prover's own buffers, in place:
+"""TEST TOOLING (not part of the product): Python stand-ins for work-queue callbacks, used to put single pieces of libbbg.so behind the
+reference prover's rounds and compare them with the reference item by item (tests/test_gpu_parity.py, tests/tools/bench_prover_real.py).
+The product's resident prover is C++: shim/bbg_resident_prover.hpp over include/bbg.h's bbg_prover_* (no Python, no torch).
+
+An engine instance belongs to ONE RefProver session (one proving key): its device copies of per-key arrays are keyed by the host
+address inside that session only and die with the engine -- there is no content fingerprinting.
+
+Works on raw host addresses of the prover's own buffers, in place:
 
     msm_raw(scalars, count, out)                    work_queue SCALAR_MULTIPLICATION (work_queue.hpp:218-245) -> bbg_msm
     fft_item_raw(wire, log2n, wire_fft, log2_4n)    work_queue FFT (:252-264)                                 -> bbg_coset_fft_extend
@@ -10,21 +16,17 @@ maintainer writes in C++.  Works on raw host addresses of th
                                                     widgets, divide_by_pseudo_vanishing_polynomial and coset_ifft on the device;
                                                     selector / sigma / L_1 arrays are uploaded once per proving key
 
-Used by tests/test_gpu_parity.py and tests/tools/bench_prover_real.py with the reference's real prover on the other side
-(oracle/ref_prover_driver.cpp).  Nothing here imports the oracle.
 """
 import ctypes
+import os
+import sys
 
 import numpy as np
 
-from . import binding
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import __graft_entry__ as _ge  # noqa: E402
 
-
-def _fingerprint(host_ptr, count):
-    """64 bytes at each of 16 evenly spaced elements of a host array of `count` field elements: recognises an array that has
-    already been uploaded (per proving key) without hashing the whole thing, and notices reused memory."""
-    step = max(count // 16, 1)
-    return b"".join(ctypes.string_at(host_ptr + 32 * i, 64) for i in range(0, max(count - 1, 1), step))
+binding = _ge.load_package().binding
 
 
 class WorkQueueEngine:
@@ -76,9 +78,8 @@ class Round4Engine(FusedFftEngine):
         import torch
         b = self.bbg
         m = 4 << log2n
-        # sigma_1..4, q_*, L_1 on the coset are fixed per proving key (= per circuit): uploaded once and recognised by a
-        # sampled fingerprint, the way an SRS is registered once
-        key = (log2n,) + tuple(_fingerprint(p, m) for p in poly_ptrs[5:])
+        # sigma_1..4, q_*, L_1 on the coset are fixed per proving key: uploaded once per engine (= per session, see the module header)
+        key = (log2n,) + tuple(poly_ptrs[5:])
         if key not in self._static:
             self._static = {key: [self._upload(p, m) for p in poly_ptrs[5:]]}
         wires = [self._upload(p, m) for p in poly_ptrs[:5]]  # w_1..4, z: new for every proof
@@ -106,7 +107,7 @@ class Round34Engine(Round4Engine):
         import torch
         b = self.bbg
         n = 1 << log2n
-        key = (log2n,) + tuple(_fingerprint(p, n) for p in sigma_ptrs)
+        key = (log2n,) + tuple(sigma_ptrs)
         if key not in self._sigma:
             self._sigma = {key: [self._upload(p, n) for p in sigma_ptrs]}
         wires = [self._upload(p, n) for p in wire_ptrs]
@@ -131,8 +132,8 @@ class Round346Engine(Round34Engine):
         self._coeff = {}
 
     def _resident(self, host_ptr, n):
-        """Device copy of a coefficient-form polynomial; cached by (address, leading 256 bytes) for the per-key ones."""
-        fp = (host_ptr, _fingerprint(host_ptr, n))
+        """Device copy of a coefficient-form polynomial of THIS session; `fresh` addresses (per-proof arrays) are never cached."""
+        fp = (host_ptr, n)
         t = self._coeff.get(fp)
         if t is None:
             if len(self._coeff) > 64:

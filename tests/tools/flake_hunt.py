@@ -18,7 +18,7 @@ bbg.set_stream(torch.cuda.current_stream().cuda_stream)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 x = O.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
 pts = O.srs_powers(x, (2 << 13) + 1)
-E = pkg.prover_engine
+import callback_engines as E
 mode = sys.argv[2] if len(sys.argv) > 2 else "default"
 if mode == "ownstream":
     bbg.close()
