@@ -62,6 +62,7 @@ def load_library():
         "bbg_srs_synth_linear": (cint, [vp, ctypes.c_uint64, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
         "bbg_srs_synth_hashed": (cint, [vp, ctypes.c_uint64, sz, ctypes.POINTER(vp)]),
         "bbg_srs_load_transcript": (cint, [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp)]),
+        "bbg_srs_register_transcript_buffer": (cint, [vp, vp, sz, ctypes.POINTER(vp)]),
         "bbg_srs_write_transcript": (cint, [vp, ctypes.c_char_p, sz, vp]),
         "bbg_transcript_checksum": (cint, [vp, sz, vp]),
         "bbg_srs_num_points": (sz, [vp]),
@@ -139,7 +140,7 @@ EXPORTED_SYMBOLS = [
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
-    "bbg_srs_write_transcript", "bbg_transcript_checksum",
+    "bbg_srs_write_transcript", "bbg_transcript_checksum", "bbg_srs_register_transcript_buffer",
     "bbg_prover_create", "bbg_prover_destroy", "bbg_prover_set_key_poly", "bbg_prover_finalize_key", "bbg_prover_round1", "bbg_prover_round3",
     "bbg_prover_round4", "bbg_prover_evaluate", "bbg_prover_linearise", "bbg_prover_round6", "bbg_prover_read_poly",
     "bbg_multi_create", "bbg_multi_destroy", "bbg_multi_count", "bbg_multi_ctx", "bbg_multi_sync", "bbg_multi_srs_register",

@@ -347,6 +347,24 @@ int bbg_srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, bbg_srs** out)
     return rc;
 }
 
+// pts: num_points x 8 limbs in STANDARD (non-Montgomery) form, slot 0 free: sets monomials[0] = G = (1, 2), converts to Montgomery form
+// on the device and registers the SRS (the tail of read_transcript_g1 / Pippenger's constructors)
+static int srs_from_plain_points(bbg_ctx* ctx, std::vector<uint64_t>& pts, size_t num_points, bbg_srs** out)
+{
+    for (int i = 0; i < 8; i++) pts[i] = 0;
+    pts[0] = 1;
+    pts[4] = 2;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void* d_plain = nullptr;
+    BBG_HIP(hipMalloc(&d_plain, num_points * 64));
+    hipError_t e = hipMemcpyAsync(d_plain, pts.data(), num_points * 64, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_plain); return hip_fail(e, "transcript upload", __FILE__, __LINE__); }
+    int rc = field_op_device(1, 5 /* to_montgomery */, d_plain, nullptr, d_plain, num_points * 2, ctx->stream);
+    if (rc == BBG_OK) rc = make_srs(ctx, d_plain, num_points, out);
+    (void)hipFree(d_plain);
+    return rc;
+}
+
 // Ignition transcript reader: restates io::read_transcript_g1 (reference srs/io.cpp:134-162): manifest of seven
 // big-endian u32 (:11-19,31-45), then num_g1_points x 64 B, every 8-byte limb big-endian, limbs least-significant
 // first, values NOT in Montgomery form (:47-67).  monomials[0] = G, file points follow; files transcript00.dat,
@@ -381,19 +399,20 @@ int bbg_srs_load_transcript(bbg_ctx* ctx, const char* dir, size_t num_points, bb
         set_error(buf);
         return BBG_E_INVALID;
     }
-    // generator (1, 2), plain form; converted with the rest
-    for (int i = 0; i < 8; i++) pts[i] = 0;
-    pts[0] = 1;
-    pts[4] = 2;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    void* d_plain = nullptr;
-    BBG_HIP(hipMalloc(&d_plain, num_points * 64));
-    hipError_t e = hipMemcpyAsync(d_plain, pts.data(), num_points * 64, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(d_plain); return hip_fail(e, "transcript upload", __FILE__, __LINE__); }
-    int rc = field_op_device(1, 5 /* to_montgomery */, d_plain, nullptr, d_plain, num_points * 2, ctx->stream);
-    if (rc == BBG_OK) rc = make_srs(ctx, d_plain, num_points, out);
-    (void)hipFree(d_plain);
-    return rc;
+    return srs_from_plain_points(ctx, pts, num_points, out);
+}
+
+// Pippenger(uint8_t const* points, size_t num_points) (pippenger.cpp:7-17; the C binding new_pippenger, c_bind.cpp:21-24): the points of a
+// transcript already in memory -- (num_points - 1) x 64 bytes in the file encoding (io::read_g1_elements_from_buffer, srs/io.cpp:47-67);
+// monomials[0] = G.
+int bbg_srs_register_transcript_buffer(bbg_ctx* ctx, const uint8_t* points, size_t num_points, bbg_srs** out)
+{
+    CHECK_CTX(ctx);
+    if (!out || num_points == 0 || (!points && num_points > 1)) { set_error("bbg_srs_register_transcript_buffer: bad argument"); return BBG_E_INVALID; }
+    std::vector<uint64_t> pts(num_points * 8);
+    if (num_points > 1) memcpy(&pts[8], points, (num_points - 1) * 64);
+    for (size_t i = 8; i < num_points * 8; i++) pts[i] = __builtin_bswap64(pts[i]);
+    return srs_from_plain_points(ctx, pts, num_points, out);
 }
 
 // BLAKE2b-512 (RFC 7693, unkeyed), the checksum an Ignition transcript carries after its points (srs/io.cpp:21-29 accounts for its

@@ -76,6 +76,9 @@ int bbg_srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, bbg_srs** out);
 /* Reads an Ignition-format transcript file (manifest + big-endian points; srs/io.cpp:11-162): result is
  * monomials[0] = G followed by the file's points, num_points in total -- exactly read_transcript_g1. */
 int bbg_srs_load_transcript(bbg_ctx* ctx, const char* path, size_t num_points, bbg_srs** out);
+/* The same from memory: Pippenger(uint8_t const* points, size_t num_points) (pippenger.cpp:7-17, the C binding new_pippenger): `points` =
+ * (num_points - 1) x 64 bytes in the transcript encoding (srs/io.cpp:47-67); monomials[0] = G. */
+int bbg_srs_register_transcript_buffer(bbg_ctx* ctx, const uint8_t* points, size_t num_points, bbg_srs** out);
 /* The inverse: writes the SRS as Ignition-format files dir/transcript00.dat, 01, ... holding points 1 .. n-1 (point 0 is the
  * generator every reader supplies itself, srs/io.cpp:137), points_per_file per file (0 = one file); manifest and point encoding of
  * srs/io.cpp:11-67.  g2_x_raw (may be NULL): 128 bytes stored as file 00's single G2 point, as given.  Each file ends with the

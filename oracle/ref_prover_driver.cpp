@@ -44,6 +44,9 @@
 
 using namespace barretenberg;
 
+// present only in the build that is linked with the drop-in shim (libbbprover_gpu.so)
+extern "C" void bbg_shim_unregister_point_table(const void* endo_table) __attribute__((weak));
+
 namespace {
 
 // SRS handed in by the test as raw Montgomery affine points (the same 64-byte layout bbg_srs_register takes) plus the
@@ -56,7 +59,11 @@ class DriverProverCrs : public waffle::ProverReferenceString {
         std::memcpy((void*)table_, points, num_points * sizeof(g1::affine_element));
         scalar_multiplication::generate_pippenger_point_table(table_, table_, num_points);
     }
-    ~DriverProverCrs() override { aligned_free(table_); }
+    ~DriverProverCrs() override
+    {
+        if (bbg_shim_unregister_point_table) bbg_shim_unregister_point_table(table_); // the Pippenger-destructor hook
+        aligned_free(table_);
+    }
     g1::affine_element* get_monomials() override { return table_; }
 
   private:

@@ -24,11 +24,13 @@
 // group element is identical -- compare through g1::affine_element, as the prover does, work_queue.hpp:233-239);
 // FFTs are in place on coeffs[domain.size]; `pippenger_runtime_state` is accepted and ignored (the scratch arena lives
 // on the device); a failing call throws std::runtime_error like throw_or_abort (common/throw_or_abort.hpp:5-13).
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -156,20 +158,41 @@ void drop(std::map<const g1::affine_element*, ShimState::Entry>::iterator it)
     bbg_srs_free(it->second.srs);
     state().tables.erase(it);
 }
+void take_samples(ShimState::Entry& e)
+{
+    const size_t step = e.n > ShimState::SAMPLES ? e.n / ShimState::SAMPLES : 1;
+    for (size_t i = 0; i < e.n; i += step) e.samples.emplace_back(i, e.base[2 * i]);
+    e.samples.emplace_back(e.n - 1, e.base[2 * (e.n - 1)]);
+}
+// every cached entry whose host range overlaps [table, table + 2 num_points) except the one AT `table`: the caller vouches that this
+// memory holds its table now, so whatever else was remembered there is dead (a table freed without the unregister hook)
+void drop_overlapping(const g1::affine_element* table, size_t num_points)
+{
+    ShimState& s = state();
+    for (auto it = s.tables.begin(); it != s.tables.end();) {
+        const ShimState::Entry& e = it->second;
+        const bool overlaps = e.base != table && e.base < table + 2 * num_points && table < e.base + 2 * e.n;
+        auto next = std::next(it);
+        if (overlaps) drop(it);
+        it = next;
+    }
+}
 // owner-announced table: uploaded once, valid until bbg_shim_unregister_point_table
 bbg_srs* register_table(const g1::affine_element* table, size_t num_points)
 {
     ShimState& s = state();
+    drop_overlapping(table, num_points);
     auto it = s.tables.find(table);
     if (it != s.tables.end()) {
-        if (it->second.registered && it->second.n >= num_points) return it->second.srs;
-        drop(it); // an implicit entry at this address, or a shorter registration: replace
+        if (it->second.registered && it->second.n >= num_points && it->second.range_still_matches(0, num_points)) return it->second.srs;
+        drop(it); // an implicit entry at this address, a shorter registration, or other contents than were registered: replace
     }
     ShimState::Entry e;
     e.base = table;
     e.n = num_points;
     e.srs = upload(table, num_points);
     e.registered = true;
+    take_samples(e);
     s.tables[table] = std::move(e);
     return s.tables[table].srs;
 }
@@ -183,15 +206,18 @@ bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t&
     if (it != s.tables.end()) {
         ShimState::Entry& e = it->second;
         const size_t off = (size_t)(points - e.base);
-        if (off % 2 == 0 && off / 2 + num_points <= e.n && (e.registered || e.range_still_matches(off / 2, num_points))) {
+        // Registered entries are sampled as well: an owner that forgot the unregister hook must not turn into wrong commitments.  Only
+        // memory inside the range THIS call passes is compared.
+        if (off % 2 == 0 && off / 2 + num_points <= e.n && e.range_still_matches(off / 2, num_points)) {
             e.last_use = ++s.clock;
             from = off / 2;
             return e.srs;
         }
-        // an implicit entry that no longer describes this memory, or that is too short: forget it.  A REGISTERED table that is
-        // asked for more points than were announced is the owner's contract broken -- serve the call from a transient copy.
-        registered_but_short = e.registered;
-        if (!e.registered) drop(it);
+        // An entry that no longer describes this memory (any kind), or an implicit one that is too short: forget it.  A REGISTERED
+        // table that still matches but is asked for more points than were announced is served from a transient copy.
+        const bool stale = off % 2 != 0 || !e.range_still_matches(off / 2, std::min(num_points, e.n - std::min(e.n, off / 2)));
+        registered_but_short = e.registered && !stale;
+        if (!e.registered || stale) drop(it);
     }
     from = 0;
     if (num_points < ShimState::MIN_CACHED_POINTS || registered_but_short) {
@@ -211,9 +237,7 @@ bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t&
     e.n = num_points;
     e.srs = upload(points, num_points);
     e.last_use = ++s.clock;
-    const size_t step = num_points > ShimState::SAMPLES ? num_points / ShimState::SAMPLES : 1;
-    for (size_t i = 0; i < num_points; i += step) e.samples.emplace_back(i, points[2 * i]);
-    e.samples.emplace_back(num_points - 1, points[2 * (num_points - 1)]);
+    take_samples(e);
     s.tables[points] = std::move(e);
     return s.tables[points].srs;
 }

@@ -60,3 +60,14 @@ def test_input_generator_is_prefix_stable(pkg):
     assert int(a[:, 3].max()) < (1 << 60)
     # splitmix64 known answer: seed 0 -> first output 0xE220A8397B1DCDAF
     assert int(pkg.splitmix64_limbs(0, 1)[0]) == 0xE220A8397B1DCDAF
+
+
+def test_reference_c_binding_names_exported(pkg):
+    """libbbg_cbind.so: the reference's own extern "C" names for this path (ecc/.../scalar_multiplication/c_bind.hpp:9-19,
+    plonk/proof_system/prover/c_bind.cpp:99-120), and nothing else."""
+    so = os.path.join(os.path.dirname(pkg.LIB_PATH), "libbbg_cbind.so")
+    if not os.path.exists(so):
+        pkg.build_library()
+    names = {l.split()[-1] for l in os.popen(f"nm -D --defined-only {so}").read().splitlines() if " T " in l}
+    assert names == {"bbmalloc", "bbfree", "new_pippenger", "delete_pippenger", "pippenger_unsafe", "g1_sum", "coset_fft_with_generator_shift",
+                     "ifft", "new_evaluation_domain", "delete_evaluation_domain"}, names

@@ -1232,3 +1232,52 @@ def test_multi_rejects_bad_groups(pkg, bbg):
     M.close()
     with pytest.raises(pkg.BbgError):
         _Multi(pkg, [99])
+
+
+def test_reference_c_binding_names(pkg, oracle, bbg):
+    """libbbg_cbind.so exports the reference's OWN extern "C" names with its signatures (scalar_multiplication/c_bind.hpp:9-19,
+    prover/c_bind.cpp:99-120): a host speaking the reference's C / WASM offload protocol binds it unchanged.  Driven here the way such
+    a host does -- bbmalloc'ed buffers, transcript-encoded points into new_pippenger, work-item style calls -- against the oracle."""
+    so = os.path.join(os.path.dirname(pkg.LIB_PATH), "libbbg_cbind.so")
+    L = ctypes.CDLL(so)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    L.bbmalloc.restype = vp; L.bbmalloc.argtypes = [sz]
+    L.bbfree.argtypes = [vp]
+    L.new_pippenger.restype = vp; L.new_pippenger.argtypes = [vp, sz]
+    L.delete_pippenger.argtypes = [vp]
+    L.pippenger_unsafe.argtypes = [vp, vp, sz, sz, vp]
+    L.g1_sum.argtypes = [vp, sz, vp]
+    L.new_evaluation_domain.restype = vp; L.new_evaluation_domain.argtypes = [sz]
+    L.delete_evaluation_domain.argtypes = [vp]
+    L.coset_fft_with_generator_shift.argtypes = [vp, vp, vp]
+    L.ifft.argtypes = [vp, vp]
+    n = 3000
+    pts = oracle.srs_hashed(31, n)
+    pts[0] = oracle.g1_generator()
+    # transcript encoding of points 1 .. n-1: standard form, every limb big-endian (srs/io.cpp:47-67)
+    raw = oracle.from_mont(1, pts[1:].reshape(-1, 4)).astype(">u8").tobytes()
+    buf = L.bbmalloc(len(raw))
+    assert buf % 64 == 0
+    ctypes.memmove(buf, raw, len(raw))
+    pip = L.new_pippenger(buf, n)
+    L.bbfree(buf)
+    sc = pkg.synthetic_scalars(77, n)
+    res = np.zeros(12, dtype=np.uint64)
+    L.pippenger_unsafe(pip, sc.ctypes.data, 0, n, res.ctypes.data)
+    assert np.array_equal(oracle.jac_to_affine(res), oracle.pippenger(sc, pts))
+    parts = np.zeros((3, 12), dtype=np.uint64)
+    for k in range(3):  # (from, range) work items + g1_sum, the composition of c_bind.cpp:31-46
+        L.pippenger_unsafe(pip, sc[k * 1000:].ctypes.data, k * 1000, 1000, parts[k].ctypes.data)
+    L.g1_sum(parts.ctypes.data, 3, res.ctypes.data)
+    assert np.array_equal(oracle.jac_to_affine(res), oracle.pippenger(sc, pts))
+    L.delete_pippenger(pip)
+    dom = L.new_evaluation_domain(1 << 12)
+    c = pkg.synthetic_scalars(78, 1 << 12)
+    k = pkg.synthetic_scalars(79, 1)[0]
+    a = c.copy()
+    L.ifft(a.ctypes.data, dom)
+    assert np.array_equal(oracle.canon(0, a), oracle.ntt(c, 1))
+    a = c.copy()
+    L.coset_fft_with_generator_shift(a.ctypes.data, k.ctypes.data, dom)
+    assert np.array_equal(oracle.canon(0, a), oracle.ntt(c, 6, 0, k))
+    L.delete_evaluation_domain(dom)
