@@ -742,11 +742,11 @@ int bbg_coset_fft_extend(bbg_ctx* ctx, const uint64_t* coeffs, unsigned log2n, u
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t n = (size_t)1 << log2n, m = (size_t)1 << log2_domain;
-    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, m * 32);
+    // n coefficients land behind the m-element result area; the transform reads them zero-extended and writes the result area
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, (m + n) * 32);
     if (rc) return rc;
-    BBG_HIP(hipMemcpyAsync(ctx->staging, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (m > n) BBG_HIP(hipMemsetAsync((char*)ctx->staging + n * 32, 0, (m - n) * 32, ctx->stream));
-    rc = ntt_run(ctx, ctx->staging, log2_domain, BBG_COSET_FFT, n, nullptr, ctx->stream);
+    BBG_HIP(hipMemcpyAsync((char*)ctx->staging + m * 32, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    rc = ntt_coset_extend(ctx, (char*)ctx->staging + m * 32, n, ctx->staging, log2_domain, ctx->stream);
     if (rc) return rc;
     BBG_HIP(hipMemcpyAsync(out, ctx->staging, m * 32, hipMemcpyDeviceToHost, ctx->stream));
     BBG_HIP(hipStreamSynchronize(ctx->stream));

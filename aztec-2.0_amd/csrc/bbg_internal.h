@@ -30,6 +30,7 @@ struct NttDomain {
     unsigned log2n = 0;
     int passes = 0;
     bool use_pass8 = false; // register-resident radix-8 pass kernel (ntt_pass8.hip.h) vs the radix-2-in-LDS one
+    bool inv_scaled = false; // the inverse inter-pass twiddles of pass 0 carry n^-1: ifft needs no scaling sweep
     int logR[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
     int logW[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
     void* consts = nullptr;                          // DomainConsts (device)
@@ -131,6 +132,7 @@ int ensure_buffer(void** buf, size_t* have, size_t need);
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
             hipStream_t stream);
 void ntt_free_domain(NttDomain& d);
+int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, unsigned log2n, hipStream_t stream);
 int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n);
 int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);

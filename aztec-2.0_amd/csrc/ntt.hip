@@ -201,6 +201,9 @@ struct PassParams {
     const Fr* tw_inter; // [R][S] table or nullptr
     const Fr* tw_radix; // R/2 entries
     const Fr* post;     // optional per-output-element multiplier table indexed by natural output index (row pass only)
+    const Fr* pre;      // first (column) pass of k_ntt_pass8: input element g < pre_count is multiplied by pre[g] as it is loaded
+    size_t pre_count;   //   (coset_fft's a_j *= g^j for j < generator_size, polynomial_arithmetic.cpp:395-399, fused into the load)
+    size_t in_count;    // first (column) pass of k_ntt_pass8: input elements g >= in_count are ZERO and are not read
     int logR, logW, logS; // logS = log2(stride) (0 for the row pass)
     int row_pass;
     int log2n;
@@ -447,8 +450,11 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
                 BBG_HIP(hipMalloc(&d.tw_inter[inv][q], cnt * sizeof(Fr)));
                 d.bytes += cnt * sizeof(Fr);
                 // w_{N_q}^(2^b) = w_n^(2^(b + log2n - logN))
+                // inverse direction: n^-1 rides on the first pass's inter-pass twiddles, so ifft costs exactly what fft costs
+                // (the reference scales in a separate sweep, polynomial_arithmetic.cpp:379-385)
+                const Fr* scale = (inv && q == 0) ? &dc->n_inv : nullptr;
                 hipLaunchKernelGGL(k_twiddle_2d, dim3(grid_for(cnt, 256)), dim3(256), 0, st, (Fr*)d.tw_inter[inv][q],
-                                   pow2 + (log2n - logN), logR, logS, (const Fr*)nullptr);
+                                   pow2 + (log2n - logN), logR, logS, scale);
             }
         }
     }
@@ -460,8 +466,9 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
     hipLaunchKernelGGL(k_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d.coset_fwd,
                        dc->pow2_tmp, (const Fr*)nullptr, n);
     hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen_inv, (const Fr*)nullptr);
+    d.inv_scaled = d.passes > 1; // the inverse core already delivers n^-1 * (...) when it has an inter-pass twiddle table
     hipLaunchKernelGGL(k_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d.coset_inv,
-                       dc->pow2_tmp, &dc->n_inv, n);
+                       dc->pow2_tmp, d.inv_scaled ? (const Fr*)nullptr : (const Fr*)&dc->n_inv, n);
     BBG_HIP(hipGetLastError());
     BBG_HIP(hipStreamSynchronize(st));
     auto ins = ctx->domains.emplace(log2n, d);
@@ -469,11 +476,15 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
     return BBG_OK;
 }
 
-static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, const Fr* in, Fr* out, const Fr* post, hipStream_t st)
+static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, const Fr* in, Fr* out, const Fr* post, hipStream_t st,
+                       const Fr* pre = nullptr, size_t pre_count = 0, size_t in_count = ~(size_t)0)
 {
     PassParams p;
     p.in = in;
     p.out = out;
+    p.pre = pre;
+    p.pre_count = pre_count;
+    p.in_count = in_count;
     p.logR = d.logR[q];
     p.logW = d.logW[q];
     p.log2n = (int)d.log2n;
@@ -526,23 +537,44 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     return BBG_OK;
 }
 
-// core transform: in place on `a` from the caller's view; `post` (optional) multiplies natural-index outputs.
-static int ntt_core(bbg_ctx* ctx, NttDomain& d, Fr* a, int inverse, const Fr* post, hipStream_t st)
+// core transform: `in` -> `out` (may be the same array); `post` (optional) multiplies natural-index outputs.
+// Multi-pass pass8 plans also take, fused into the first pass's load: a pre-scale table (pre[g], g < pre_count) and a zero-extended
+// input (only in[0 .. in_count) exists; the rest of the domain is zero).  can_fuse(d) says whether the plan supports that.
+static bool can_fuse(const NttDomain& d) { return d.use_pass8 && d.passes > 1; }
+static int ntt_core(bbg_ctx* ctx, NttDomain& d, const Fr* in, Fr* out, int inverse, const Fr* post, hipStream_t st, const Fr* pre = nullptr,
+                    size_t pre_count = 0, size_t in_count = ~(size_t)0)
 {
     const size_t n = (size_t)1 << d.log2n;
     if (d.log2n == 0) {
-        if (post) hipLaunchKernelGGL(k_scale_table, dim3(1), dim3(64), 0, st, a, post, (size_t)1);
+        if (in != out) BBG_HIP(hipMemcpyAsync(out, in, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        if (post) hipLaunchKernelGGL(k_scale_table, dim3(1), dim3(64), 0, st, out, post, (size_t)1);
         return BBG_OK;
     }
-    if (d.passes == 1) return launch_pass(ctx, d, 0, inverse, a, a, post, st);
+    if (d.passes == 1) return launch_pass(ctx, d, 0, inverse, in, out, post, st);
     int rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, n * sizeof(Fr));
     if (rc) return rc;
     Fr* scratch = (Fr*)ctx->ntt_scratch;
-    // pass 0: a -> scratch (same positions); middle passes in place on scratch; last pass scratch -> a (transposing)
-    rc = launch_pass(ctx, d, 0, inverse, a, scratch, nullptr, st);
+    // pass 0: in -> scratch (same positions); middle passes in place on scratch; last pass scratch -> out (transposing)
+    rc = launch_pass(ctx, d, 0, inverse, in, scratch, nullptr, st, pre, pre_count, in_count);
     for (int q = 1; q < d.passes - 1 && !rc; q++) rc = launch_pass(ctx, d, q, inverse, scratch, scratch, nullptr, st);
-    if (!rc) rc = launch_pass(ctx, d, d.passes - 1, inverse, scratch, a, post, st);
+    if (!rc) rc = launch_pass(ctx, d, d.passes - 1, inverse, scratch, out, post, st);
     return rc;
+}
+
+// The prover's FFT work item without its copies (work_queue.hpp:252-264): the n_in coefficients at d_in, zero-extended to the 2^log2n
+// domain, coset FFT with generator_size n_in, result to d_out (2^log2n elements; must not overlap d_in).  No staging copy, no
+// zero fill, no separate scaling sweep when the plan fuses (any domain of >= 2^12 points).
+int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, unsigned log2n, hipStream_t st)
+{
+    if (!d_in || !d_out || log2n > 28 || n_in > ((size_t)1 << log2n)) { set_error("ntt_coset_extend: bad argument"); return BBG_E_INVALID; }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log2n;
+    if (can_fuse(*dp)) return ntt_core(ctx, *dp, (const Fr*)d_in, (Fr*)d_out, 0, nullptr, st, (const Fr*)dp->coset_fwd, n_in, n_in);
+    BBG_HIP(hipMemcpyAsync(d_out, d_in, n_in * 32, hipMemcpyDeviceToDevice, st));
+    if (n > n_in) BBG_HIP(hipMemsetAsync((char*)d_out + n_in * 32, 0, (n - n_in) * 32, st));
+    return ntt_run(ctx, d_out, log2n, BBG_COSET_FFT, n_in, nullptr, st);
 }
 
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
@@ -567,22 +599,26 @@ int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generat
     }
     switch (op) {
     case BBG_FFT:
-        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        rc = ntt_core(ctx, d, a, a, 0, nullptr, st);
         break;
     case BBG_IFFT:
-        rc = ntt_core(ctx, d, a, 1, nullptr, st);
-        if (!rc) hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, &dc->n_inv, n);
+        rc = ntt_core(ctx, d, a, a, 1, nullptr, st);
+        if (!rc && !d.inv_scaled) hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, &dc->n_inv, n);
         break;
     case BBG_COSET_FFT:
+        if (can_fuse(d)) { // a_j *= g^j (j < generator_size) as the first pass loads a_j
+            rc = ntt_core(ctx, d, a, a, 0, nullptr, st, (const Fr*)d.coset_fwd, generator_size);
+            break;
+        }
         hipLaunchKernelGGL(k_scale_table, dim3(grid_for(generator_size, 256)), dim3(256), 0, st, a, (const Fr*)d.coset_fwd,
                            generator_size);
-        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        rc = ntt_core(ctx, d, a, a, 0, nullptr, st);
         break;
     case BBG_COSET_IFFT:
-        rc = ntt_core(ctx, d, a, 1, (const Fr*)d.coset_inv, st);
+        rc = ntt_core(ctx, d, a, a, 1, (const Fr*)d.coset_inv, st); // the table carries n^-1 g^-j, or g^-j when the core delivers n^-1
         break;
     case BBG_FFT_WITH_CONSTANT:
-        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        rc = ntt_core(ctx, d, a, a, 0, nullptr, st);
         if (!rc) hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, cst, n);
         break;
     case BBG_COSET_FFT_WITH_CONSTANT:
@@ -590,19 +626,19 @@ int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generat
         hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen, (const Fr*)nullptr);
         hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((generator_size + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, a,
                            dc->pow2_tmp, cst, generator_size);
-        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        rc = ntt_core(ctx, d, a, a, 0, nullptr, st);
         break;
     case BBG_COSET_FFT_WITH_GENERATOR_SHIFT:
         // generator = g * constant
         hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dc->pow2_tmp, &dc->gen, (const Fr*)cst);
         hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((generator_size + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, a,
                            dc->pow2_tmp, (const Fr*)nullptr, generator_size);
-        rc = ntt_core(ctx, d, a, 0, nullptr, st);
+        rc = ntt_core(ctx, d, a, a, 0, nullptr, st);
         break;
     case BBG_IFFT_WITH_CONSTANT:
-        rc = ntt_core(ctx, d, a, 1, nullptr, st);
+        rc = ntt_core(ctx, d, a, a, 1, nullptr, st);
         if (!rc) {
-            hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, &dc->n_inv, n);
+            if (!d.inv_scaled) hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, &dc->n_inv, n);
             hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, a, cst, n);
         }
         break;
@@ -638,7 +674,7 @@ int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hi
         hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dcs->pow2_tmp, (const Fr*)gk, (const Fr*)nullptr);
         hipLaunchKernelGGL(k_scale_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, a + k * n,
                            dcs->pow2_tmp, (const Fr*)nullptr, n);
-        rc = ntt_core(ctx, *dsmall, a + k * n, 0, nullptr, st);
+        rc = ntt_core(ctx, *dsmall, a + k * n, a + k * n, 0, nullptr, st);
         if (rc) return rc;
         // gk *= root_large  (k_pow2_table with two bases writes pow2[0] = gk*root; copy back)
         hipLaunchKernelGGL(k_pow2_table, dim3(1), dim3(64), 0, st, dcs->pow2_tmp, (const Fr*)gk, (const Fr*)&dcl->root);

@@ -114,8 +114,17 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
         const int pj = pbase | (j << F);
         if (FIRST) {
             size_t g;
-            if (!ROW) g = base + ((size_t)pj << p.logS) + c;
-            else g = (((((d1_0 + c) << logRestCount) + rest)) << LOGR) + pj;
+            if (!ROW) {
+                g = base + ((size_t)pj << p.logS) + c; // first pass of a multi-pass plan: g is the natural input index
+                if (g >= p.in_count) { // zero-extended input (the prover's n coefficients on the 4n domain): nothing to read
+                    x[j] = Fr::zero();
+                    continue;
+                }
+                x[j] = fe_load<FrP>(p.in + g);
+                if (p.pre && g < p.pre_count) x[j] = fe_mul(x[j], fe_load<FrP>(p.pre + g)); // coset_fft's g^j, fused into the load
+                continue;
+            }
+            g = (((((d1_0 + c) << logRestCount) + rest)) << LOGR) + pj;
             x[j] = fe_load<FrP>(p.in + g);
         } else {
             x[j] = p8_lds_load(plo, phi, p8_addr(pj, c, LOGW));

@@ -124,10 +124,7 @@ int fetch_commitments(bbg_prover* p, size_t count, uint64_t* out, hipStream_t st
 // prover appends are not needed: the widget kernels index modulo 4n)
 int to_coset(bbg_prover* p, const void* d_coeff, void* d_out, hipStream_t st)
 {
-    const size_t n = p->n;
-    BBG_HIP(hipMemcpyAsync(d_out, d_coeff, n * 32, hipMemcpyDeviceToDevice, st));
-    BBG_HIP(hipMemsetAsync((char*)d_out + n * 32, 0, 3 * n * 32, st));
-    return ntt_run(p->ctx, d_out, p->log2n + 2, BBG_COSET_FFT, n, nullptr, st);
+    return ntt_coset_extend(p->ctx, d_coeff, p->n, d_out, p->log2n + 2, st); // no staging copy, no zero fill, g^j fused into the first load
 }
 
 // device address and length of a polynomial id (bbg_quotient_poly / bbg_prover_poly) in coefficient form

@@ -396,6 +396,7 @@ def reference_prover_sequence(srs, scalars, coeffs, lg):
     this is the MSM + FFT wall-clock north_star's 10x target refers to.)  CPU baseline leg only."""
     from oracle.oracle import Ref
     ref = Ref()
+    ref.set_threads(os.cpu_count() or 1)
     n = 1 << lg
     ctx = ref.msm(srs.read())
     t_msm = sum(ctx.run(scalars, 0, True)[1] for _ in range(11))
@@ -428,6 +429,8 @@ def cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, gpu_val
         ref = Ref()
         if lg < 18:  # the reference's CPU pippenger is unsafe with a large OpenMP team on small inputs
             ref.set_threads(min(os.cpu_count() or 1, 16))
+        else:        # all host cores for the baseline (the oracle caps the shared OpenMP runtime's team for its own checks)
+            ref.set_threads(os.cpu_count() or 1)
         ctx = ref.msm(points)
         best = 1e9
         for _ in range(2):

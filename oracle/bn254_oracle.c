@@ -963,6 +963,17 @@ int oracle_divide_by_pseudo_vanishing(uint64_t* evals, unsigned log2_src, unsign
     return 0;
 }
 
+/* OpenMP team size of every oracle routine.  The restatement is a checker, not a benchmark: on hosts with hundreds of hardware
+ * threads an uncapped team spends its time in barriers (a 2^19 NTT took 20 s with 256 threads against 0.3 s with 16). */
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP
