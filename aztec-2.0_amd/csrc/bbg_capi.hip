@@ -192,6 +192,20 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_async_reduce = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "msm_reduce_priority")) { // 1 = low-priority auxiliary stream (default), 0 = normal; takes effect when the stream is (re)created
+        BBG_HIP(hipDeviceSynchronize());
+        ctx->msm_reduce_low_priority = value != 0;
+        if (ctx->aux_stream) {
+            (void)hipStreamDestroy(ctx->aux_stream);
+            ctx->aux_stream = nullptr;
+            for (int k = 0; k < 2; k++) {
+                (void)hipEventDestroy(ctx->ev_acc[k]);
+                (void)hipEventDestroy(ctx->ev_done[k]);
+                ctx->ev_done_valid[k] = false;
+            }
+        }
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_window")) {
         if (value != 0 && value != 16 && value != 20) { set_error("msm_window must be 0 (automatic), 16 or 20"); return BBG_E_INVALID; }
         ctx->msm_window = (int)value;

@@ -89,6 +89,7 @@ struct bbg_ctx {
     int msm_layout_c = 0;    // every region, so pending reduce phases are joined first (msm_run_c)
     int msm_layout_sort = 1; // (the sort path is part of the layout: the library-sort path reserves rocPRIM's temporary storage)
     bool msm_async_reduce = false;
+    bool msm_reduce_low_priority = true; // auxiliary stream created with the lowest priority (option "msm_reduce_priority" = 0 undoes it)
     void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants

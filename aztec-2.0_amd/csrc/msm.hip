@@ -968,7 +968,11 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
     if (!ctx->aux_stream) {
-        BBG_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        // the reduce phase is latency work that only has to finish before its result is consumed: a LOW-priority stream, so that what
+        // the caller queues next on the main stream (the following MSM's sort / accumulation, an NTT) is dispatched first
+        int least = 0, greatest = 0;
+        BBG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        BBG_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, ctx->msm_reduce_low_priority ? least : (least + greatest) / 2));
         for (int k = 0; k < 2; k++) {
             BBG_HIP(hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming));
             BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));

@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip extra.config5 (one 2^24 MSM + one 2^24 coset NTT, strong scaling)")
     ap.add_argument("--no-prover-shaped", action="store_true", help="skip extra.prover_shaped (BASELINE config 4 on the resident prover rounds)")
     ap.add_argument("--config5-log2n", type=int, default=24)
+    ap.add_argument("--reduce-priority", type=int, default=-1, help="A/B: 1 = low-priority auxiliary stream for the MSM reduce phase (library default), 0 = normal")
     ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, 16 or 20 (A/B runs)")
     args = ap.parse_args()
 
@@ -134,6 +135,8 @@ def main():
     bbg.set_option("msm_async_reduce", 1)  # bucket reduction of MSM i overlaps sort/accumulate of step i+1
     if args.msm_window:
         bbg.set_option("msm_window", args.msm_window)
+    if args.reduce_priority >= 0:
+        bbg.set_option("msm_reduce_priority", args.reduce_priority)
 
     # ---- setup (untimed): SRS shard resident in HBM, scalars / coefficients resident, twiddles built
     start = rank * n  # weak scaling: every rank owns n points of a world*n-point SRS
@@ -396,7 +399,6 @@ def reference_prover_sequence(srs, scalars, coeffs, lg):
     this is the MSM + FFT wall-clock north_star's 10x target refers to.)  CPU baseline leg only."""
     from oracle.oracle import Ref
     ref = Ref()
-    ref.set_threads(os.cpu_count() or 1)
     n = 1 << lg
     ctx = ref.msm(srs.read())
     t_msm = sum(ctx.run(scalars, 0, True)[1] for _ in range(11))
@@ -429,8 +431,7 @@ def cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, gpu_val
         ref = Ref()
         if lg < 18:  # the reference's CPU pippenger is unsafe with a large OpenMP team on small inputs
             ref.set_threads(min(os.cpu_count() or 1, 16))
-        else:        # all host cores for the baseline (the oracle caps the shared OpenMP runtime's team for its own checks)
-            ref.set_threads(os.cpu_count() or 1)
+
         ctx = ref.msm(points)
         best = 1e9
         for _ in range(2):

@@ -28,6 +28,21 @@
 #include <omp.h>
 #endif
 
+/* OpenMP team size of every oracle routine: a PRIVATE cap applied with num_threads() clauses.  The restatement is a checker, not a
+ * benchmark -- on hosts with hundreds of hardware threads an uncapped team spends its time in barriers (a 2^19 NTT took 20 s with 256
+ * threads against 0.3 s with 16) -- and the process-wide OpenMP setting must stay untouched: the compiled reference shares the
+ * runtime and its CPU pippenger misbehaves when its team size changes under it. */
+static int g_oracle_team = 32;
+static int oracle_team(void)
+{
+#ifdef _OPENMP
+    const int m = omp_get_max_threads();
+    return m < g_oracle_team ? m : g_oracle_team;
+#else
+    return 1;
+#endif
+}
+
 typedef unsigned __int128 u128;
 typedef struct { uint64_t d[4]; } fe;
 
@@ -542,7 +557,7 @@ static uint64_t mix64(uint64_t z)
 void oracle_srs_hashed(uint64_t seed, size_t n, uint64_t* out_points)
 {
     g1_affine G; oracle_g1_generator((uint64_t*)&G);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(oracle_team())
     for (size_t i = 0; i < n; i++) {
         uint64_t k[4] = { mix64(seed + (uint64_t)i) | 1ULL, 0, 0, 0 };
         g1_jac acc; jac_set_inf(&acc);
@@ -559,7 +574,7 @@ void oracle_srs_powers(const uint64_t* x_mont, size_t n, uint64_t* out_points)
 {
     g1_affine G; oracle_g1_generator((uint64_t*)&G);
     fe x; memcpy(x.d, x_mont, 32); x = fe_canon(&FR, x);
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(oracle_team())
     for (size_t i = 0; i < n; i++) {
         fe xi = fe_from_mont(&FR, fe_pow64(&FR, x, (uint64_t)i));
         g1_jac r; jac_mul(&r, &G, xi.d);
@@ -693,7 +708,7 @@ static void msm_bucket(const uint64_t* scalars_mont, const uint64_t* table, size
     uint64_t counts[256];
     oracle_wnaf_schedule(scalars_mont, n, w, sched, skew, counts);
     g1_jac* round_sum = (g1_jac*)malloc(rounds * sizeof(g1_jac));
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_team())
     for (size_t r = 0; r < rounds; r++) {
         g1_jac* buckets = (g1_jac*)malloc(nb * sizeof(g1_jac));
         for (size_t k = 0; k < nb; k++) jac_set_inf(&buckets[k]);
@@ -751,7 +766,7 @@ void oracle_pippenger(const uint64_t* scalars_mont, const uint64_t* points, size
 void oracle_msm_naive(const uint64_t* scalars_mont, const uint64_t* points, size_t n, uint64_t* out)
 {
     g1_jac acc; jac_set_inf(&acc);
-#pragma omp parallel
+#pragma omp parallel num_threads(oracle_team())
     {
         g1_jac local; jac_set_inf(&local);
 #pragma omp for schedule(dynamic, 8) nowait
@@ -803,7 +818,7 @@ static void fft_inner(fe* a, size_t n, fe root)
         fe* tw = (fe*)malloc(m * sizeof(fe));
         tw[0] = fe_one(&FR);
         for (size_t j = 1; j < m; j++) tw[j] = fe_mul(&FR, tw[j - 1], round_root);
-#pragma omp parallel for schedule(static) if (n >= 4096)
+#pragma omp parallel for schedule(static) if (n >= 4096) num_threads(oracle_team())
         for (size_t kk = 0; kk < n / (2 * m); kk++) {
             size_t k = kk * 2 * m;
             for (size_t j = 0; j < m; j++) {
@@ -823,7 +838,7 @@ static void scale_by_generator(fe* a, size_t size, fe start, fe shift)
 }
 static void scale_all(fe* a, size_t n, fe v)
 {
-#pragma omp parallel for schedule(static) if (n >= 4096)
+#pragma omp parallel for schedule(static) if (n >= 4096) num_threads(oracle_team())
     for (size_t i = 0; i < n; i++) a[i] = fe_mul(&FR, a[i], v);
 }
 
@@ -963,21 +978,12 @@ int oracle_divide_by_pseudo_vanishing(uint64_t* evals, unsigned log2_src, unsign
     return 0;
 }
 
-/* OpenMP team size of every oracle routine.  The restatement is a checker, not a benchmark: on hosts with hundreds of hardware
- * threads an uncapped team spends its time in barriers (a 2^19 NTT took 20 s with 256 threads against 0.3 s with 16). */
-void oracle_set_threads(int n)
-{
-#ifdef _OPENMP
-    omp_set_num_threads(n < 1 ? 1 : n);
-#else
-    (void)n;
-#endif
-}
+void oracle_set_threads(int n) { g_oracle_team = n < 1 ? 1 : n; }
 
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    return oracle_team();
 #else
     return 1;
 #endif

@@ -58,7 +58,7 @@ class Oracle:
         L.oracle_coset_fft_split.argtypes = [vp, cu, sz]; L.oracle_coset_fft_split.restype = cint
         L.oracle_num_threads.argtypes = []; L.oracle_num_threads.restype = cint
         L.oracle_set_threads.argtypes = [cint]; L.oracle_set_threads.restype = None
-        L.oracle_set_threads(min(os.cpu_count() or 1, 32))  # a checker, not a benchmark: large teams drown in barriers
+        # (the oracle caps its own OpenMP teams at 32 with num_threads() clauses; the process-wide setting is never touched)
         L.oracle_poly_binop.argtypes = [cint, vp, vp, vp, sz]; L.oracle_poly_binop.restype = None
         L.oracle_kate_opening.argtypes = [vp, vp, sz, vp, vp]; L.oracle_kate_opening.restype = None
         L.oracle_divide_by_pseudo_vanishing.argtypes = [vp, cu, cu, sz]; L.oracle_divide_by_pseudo_vanishing.restype = cint
