@@ -28,7 +28,6 @@ int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* 
                         const uint64_t* zeta, void** d_results, hipStream_t st);
 int poly_kate_opening_async(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, void* d_f, hipStream_t st);
 int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
-int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st);
 
 // out[j] = *c, j < count
 __global__ void k_fill_const(Fr* out, const Fr* c, size_t count)
@@ -47,7 +46,7 @@ using namespace bbg;
 
 namespace {
 constexpr int MAX_RESULTS = 16;
-constexpr size_t PIN_AFFINE = 0, PIN_EVAL = 1024, PIN_BLIND = 2048, PIN_BYTES = 4096;
+constexpr size_t PIN_AFFINE = 0, PIN_EVAL = 2048, PIN_BLIND = 3072, PIN_BYTES = 4096;
 }
 
 struct bbg_prover {
@@ -73,7 +72,6 @@ struct bbg_prover {
     void* opening[2] = {};    // n + 1 each
     void* tmp = nullptr;      // n + 1
     void* d_jac = nullptr;    // MAX_RESULTS x 96 B
-    void* d_aff = nullptr;    // MAX_RESULTS x 64 B
     char* h_pin = nullptr;    // pinned host staging (results down, blinding rows up)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_up[4] = {};
@@ -106,17 +104,17 @@ struct AsyncReduce {
     ~AsyncReduce() { ctx->msm_async_reduce = saved; }
 };
 
-// commitments of a round: join the reduce phases, normalise on the device (g1::affine_element(result), work_queue.hpp:233-239),
-// one copy down, ONE host synchronisation
+// commitments of a round: join the reduce phases, one copy down, ONE host synchronisation.  They leave as g1::element (Jacobian, 96
+// bytes), what pippenger_unsafe returns; the caller normalises exactly as work_queue::process_queue does with an MSM result
+// (g1::affine_element(result), work_queue.hpp:233-239) -- a Fermat inversion is 0.27 ms of single-lane latency on the device (it was
+// 1.1 ms of every 2^20-gate proof, profiles/r02_prover_kernel_stats_v1.txt) and microseconds on a host core.
 int fetch_commitments(bbg_prover* p, size_t count, uint64_t* out, hipStream_t st)
 {
     int rc = msm_join(p->ctx, st);
     if (rc) return rc;
-    rc = g1_normalize_device(p->d_jac, count, p->d_aff, st);
-    if (rc) return rc;
-    BBG_HIP(hipMemcpyAsync(p->h_pin + PIN_AFFINE, p->d_aff, count * 64, hipMemcpyDeviceToHost, st));
+    BBG_HIP(hipMemcpyAsync(p->h_pin + PIN_AFFINE, p->d_jac, count * 96, hipMemcpyDeviceToHost, st));
     BBG_HIP(hipStreamSynchronize(st));
-    memcpy(out, p->h_pin + PIN_AFFINE, count * 64);
+    memcpy(out, p->h_pin + PIN_AFFINE, count * 96);
     return BBG_OK;
 }
 
@@ -185,7 +183,6 @@ int bbg_prover_create(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int program_wi
     if (!rc) rc = dev_alloc(p, &p->opening[1], (n + 1) * 32);
     if (!rc) rc = dev_alloc(p, &p->tmp, (n + 1) * 32);
     if (!rc) rc = dev_alloc(p, &p->d_jac, MAX_RESULTS * 96);
-    if (!rc) rc = dev_alloc(p, &p->d_aff, MAX_RESULTS * 64);
     hipError_t e = hipSuccess;
     if (!rc) e = hipHostMalloc((void**)&p->h_pin, PIN_BYTES, hipHostMallocDefault);
     if (!rc && e == hipSuccess) e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
@@ -310,7 +307,7 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     return BBG_OK;
 }
 
-int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* blind, uint64_t z_commitment[8])
+int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* blind, uint64_t z_commitment[12])
 {
     CHECK_P(p);
     if (!beta || !gamma || !blind || !z_commitment) { set_error("bbg_prover_round3: null argument"); return BBG_E_INVALID; }
@@ -430,7 +427,7 @@ int bbg_prover_linearise(bbg_prover* p, size_t count, const int* ids, const uint
 
 int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, const uint64_t* scalars_zeta, size_t count_omega,
                       const int* ids_omega, const uint64_t* scalars_omega, const uint64_t zeta[4], const uint64_t zeta_omega[4],
-                      const uint64_t* t_high_top_scalar, uint64_t pi_z[8], uint64_t pi_z_omega[8])
+                      const uint64_t* t_high_top_scalar, uint64_t pi_z[12], uint64_t pi_z_omega[12])
 {
     CHECK_P(p);
     if (!ids_zeta || !scalars_zeta || !ids_omega || !scalars_omega || !zeta || !zeta_omega || !pi_z || !pi_z_omega || count_zeta > 32 ||
@@ -471,11 +468,11 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
     if (!rc) rc = poly_kate_opening_async(p->ctx, p->tmp, p->opening[1], n, zeta_omega, nullptr, st);
     if (!rc) rc = msm_run(p->ctx, p->srs->s, p->opening[1], 0, n, (char*)p->d_jac + 96, st);
     if (rc) return rc;
-    uint64_t both[16];
+    uint64_t both[24];
     rc = fetch_commitments(p, 2, both, st);
     if (rc) return rc;
-    memcpy(pi_z, both, 64);
-    memcpy(pi_z_omega, both + 8, 64);
+    memcpy(pi_z, both, 96);
+    memcpy(pi_z_omega, both + 12, 96);
     p->stage = 0;
     return BBG_OK;
 }

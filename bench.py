@@ -362,7 +362,7 @@ def prover_shaped(pkg, bbg, srs, lg, reps=5):
         wires = [pkg.synthetic_scalars(SEED + 600 + k, n) for k in range(4)]
         wp = (ctypes.c_void_p * 4)(*[w.ctypes.data for w in wires])
         ch = pkg.synthetic_scalars(SEED + 700, 40)
-        com = np.zeros((4, 8), dtype=np.uint64)
+        com = np.zeros((4, 12), dtype=np.uint64)
         ev = np.zeros((32, 4), dtype=np.uint64)
         ids16 = (ctypes.c_int * 16)(0, 0, 1, 1, 2, 2, 3, 3, 4, 15, 16, 17, 5, 6, 7, 21)  # manifest order: w_i, w_i_omega, z_omega, q_c, q_arith, q_ecc_1, sigma_1..3, t
         sh16 = (ctypes.c_int * 16)(0, 1, 0, 1, 0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0)

@@ -218,8 +218,10 @@ int bbg_permutation_grand_product_device(bbg_ctx* ctx, const void* const d_wires
  *      shim/bbg_resident_prover.hpp, which drives these entry points from ProverBase's own public members in place of
  *      ProverBase::construct_proof (prover.cpp:420-436) and work_queue::process_queue (work_queue.hpp:208-282).
  *      One handle per proving key; selector / permutation polynomials are registered ONCE (explicit lifetime, no content
- *      fingerprints), wires go up per proof, 11 commitments and the opening evaluations come down.  All values Montgomery Fr /
- *      Montgomery affine g1 in the reference's layouts.  Rounds must be called in order; each returns after ONE host sync. ---- */
+ *      fingerprints), wires go up per proof, 11 commitments and the opening evaluations come down.  All values Montgomery Fr; commitments
+ *      leave as g1::element (Jacobian, 96 bytes = 12 limbs, what pippenger_unsafe returns) and the caller normalises them the way
+ *      work_queue::process_queue does (g1::affine_element(result), work_queue.hpp:233-239).  Rounds must be called in order; each
+ *      returns after ONE host sync. ---- */
 typedef struct bbg_prover bbg_prover;
 enum bbg_poly_form {
     BBG_FORM_COEFF = 0,    /* n coefficients (monomial form)                                   */
@@ -247,13 +249,13 @@ int bbg_prover_set_key_poly(bbg_prover* p, int id, int form, const uint64_t* val
 int bbg_prover_finalize_key(bbg_prover* p);
 /* Preamble + round 1 (prover.cpp:139-190, :66-84): wires_lagrange[k], k < program_width: the n values of wire k INCLUDING the blinding
  * rows n-4 .. n-2 the host has drawn.  Uploads them (kept for round 3), iffts to coefficient form (resident), commits.
- * commitments: program_width x 8 limbs, affine W_1 .. W_w. */
+ * commitments: program_width x 12 limbs, W_1 .. W_w as g1::element. */
 int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint64_t* commitments);
 /* Round 3 (permutation_widget_impl.hpp:48-312, prover.cpp:239-268): grand product z over the resident wires and sigmas, rows
  * n-3 .. n-1 <- blind[3][4], ifft, commitment Z, and the 4n-coset forms of z and the wires (resident, for round 4). */
-int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* blind, uint64_t z_commitment[8]);
+int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t* blind, uint64_t z_commitment[12]);
 /* Round 4 (prover.cpp:275-363): the flavour's widgets in the prover's order, division by Z*_H, coset_ifft(4n) -> t(X) resident;
- * commitments T_1 .. T_w (the last one over n + 1 coefficients for StandardPLONK, prover.cpp:117-137). */
+ * commitments T_1 .. T_w, 12 limbs each (the last one over n + 1 coefficients for StandardPLONK, prover.cpp:117-137). */
 int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t public_input_delta[4], uint64_t* t_commitments);
 /* Round 5a (add_opening_evaluations_to_transcript, kate_commitment_scheme.cpp:362-420; quotient_large.evaluate, prover.cpp:397):
  * out[k] = P_ids[k](zeta), or P(zeta * w_n) where shifted[k] != 0 (shifted may be NULL); ids from bbg_quotient_poly /
@@ -268,7 +270,7 @@ int bbg_prover_linearise(bbg_prover* p, size_t count, const int* ids, const uint
  * enters F as its coefficient n (:196-205). */
 int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, const uint64_t* scalars_zeta, size_t count_omega,
                       const int* ids_omega, const uint64_t* scalars_omega, const uint64_t zeta[4], const uint64_t zeta_omega[4],
-                      const uint64_t* t_high_top_scalar, uint64_t pi_z[8], uint64_t pi_z_omega[8]);
+                      const uint64_t* t_high_top_scalar, uint64_t pi_z[12], uint64_t pi_z_omega[12]);
 /* Copies a resident polynomial back (tests; a host that wants the reference's post-proof state): id / form as above. */
 int bbg_prover_read_poly(bbg_prover* p, int id, int form, uint64_t* out, size_t count);
 

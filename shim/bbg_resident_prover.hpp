@@ -150,9 +150,10 @@ template <typename T> const uint64_t* limbs(const T& v)
 {
     return reinterpret_cast<const uint64_t*>(&v);
 }
-inline void add_commitment(transcript::StandardTranscript& transcript, const std::string& tag, const g1::affine_element& point)
+inline void add_commitment(transcript::StandardTranscript& transcript, const std::string& tag, const g1::element& point)
 {
-    transcript.add_element(tag, point.to_buffer()); // what work_queue::process_queue does with an MSM result (work_queue.hpp:238)
+    // what work_queue::process_queue does with an MSM result: normalise, serialise, add (work_queue.hpp:233-239)
+    transcript.add_element(tag, g1::affine_element(point).to_buffer());
 }
 
 // One transition widget's share of the linearisation polynomial: r(X) += sum_selectors c_sel * q_sel(X).  The scalars are taken
@@ -274,7 +275,7 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
         for (size_t i = 0; i < key->num_public_inputs; ++i) public_wires.push_back(w_2[i]);
         transcript.add_element("public_inputs", ::to_buffer(public_wires));
     }
-    g1::affine_element commitments[4];
+    g1::element commitments[4];
     if (bbg_prover_round1(dev, wire_ptrs, reinterpret_cast<uint64_t*>(commitments)) != BBG_OK) resident_fail("bbg_prover_round1");
     for (size_t i = 0; i < W; ++i) detail::add_commitment(transcript, "W_" + std::to_string(i + 1), commitments[i]);
     // ---- round 2 (:224-231): nothing to commit for these flavours

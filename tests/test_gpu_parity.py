@@ -1107,7 +1107,7 @@ def test_prover_handle_error_paths(pkg, bbg):
     assert lib.bbg_prover_create(bbg.ctx, srs.handle, 6, 3, gens.ctypes.data, ctypes.byref(h)) != 0        # StandardPLONK needs n + 1 points
     assert lib.bbg_prover_create(bbg.ctx, srs.handle, 6, 4, gens.ctypes.data, ctypes.byref(h)) == 0
     a = pkg.synthetic_scalars(9, 64)
-    out = np.zeros((4, 8), dtype=np.uint64)
+    out = np.zeros((4, 12), dtype=np.uint64)
     wires = (ctypes.c_void_p * 4)(*[a.ctypes.data] * 4)
     assert lib.bbg_prover_round1(h, wires, out.ctypes.data) != 0                                            # key not finalised
     assert b"finalize" in lib.bbg_last_error()
