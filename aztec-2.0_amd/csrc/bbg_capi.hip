@@ -129,6 +129,7 @@ void bbg_destroy(bbg_ctx* ctx)
         for (auto e : kv.second.start) (void)hipEventDestroy(e);
         for (auto e : kv.second.stop) (void)hipEventDestroy(e);
     }
+    for (auto& kv : ctx->dpv_consts) (void)hipFree(kv.second);
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
     if (ctx->quot_setup) (void)hipFree(ctx->quot_setup);
     if (ctx->gp_totals) (void)hipFree(ctx->gp_totals);

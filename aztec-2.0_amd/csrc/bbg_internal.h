@@ -90,6 +90,7 @@ struct bbg_ctx {
     int msm_layout_sort = 1; // (the sort path is part of the layout: the library-sort path reserves rocPRIM's temporary storage)
     bool msm_async_reduce = false;
     bool msm_reduce_low_priority = true; // auxiliary stream created with the lowest priority (option "msm_reduce_priority" = 0 undoes it)
+    std::map<uint32_t, void*> dpv_consts; // poly.hip: Z*_H division constants per (src, target, roots cut)
     void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
