@@ -20,8 +20,10 @@
 #include "ntt_consts.hip.h"
 
 namespace bbg {
-int permutation_grand_product_w(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n,
-                                const uint64_t* challenges, void* d_z, hipStream_t st);
+int permutation_grand_product_begin(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n,
+                                    const uint64_t* challenges, void* d_z, hipStream_t st, hipStream_t inv_stream, hipEvent_t ev_ready, hipEvent_t ev_inverted);
+int permutation_grand_product_finish(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, void* d_z,
+                                     hipStream_t st, hipEvent_t ev_inverted);
 int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const void* const* d_polys, unsigned log2_large,
                            const uint64_t* challenges, void* d_quotient, uint64_t* alpha_out, hipStream_t st);
 int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* lens, const int* shifted, size_t count, unsigned log2n,
@@ -322,16 +324,19 @@ int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamm
     memcpy(ch, beta, 32);
     memcpy(ch + 4, gamma, 32);
     memcpy(ch + 8, p->gens + 4, 96); // k1..k3
-    int rc = permutation_grand_product_w(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, ch, p->z_coeff, st);
+    // The grand product needs ONE inversion, a 0.25 ms dependency chain on a single lane: it runs on the (idle) copy stream while the
+    // main stream does the part of the round that does not depend on z -- the wires' coset FFTs (the FFT work items, prover.cpp:255-264)
+    int rc = permutation_grand_product_begin(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, ch, p->z_coeff, st, p->copy_stream,
+                                             p->ev_up[0], p->ev_up[1]);
+    for (int k = 0; k < p->width && !rc; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+    if (!rc) rc = permutation_grand_product_finish(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, p->z_coeff, st, p->ev_up[1]);
     if (rc) return rc;
     // rows n-3 .. n-1 carry the zero-knowledge blinding of z (permutation_widget_impl.hpp:283-287); pinned staging, stream ordered
     memcpy(p->h_pin + PIN_BLIND, blind, 96);
     BBG_HIP(hipMemcpyAsync((char*)p->z_coeff + (n - 3) * 32, p->h_pin + PIN_BLIND, 96, hipMemcpyHostToDevice, st));
     rc = ntt_run(p->ctx, p->z_coeff, p->log2n, BBG_IFFT, 0, nullptr, st);
     if (!rc) rc = msm_run(p->ctx, p->srs->s, p->z_coeff, 0, n, p->d_jac, st);
-    // the FFT work items of the round: z and the wires on the 4n coset, resident for round 4
-    if (!rc) rc = to_coset(p, p->z_coeff, p->coset[4], st);
-    for (int k = 0; k < p->width && !rc; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+    if (!rc) rc = to_coset(p, p->z_coeff, p->coset[4], st); // z on the 4n coset while its commitment's reduce phase runs beside it
     if (rc) return rc;
     rc = fetch_commitments(p, 1, z_commitment, st);
     if (rc) return rc;

@@ -319,15 +319,18 @@ __global__ void __launch_bounds__(256) k_quotient_turbo_logic(QuotientArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------- permutation grand product
-// z of ProverPermutationWidget<4,false>::compute_round_commitments (permutation_widget_impl.hpp:48-268, steps 1-3; the
-// blinding of the last rows and the ifft stay with the caller):
+// z of ProverPermutationWidget<W,false>::compute_round_commitments (permutation_widget_impl.hpp:48-268, steps 1-3; the blinding of
+// the last rows and the ifft stay with the caller):
 //   z[0] = 1,   z[j+1] = prod_{i <= j} N_i / D_i,   N_i = prod_k (w_k[i] + gamma + beta K_k w^i),  D_i = prod_k (w_k[i] + gamma + beta sigma_k[i])
-// The reference runs 8 serial prefix products and one batched inversion per thread; here:
-//   k_gp_ratio  : thread = GP_E consecutive rows: N_i, D_i, Montgomery's trick over the thread's GP_E denominators (one
-//                 Fermat inversion per thread), R_i = N_i / D_i, thread-local running products; per-thread totals
-//   k_gp_scan   : exclusive prefix PRODUCT of the thread totals (one block, serial over chunks + LDS Hillis-Steele)
-//   k_gp_apply  : z[j+1] = (thread prefix) * (local running product)
-constexpr int GP_E = 16;
+// The reference runs 2W serial prefix products and one batched inversion per thread.  Round 1 of this repo inverted once per 16 rows
+// (65 536 Fermat chains at n = 2^20: 0.83 ms).  Here the whole polynomial costs ONE inversion:
+//   z[j+1] = PN_j * SD_{j+1} * (prod_all D)^-1,     PN_j = prod_{i <= j} N_i (prefix),   SD_{j+1} = prod_{i > j} D_i (suffix)
+//   k_gp_terms  : block = 1024 rows (256 threads x 4): N_i, D_i; in-block inclusive prefix of N -> z[j+1], in-block exclusive suffix of D
+//                 -> sd[j]; block totals of both
+//   k_gp_blocks : one block: exclusive prefix of the N block totals, exclusive suffix of the D block totals, the grand total of D
+//   k_gp_invert : one lane: (prod_all D)^-1  (a 0.25 ms dependency chain: the prover overlaps it with the wires' coset FFTs)
+//   k_gp_apply  : z[j+1] *= (prefix of earlier blocks) * sd[j] * (suffix of later blocks) * inverse
+constexpr int GP_E = 4, GP_BLOCK_ROWS = 256 * GP_E;
 __device__ inline Fr fr_inverse(const Fr& a) // a^(r-2)
 {
     uint32_t e[8];
@@ -344,99 +347,139 @@ __device__ inline Fr fr_inverse(const Fr& a) // a^(r-2)
 struct GpArgs {
     const Fr* w[4];
     const Fr* sigma[4];
-    Fr* z;       // n entries
-    Fr* totals;  // ceil(n / GP_E) thread totals, then their exclusive prefix products
-    size_t n;
+    Fr* z;      // n entries
+    Fr* sd;     // n entries: in-block exclusive suffix products of D
+    Fr* bt;     // block tables: [0, B) N totals -> exclusive prefixes; [B, 2B) D totals -> exclusive suffixes; [2B] total of D; [2B+1] its inverse
+    size_t n, nblocks;
     const QuotientSetup* s; // beta, gamma, k1..k3
     const DomainConsts* dc; // small (n) domain
 };
-template <int WIDTH> __global__ void __launch_bounds__(128) k_gp_ratio(GpArgs a)
+template <int WIDTH> __global__ void __launch_bounds__(256) k_gp_terms(GpArgs a)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t j0 = t * GP_E;
-    if (j0 >= a.n) return;
+    __shared__ Fr smn[256], smd[256];
+    const int tid = threadIdx.x;
+    const size_t j0 = (size_t)blockIdx.x * GP_BLOCK_ROWS + (size_t)tid * GP_E;
     const QuotientSetup& s = *a.s;
-    const int cnt = (a.n - j0 < (size_t)GP_E) ? (int)(a.n - j0) : GP_E;
+    Fr num[GP_E], den[GP_E];
     Fr rb = fe_mul(s.beta, pow_from_table(a.dc->pow2_root, (uint64_t)j0)); // beta * w^j
     const Fr root = a.dc->root;
-    Fr num[GP_E], pd[GP_E]; // numerators; running products of the denominators
-    Fr run = Fr::one();
-#pragma unroll 1
-    for (int e = 0; e < cnt; e++) {
+#pragma unroll
+    for (int e = 0; e < GP_E; e++) {
         const size_t j = j0 + e;
-        Fr wpg = fe_add(fe_load<FrP>(a.w[0] + j), s.gamma);
-        Fr n_ = fe_add(wpg, rb);
-        Fr d_ = fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[0] + j), s.beta));
-        wpg = fe_add(fe_load<FrP>(a.w[1] + j), s.gamma);
-        n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k1, rb)));
-        d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[1] + j), s.beta)));
-        wpg = fe_add(fe_load<FrP>(a.w[2] + j), s.gamma);
-        n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k2, rb)));
-        d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[2] + j), s.beta)));
-        if constexpr (WIDTH == 4) { // StandardPLONK: three wire columns (ProverPermutationWidget<3,false>)
-            wpg = fe_add(fe_load<FrP>(a.w[3] + j), s.gamma);
-            n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k3, rb)));
-            d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[3] + j), s.beta)));
+        if (j < a.n) {
+            Fr wpg = fe_add(fe_load<FrP>(a.w[0] + j), s.gamma);
+            Fr n_ = fe_add(wpg, rb);
+            Fr d_ = fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[0] + j), s.beta));
+            wpg = fe_add(fe_load<FrP>(a.w[1] + j), s.gamma);
+            n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k1, rb)));
+            d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[1] + j), s.beta)));
+            wpg = fe_add(fe_load<FrP>(a.w[2] + j), s.gamma);
+            n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k2, rb)));
+            d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[2] + j), s.beta)));
+            if constexpr (WIDTH == 4) { // StandardPLONK: three wire columns (ProverPermutationWidget<3,false>)
+                wpg = fe_add(fe_load<FrP>(a.w[3] + j), s.gamma);
+                n_ = fe_mul(n_, fe_add(wpg, fe_mul(s.k3, rb)));
+                d_ = fe_mul(d_, fe_add(wpg, fe_mul(fe_load<FrP>(a.sigma[3] + j), s.beta)));
+            }
+            num[e] = n_;
+            den[e] = d_;
+        } else { // rows beyond n: neutral
+            num[e] = Fr::one();
+            den[e] = Fr::one();
         }
-        num[e] = n_;
-        // z is written shifted by one (z[j+1] belongs to row j); park D_j there until the backward pass
-        if (j + 1 < a.n) fe_store<FrP>(a.z + j + 1, d_);
-        else fe_store<FrP>(a.z, d_); // the last row's denominator: slot 0 is free until k_gp_apply sets z[0] = 1
-        run = fe_mul(run, d_);
-        pd[e] = run;
         rb = fe_mul(rb, root);
     }
-    Fr inv = fr_inverse(run); // 1 / (D_j0 ... D_j0+cnt-1); a zero denominator has probability ~2^-250 (random beta, gamma)
-    Fr ratio[GP_E];
-#pragma unroll 1
-    for (int e = cnt - 1; e >= 0; e--) {
-        const size_t j = j0 + e;
-        const Fr d_ = fe_load<FrP>(j + 1 < a.n ? a.z + j + 1 : a.z);
-        const Fr dinv = e ? fe_mul(inv, pd[e - 1]) : inv; // 1 / D_j
-        inv = fe_mul(inv, d_);
-        ratio[e] = fe_mul(num[e], dinv);
-    }
-    run = Fr::one();
-#pragma unroll 1
-    for (int e = 0; e < cnt; e++) { // local running products R_j0 ... R_j
-        run = fe_mul(run, ratio[e]);
-        const size_t j = j0 + e;
-        if (j + 1 < a.n) fe_store<FrP>(a.z + j + 1, run);
-    }
-    fe_store<FrP>(a.totals + t, run);
-}
-__global__ void __launch_bounds__(256) k_gp_scan(Fr* totals, size_t count)
-{
-    __shared__ Fr sm[256];
-    const int tid = threadIdx.x;
-    const size_t per = (count + 255) / 256;
-    const size_t lo = (size_t)tid * per, hi = lo + per < count ? lo + per : count;
-    Fr run = Fr::one();
-    for (size_t i = lo; i < hi; i++) run = fe_mul(run, fe_load<FrP>(totals + i));
-    sm[tid] = run;
+    // thread-local inclusive prefix of N and exclusive suffix of D
+    Fr pn[GP_E], sdl[GP_E];
+    pn[0] = num[0];
+#pragma unroll
+    for (int e = 1; e < GP_E; e++) pn[e] = fe_mul(pn[e - 1], num[e]);
+    sdl[GP_E - 1] = Fr::one();
+#pragma unroll
+    for (int e = GP_E - 2; e >= 0; e--) sdl[e] = fe_mul(sdl[e + 1], den[e + 1]);
+    const Fr tn = pn[GP_E - 1], td = fe_mul(sdl[0], den[0]);
+    // block scans over the 256 thread totals: inclusive prefix of N (Hillis-Steele upwards), inclusive suffix of D (downwards)
+    Fr vn = tn, vd = td;
+    smn[tid] = vn;
+    smd[tid] = vd;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele product scan of the 256 chunk totals
-        Fr v = sm[tid];
-        if (tid >= d) v = fe_mul(sm[tid - d], v);
+    for (int d = 1; d < 256; d <<= 1) {
+        Fr xn = vn, xd = vd;
+        if (tid >= d) xn = fe_mul(smn[tid - d], vn);
+        if (tid + d < 256) xd = fe_mul(vd, smd[tid + d]);
         __syncthreads();
-        sm[tid] = v;
+        vn = xn;
+        vd = xd;
+        smn[tid] = vn;
+        smd[tid] = vd;
         __syncthreads();
     }
-    Fr pre = tid ? sm[tid - 1] : Fr::one(); // product of everything before this chunk
+    const Fr before = tid ? smn[tid - 1] : Fr::one();        // product of N over the block's earlier threads
+    const Fr after = tid + 1 < 256 ? smd[tid + 1] : Fr::one(); // product of D over the block's later threads
+#pragma unroll
+    for (int e = 0; e < GP_E; e++) {
+        const size_t j = j0 + e;
+        if (j < a.n) {
+            if (j + 1 < a.n) fe_store<FrP>(a.z + j + 1, fe_mul(before, pn[e])); // in-block PN_j, parked where z[j+1] will be
+            fe_store<FrP>(a.sd + j, fe_mul(sdl[e], after));                      // in-block SD_{j+1}
+        }
+    }
+    if (tid == 255) a.bt[blockIdx.x] = vn;           // block total of N (inclusive prefix at the last thread)
+    if (tid == 0) a.bt[a.nblocks + blockIdx.x] = vd; // block total of D (inclusive suffix at the first thread)
+}
+// exclusive prefix products of bt[0 .. B) (N totals), exclusive suffix products of bt[B .. 2B) (D totals), bt[2B] = prod of all D
+__global__ void __launch_bounds__(256) k_gp_blocks(Fr* bt, size_t B)
+{
+    __shared__ Fr smn[256], smd[256];
+    const int tid = threadIdx.x;
+    const size_t per = (B + 255) / 256;
+    const size_t lo = (size_t)tid * per, hi = lo + per < B ? lo + per : B;
+    Fr vn = Fr::one(), vd = Fr::one();
     for (size_t i = lo; i < hi; i++) {
-        const Fr v = fe_load<FrP>(totals + i);
-        fe_store<FrP>(totals + i, pre); // exclusive prefix
+        vn = fe_mul(vn, fe_load<FrP>(bt + i));
+        vd = fe_mul(vd, fe_load<FrP>(bt + B + i));
+    }
+    smn[tid] = vn;
+    smd[tid] = vd;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        Fr xn = vn, xd = vd;
+        if (tid >= d) xn = fe_mul(smn[tid - d], vn);
+        if (tid + d < 256) xd = fe_mul(vd, smd[tid + d]);
+        __syncthreads();
+        vn = xn;
+        vd = xd;
+        smn[tid] = vn;
+        smd[tid] = vd;
+        __syncthreads();
+    }
+    if (tid == 0) bt[2 * B] = fe_reduce_once(smd[0]); // product of every D
+    Fr pre = tid ? smn[tid - 1] : Fr::one();
+    for (size_t i = lo; i < hi; i++) { // exclusive prefix of the N totals
+        const Fr v = fe_load<FrP>(bt + i);
+        fe_store<FrP>(bt + i, pre);
         pre = fe_mul(pre, v);
     }
+    Fr suf = tid + 1 < 256 ? smd[tid + 1] : Fr::one();
+    for (size_t i = hi; i-- > lo;) { // exclusive suffix of the D totals
+        const Fr v = fe_load<FrP>(bt + B + i);
+        fe_store<FrP>(bt + B + i, suf);
+        suf = fe_mul(suf, v);
+    }
+}
+__global__ void k_gp_invert(Fr* bt, size_t B)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) bt[2 * B + 1] = fe_reduce_once(fr_inverse(bt[2 * B])); // a zero D has probability ~2^-230 (random beta, gamma)
 }
 __global__ void __launch_bounds__(256) k_gp_apply(GpArgs a)
 {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // row j -> z[j+1]
     if (j == 0) fe_store<FrP>(a.z, Fr::one());
     if (j + 1 >= a.n) return;
-    const size_t t = j / GP_E;
-    if (t == 0) return; // prefix of the first thread is 1
-    fe_store<FrP>(a.z + j + 1, fe_mul(fe_load<FrP>(a.z + j + 1), fe_load<FrP>(a.totals + t)));
+    const size_t b = j / GP_BLOCK_ROWS;
+    // per-block factor: (N of earlier blocks) * (D of later blocks) / (all D); 2 products per row is cheaper than another kernel
+    const Fr f = fe_mul(fe_mul(fe_load<FrP>(a.bt + b), fe_load<FrP>(a.bt + a.nblocks + b)), fe_load<FrP>(a.bt + 2 * a.nblocks + 1));
+    fe_store<FrP>(a.z + j + 1, fe_mul(fe_mul(fe_load<FrP>(a.z + j + 1), fe_load<FrP>(a.sd + j)), f));
 }
 
 int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
@@ -451,24 +494,42 @@ static int quot_setup_block(bbg_ctx* ctx, int slot, QuotientSetup** out)
     return BBG_OK;
 }
 
-// width = 4 (TurboPLONK, ProverPermutationWidget<4,false>) or 3 (StandardPLONK, <3,false>: w_4 / sigma_4 not read)
-int permutation_grand_product_w(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n,
-                                const uint64_t* challenges, void* d_z, hipStream_t st)
+// width = 4 (TurboPLONK, ProverPermutationWidget<4,false>) or 3 (StandardPLONK, <3,false>: w_4 / sigma_4 not read).
+// Two halves so that a caller can put independent work between them: _begin queues the row terms, the scans and -- on inv_stream,
+// ordered by events -- the single inversion; _finish makes `st` wait for it and applies it.
+static int gp_fill(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, void* d_z, GpArgs& a)
 {
     if (log2n > 28) { set_error("bbg_permutation_grand_product_device: log2n > 28"); return BBG_E_INVALID; }
     if (width != 3 && width != 4) { set_error("bbg_permutation_grand_product_device: width must be 3 or 4"); return BBG_E_INVALID; }
-    if (!d_wires || !d_sigmas || !challenges || !d_z) { set_error("bbg_permutation_grand_product_device: null argument"); return BBG_E_INVALID; }
-    GpArgs a;
+    if (!d_wires || !d_sigmas || !d_z) { set_error("bbg_permutation_grand_product_device: null argument"); return BBG_E_INVALID; }
     for (int k = 0; k < 4; k++) {
         if (k < width && (!d_wires[k] || !d_sigmas[k])) { set_error("bbg_permutation_grand_product_device: null polynomial"); return BBG_E_INVALID; }
         a.w[k] = k < width ? (const Fr*)d_wires[k] : nullptr;
         a.sigma[k] = k < width ? (const Fr*)d_sigmas[k] : nullptr;
     }
-    const size_t n = (size_t)1 << log2n, threads = (n + GP_E - 1) / GP_E;
-    QuotientSetup* setup = nullptr;
-    int rc = quot_setup_block(ctx, 0, &setup);
+    a.n = (size_t)1 << log2n;
+    a.nblocks = (a.n + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+    int rc = ensure_buffer(&ctx->gp_totals, &ctx->gp_totals_bytes, (a.n + 2 * a.nblocks + 2) * sizeof(Fr));
     if (rc) return rc;
-    rc = ensure_buffer(&ctx->gp_totals, &ctx->gp_totals_bytes, threads * sizeof(Fr));
+    a.sd = (Fr*)ctx->gp_totals;
+    a.bt = a.sd + a.n;
+    a.z = (Fr*)d_z;
+    QuotientSetup* setup = nullptr;
+    rc = quot_setup_block(ctx, QUOT_SETUPS - 1, &setup); // its own block: the widgets' chain uses blocks 0 ..
+    if (rc) return rc;
+    a.s = setup;
+    void* dc = nullptr;
+    rc = ntt_domain_consts(ctx, log2n, &dc);
+    if (rc) return rc;
+    a.dc = (const DomainConsts*)dc;
+    return BBG_OK;
+}
+int permutation_grand_product_begin(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n,
+                                    const uint64_t* challenges, void* d_z, hipStream_t st, hipStream_t inv_stream, hipEvent_t ev_ready, hipEvent_t ev_inverted)
+{
+    if (!challenges) { set_error("bbg_permutation_grand_product_device: null argument"); return BBG_E_INVALID; }
+    GpArgs a;
+    int rc = gp_fill(ctx, width, d_wires, d_sigmas, log2n, d_z, a);
     if (rc) return rc;
     // same set-up kernel as the widgets: slots alpha_base, alpha, delta, g are unused here (zeros)
     QuotientChallenges ch;
@@ -476,22 +537,40 @@ int permutation_grand_product_w(bbg_ctx* ctx, int width, const void* const* d_wi
     memcpy(&ch.v[2], challenges, 32);          // beta
     memcpy(&ch.v[3], challenges + 4, 32);      // gamma
     memcpy(&ch.v[6], challenges + 8, 3 * 32);  // k1..k3
-    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setup, ch, (const Fr*)nullptr);
-    void* dc = nullptr;
-    rc = ntt_domain_consts(ctx, log2n, &dc);
-    if (rc) return rc;
-    a.z = (Fr*)d_z;
-    a.totals = (Fr*)ctx->gp_totals;
-    a.n = n;
-    a.s = setup;
-    a.dc = (const DomainConsts*)dc;
-    ProfScope ps(ctx, "grand_product", st);
-    if (width == 4) hipLaunchKernelGGL(k_gp_ratio<4>, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL(k_gp_ratio<3>, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, a);
-    hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(256), 0, st, a.totals, threads);
-    hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, (QuotientSetup*)a.s, ch, (const Fr*)nullptr);
+    {
+        ProfScope ps(ctx, "grand_product", st);
+        if (width == 4) hipLaunchKernelGGL(k_gp_terms<4>, dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_gp_terms<3>, dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_gp_blocks, dim3(1), dim3(256), 0, st, a.bt, a.nblocks);
+    }
+    if (inv_stream != st) {
+        BBG_HIP(hipEventRecord(ev_ready, st));
+        BBG_HIP(hipStreamWaitEvent(inv_stream, ev_ready, 0));
+    }
+    hipLaunchKernelGGL(k_gp_invert, dim3(1), dim3(64), 0, inv_stream, a.bt, a.nblocks);
+    if (inv_stream != st) BBG_HIP(hipEventRecord(ev_inverted, inv_stream));
     BBG_HIP(hipGetLastError());
     return BBG_OK;
+}
+int permutation_grand_product_finish(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, void* d_z,
+                                     hipStream_t st, hipEvent_t ev_inverted)
+{
+    GpArgs a;
+    int rc = gp_fill(ctx, width, d_wires, d_sigmas, log2n, d_z, a);
+    if (rc) return rc;
+    if (ev_inverted) BBG_HIP(hipStreamWaitEvent(st, ev_inverted, 0));
+    ProfScope ps(ctx, "grand_product", st);
+    hipLaunchKernelGGL(k_gp_apply, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+int permutation_grand_product_w(bbg_ctx* ctx, int width, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n,
+                                const uint64_t* challenges, void* d_z, hipStream_t st)
+{
+    int rc = permutation_grand_product_begin(ctx, width, d_wires, d_sigmas, log2n, challenges, d_z, st, st, nullptr, nullptr);
+    if (rc) return rc;
+    return permutation_grand_product_finish(ctx, width, d_wires, d_sigmas, log2n, d_z, st, nullptr);
 }
 int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
                               void* d_z, hipStream_t st)
