@@ -137,8 +137,8 @@ void bbg_destroy(bbg_ctx* ctx)
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
     if (ctx->poly_scratch) (void)hipFree(ctx->poly_scratch);
     if (ctx->aux_stream) {
-        (void)hipStreamDestroy(ctx->aux_stream);
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
+            (void)hipStreamDestroy(ctx->aux_streams[k]);
             (void)hipEventDestroy(ctx->ev_acc[k]);
             (void)hipEventDestroy(ctx->ev_done[k]);
         }
@@ -151,7 +151,8 @@ int bbg_sync(bbg_ctx* ctx)
 {
     CHECK_CTX(ctx);
     BBG_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->aux_stream) BBG_HIP(hipStreamSynchronize(ctx->aux_stream));
+    if (ctx->aux_stream)
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) BBG_HIP(hipStreamSynchronize(ctx->aux_streams[k]));
     return BBG_OK;
 }
 
@@ -167,9 +168,12 @@ int bbg_join_lag(bbg_ctx* ctx, int lag)
     CHECK_CTX(ctx);
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (lag <= 0) return msm_join(ctx, ctx->stream);
-    if (lag > 1) return BBG_OK; // only two reductions can be outstanding: nothing older to wait for
-    const int older = (int)(ctx->msm_seq & 1); // slot of the MSM before the most recent one
-    if (ctx->ev_done_valid[older]) BBG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_done[older], 0));
+    // wait for every outstanding reduction except the `lag` most recent ones (slots are used round robin)
+    for (int back = lag; back < bbg_ctx::MSM_SLOTS; back++) {
+        if (ctx->msm_seq < (unsigned long)back + 1) break;
+        const int slot = (int)((ctx->msm_seq - 1 - (unsigned long)back) % bbg_ctx::MSM_SLOTS);
+        if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_done[slot], 0));
+    }
     return BBG_OK;
 }
 
@@ -197,13 +201,14 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         BBG_HIP(hipDeviceSynchronize());
         ctx->msm_reduce_low_priority = value != 0;
         if (ctx->aux_stream) {
-            (void)hipStreamDestroy(ctx->aux_stream);
-            ctx->aux_stream = nullptr;
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
+                (void)hipStreamDestroy(ctx->aux_streams[k]);
+                ctx->aux_streams[k] = nullptr;
                 (void)hipEventDestroy(ctx->ev_acc[k]);
                 (void)hipEventDestroy(ctx->ev_done[k]);
                 ctx->ev_done_valid[k] = false;
             }
+            ctx->aux_stream = nullptr;
         }
         return BBG_OK;
     }

@@ -851,7 +851,8 @@ struct MsmLayout {
     size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort, off_parts;
     uint32_t seg;
     // reduce-phase working set, double buffered so that the reduce of MSM i (aux stream) overlaps MSM i+1
-    size_t off_offsets[2], off_head[2], off_tail[2], off_buckets[2], off_rows[2], off_cols[2], off_long[2];
+    size_t off_offsets[bbg_ctx::MSM_SLOTS], off_head[bbg_ctx::MSM_SLOTS], off_tail[bbg_ctx::MSM_SLOTS], off_buckets[bbg_ctx::MSM_SLOTS], off_rows[bbg_ctx::MSM_SLOTS],
+        off_cols[bbg_ctx::MSM_SLOTS], off_long[bbg_ctx::MSM_SLOTS];
     size_t sort_bytes;
     size_t total;
 };
@@ -903,7 +904,7 @@ template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L
     L.off_vals1 = take(L.entries * 4);
     L.off_sort = take(L.sort_bytes);
     L.off_parts = take(3 * SORT_PAD * 4);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
         L.off_offsets[k] = take(((size_t)K::buckets + 2) * 4);
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
         L.off_tail[k] = take(L.lanes * sizeof(Xyzz));
@@ -972,22 +973,23 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
         // the caller queues next on the main stream (the following MSM's sort / accumulation, an NTT) is dispatched first
         int least = 0, greatest = 0;
         BBG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        BBG_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, ctx->msm_reduce_low_priority ? least : (least + greatest) / 2));
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
+            BBG_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[k], hipStreamNonBlocking, ctx->msm_reduce_low_priority ? least : (least + greatest) / 2));
             BBG_HIP(hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming));
             BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
         }
+        ctx->aux_stream = ctx->aux_streams[0];
     }
     if (ctx->msm_layout_n != n || ctx->msm_layout_c != C || ctx->msm_layout_sort != ctx->msm_sort) {
         // a different (n, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
         // regions this call is about to overwrite, so the main stream first waits for both slots (no host sync)
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++)
             if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
         ctx->msm_layout_n = n;
         ctx->msm_layout_c = C;
         ctx->msm_layout_sort = ctx->msm_sort;
     }
-    const int slot = (int)(ctx->msm_seq++ & 1);
+    const int slot = (int)(ctx->msm_seq++ % bbg_ctx::MSM_SLOTS);
     char* base = (char*)ctx->msm.buf;
     uint32_t* keys0 = (uint32_t*)(base + L.off_keys0);
     uint32_t* keys1 = (uint32_t*)(base + L.off_keys1);
@@ -1003,9 +1005,9 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
     uint32_t* long_count = (uint32_t*)(base + L.off_long[slot]);
     uint32_t* long_list = long_count + 1;
     const bool overlap = ctx->msm_async_reduce;
-    hipStream_t rst = overlap ? ctx->aux_stream : st; // stream of the reduce phase
+    hipStream_t rst = overlap ? ctx->aux_streams[slot] : st; // stream of the reduce phase
 
-    // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM two calls ago
+    // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM MSM_SLOTS calls ago
     if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[slot], 0));
     const uint32_t* svals;
     if (ctx->msm_sort == 1) {
@@ -1122,7 +1124,7 @@ int msm_debug_idx_mask(uint32_t mask)
 }
 int msm_join(bbg_ctx* ctx, hipStream_t st)
 {
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++)
         if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
     return BBG_OK;
 }
