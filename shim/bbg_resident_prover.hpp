@@ -24,12 +24,16 @@
 // rows written, like execute_preamble_round leaves them); the proof is the only output, as with the reference.
 #pragma once
 #include <array>
+#include <cerrno>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include <sys/random.h>
+
+#include <numeric/uintx/uintx.hpp>
 #include <plonk/proof_system/prover/prover.hpp>
 #include <plonk/proof_system/public_inputs/public_inputs.hpp>
 #include <plonk/proof_system/types/program_settings.hpp>
@@ -51,11 +55,30 @@ using barretenberg::g1;
     throw std::runtime_error(std::string(what) + ": " + bbg_last_error());
 }
 
-// where the blinding scalars come from: fr::random_element() unless a test replays recorded values
+// Where the blinding scalars come from.  Default: os_random_fr(), the distribution of fr::random_element() (a uniform 512-bit
+// string reduced mod r, field_impl.hpp:505-515) with the 64 bytes taken from the kernel CSPRNG in ONE getrandom(2) call.  The
+// reference's engine draws the same bytes through 64 separate std::random_device reads per element (numeric/random/engine.cpp:9-14,
+// :103-120), which measured 1.1 ms per element on the GPU box's host: 17 ms for the 15 scalars of a TurboPLONK proof that otherwise
+// takes 7-33 ms.  `random` overrides it (tests replay recorded values; a caller may plug its own DRBG).
 struct ResidentOptions {
     fr (*random)(void* user) = nullptr;
     void* user = nullptr;
 };
+inline fr os_random_fr()
+{
+    uint64_t w[8];
+    size_t have = 0;
+    while (have < sizeof(w)) {
+        const ssize_t got = getrandom(reinterpret_cast<char*>(w) + have, sizeof(w) - have, 0);
+        if (got < 0) {
+            if (errno == EINTR) continue;
+            throw std::runtime_error("bbg_shim: getrandom failed");
+        }
+        have += (size_t)got;
+    }
+    const uint512_t source(uint256_t(w[0], w[1], w[2], w[3]), uint256_t(w[4], w[5], w[6], w[7]));
+    return fr((source % uint512_t(fr::modulus)).lo);
+}
 
 // PolynomialIndex (types/polynomial_manifest.hpp:9-49) -> polynomial id of include/bbg.h; -1 = not known to the device
 inline int device_poly_id(waffle::PolynomialIndex index)
@@ -253,7 +276,7 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
     auto* key = p.key.get();
     auto* witness = p.witness.get();
     const size_t n = key->n;
-    auto random = [&]() { return opt.random ? opt.random(opt.user) : fr::random_element(); };
+    auto random = [&]() { return opt.random ? opt.random(opt.user) : os_random_fr(); };
     p.queue.flush_queue();
 
     // ---- preamble (prover.cpp:139-190): sizes, "init", three blinding scalars per wire in rows n-4 .. n-2 of its Lagrange form
