@@ -72,6 +72,21 @@ def pmc_counter(kernel, counter):
         return None
 
 
+VALU_PEAK_GWAVE = 1024 * 2.4 / 4  # 256 CUs x 4 SIMDs, one wave-instruction per 4 clocks at 2.4 GHz = 614 G wave-instructions/s
+
+
+def valu_issue(acc_ms, ntt_ms):
+    """What actually bounds these kernels: VALU instruction issue.  SQ_INSTS_VALU (wave-instructions per launch, committed PMC pass)
+    over the launch duration measured in THIS run, against the chip's issue peak."""
+    acc, ntt = pmc_counter("k_accumulate", "SQ_INSTS_VALU"), pmc_counter("k_ntt_pass8", "SQ_INSTS_VALU")
+    out = {"unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE) + " SQ_INSTS_VALU"}
+    if acc:
+        out["msm_accumulate"] = {"insts_per_launch": acc, "achieved": round(acc / (acc_ms * 1e-3) / 1e9, 1), "frac": round(acc / (acc_ms * 1e-3) / 1e9 / VALU_PEAK_GWAVE, 3)}
+    if ntt:
+        out["ntt_whole"] = {"insts_per_ntt": ntt, "achieved": round(ntt / (ntt_ms * 1e-3) / 1e9, 1), "frac": round(ntt / (ntt_ms * 1e-3) / 1e9 / VALU_PEAK_GWAVE, 3)}
+    return out
+
+
 def pmc_traffic_ntt():
     """HBM bytes of ONE whole NTT (both pass kernels, one launch each) from the committed PMC passes.  The passes stream wide
     coalesced rows, the case for which MI355X_MICROARCH.md prescribes FETCH_SIZE x 2 on gfx950; WRITE_SIZE is taken as reported."""
@@ -227,6 +242,7 @@ def main():
                          "avg_launch_ms": round(pass_ms, 4), "launches_per_ntt": ntt_passes,
                          "whole_ntt_frac": round(ntt_alg / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         "timed_blocks_ms": [round(b[0] * 1e3, 3) for b in blocks], "reported_block": "median",
+        "valu_issue": valu_issue(acc_ms, ntt_ms),
         "alu": {"unit": "T v_mad_u64_u32/s", "peak_measured": MAD_PEAK_TOPS,
                 # 16 windows x n mixed additions x 10 Fq mul x 136 mads ; n/2*(lg - passes) + n*(passes-1) Fr mul x 136
                 "msm_accumulate": round(16.0 * n * 10 * 136 / (acc_ms * 1e-3) / 1e12, 2),
