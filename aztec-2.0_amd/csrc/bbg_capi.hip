@@ -212,6 +212,11 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         }
         return BBG_OK;
     }
+    if (!strcmp(key, "msm_reduce_quad")) {
+        BBG_HIP(hipDeviceSynchronize());
+        ctx->msm_reduce_quad = (int)value & 15;
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_window")) {
         if (value != 0 && value != 16 && value != 20) { set_error("msm_window must be 0 (automatic), 16 or 20"); return BBG_E_INVALID; }
         ctx->msm_window = (int)value;

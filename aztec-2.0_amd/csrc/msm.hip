@@ -26,6 +26,7 @@
 // pippenger_unsafe's "attempted to invert zero" failure mode (:317-318) does not exist here.
 #include "bbg_internal.h"
 #include "curve.hip.h"
+#include "curve_quad.hip.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -802,6 +803,180 @@ __global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ pl
     }
 }
 
+// ------------------------------------------------------------------------------------ quad-cooperative reduce phase
+// The same reduce phase with every EC operation shared by FOUR adjacent lanes (curve_quad.hip.h): a logical lane lt = thread / 4,
+// q = thread % 4.  Identical structure and results; the dependency chain is ~3x shorter in time.  Blocks carry 4x the threads for the
+// same number of logical lanes (512 threads = 128 logical lanes, so that a thread may keep up to 256 VGPRs).
+__device__ __forceinline__ Xyzz block_reduce_q4(Xyzz v, Xyzz* sm, int nlogical)
+{
+    const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
+    for (int stride = nlogical >> 1; stride >= 1; stride >>= 1) {
+        if (q == 0 && lt >= stride && lt < 2 * stride) sm[lt - stride] = v;
+        __syncthreads();
+        if (lt < stride) v = xyzz_add_q4(v, sm[lt], q);
+        __syncthreads();
+    }
+    return v;
+}
+constexpr int Q_LOGICAL = 128, Q_THREADS = 4 * Q_LOGICAL;
+
+template <int C> __global__ void __launch_bounds__(Q_THREADS)
+k_combine_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+{
+    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t total = offsets[MSM_BUCKETS + 1];
+    const uint32_t gl = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int q = threadIdx.x & 3;
+    const uint32_t b = gl + 1;
+    if (b > MSM_BUCKETS) return;
+    const uint32_t base = offsets[1];
+    const uint32_t sb = offsets[b], eb = offsets[b + 1];
+    if (sb == eb) {
+        if (q == 0) xyzz_store(buckets + (b - 1), xyzz_inf());
+        return;
+    }
+    const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
+    const bool at_start = (sb == base + l0 * seg);
+    if (l0 == l1) {
+        uint32_t seg_end = base + (l0 + 1) * seg;
+        if (seg_end > total || seg_end < base) seg_end = total;
+        if (at_start) { if (q == 0) xyzz_store(buckets + (b - 1), xyzz_load(head + l0)); }
+        else if (eb == seg_end) { if (q == 0) xyzz_store(buckets + (b - 1), xyzz_load(tail + l0)); }
+        return; // else: complete run, already stored
+    }
+    if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
+        if (q == 0) {
+            const uint32_t slot = atomicAdd(long_count, 1u);
+            long_list[slot] = b;
+        }
+        return;
+    }
+    Xyzz acc = bucket_piece(head, tail, l0, l0, at_start);
+    for (uint32_t l = l0 + 1; l <= l1; l++) acc = xyzz_add_q4(acc, xyzz_load(head + l), q);
+    if (q == 0) xyzz_store(buckets + (b - 1), acc);
+}
+
+// MSM_COMBINE_LANES logical lanes (16 threads) per bucket, butterfly across the logical lanes (shuffle distances 8 and 4)
+template <int C> __global__ void __launch_bounds__(Q_THREADS)
+k_combine_lanes_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
+                  Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+{
+    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t total = offsets[MSM_BUCKETS + 1];
+    const uint32_t gl = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int q = threadIdx.x & 3;
+    const uint32_t b = gl / MSM_COMBINE_LANES + 1;
+    const uint32_t r = gl % MSM_COMBINE_LANES;
+    if (b > MSM_BUCKETS) return; // whole waves drop out together (64 threads = 4 buckets)
+    const uint32_t base = offsets[1];
+    const uint32_t sb = offsets[b], eb = offsets[b + 1];
+    bool store = true, reduce = false;
+    Xyzz acc = xyzz_inf();
+    if (sb != eb) {
+        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
+        const bool at_start = (sb == base + l0 * seg);
+        if (l0 == l1) {
+            uint32_t seg_end = base + (l0 + 1) * seg;
+            if (seg_end > total || seg_end < base) seg_end = total;
+            if (at_start) acc = xyzz_load(head + l0);
+            else if (eb == seg_end) acc = xyzz_load(tail + l0);
+            else store = false; // complete run, already written by k_accumulate
+        } else if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
+            if (r == 0 && q == 0) {
+                const uint32_t slot = atomicAdd(long_count, 1u);
+                long_list[slot] = b;
+            }
+            store = false;
+        } else {
+            reduce = true;
+            for (uint32_t l = l0 + r; l <= l1; l += MSM_COMBINE_LANES) acc = xyzz_add_q4(acc, bucket_piece(head, tail, l, l0, at_start), q);
+        }
+    }
+    if (!reduce && !(sb != eb && store)) acc = xyzz_inf();
+    const unsigned long long any = __ballot(reduce);
+    if (any) {
+        Xyzz part = reduce ? acc : xyzz_inf();
+        for (int m = MSM_COMBINE_LANES >> 1; m >= 1; m >>= 1) part = xyzz_add_q4(part, xyzz_shfl_xor(part, 4 * m), q);
+        if (reduce) acc = part;
+    }
+    if (store && r == 0 && q == 0) xyzz_store(buckets + (b - 1), acc);
+}
+
+template <int C> __global__ void __launch_bounds__(Q_THREADS)
+k_combine_long_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
+                 const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list)
+{
+    __shared__ Xyzz sm[Q_LOGICAL / 2];
+    const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const uint32_t cnt = *long_count;
+    const uint32_t base = offsets[1];
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        const uint32_t b = long_list[i];
+        const uint32_t sb = offsets[b], eb = offsets[b + 1];
+        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
+        const bool at_start = (sb == base + l0 * seg);
+        Xyzz acc = xyzz_inf();
+        for (uint32_t l = l0 + lt; l <= l1; l += Q_LOGICAL) acc = xyzz_add_q4(acc, bucket_piece(head, tail, l, l0, at_start), q);
+        acc = block_reduce_q4(acc, sm, Q_LOGICAL);
+        if (threadIdx.x == 0) xyzz_store(buckets + (b - 1), acc);
+        __syncthreads();
+    }
+}
+
+template <int C> __global__ void __launch_bounds__(Q_THREADS) k_rowcol_q(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
+{
+    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
+    __shared__ Xyzz sm[Q_LOGICAL / 2];
+    const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
+    Xyzz v = xyzz_inf();
+    if (blockIdx.x < ROWS) {
+        const int hi = blockIdx.x;
+        for (int lo = lt; lo < COLS; lo += Q_LOGICAL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
+        v = block_reduce_q4(v, sm, Q_LOGICAL);
+        if (threadIdx.x == 0) xyzz_store(rows + hi, v);
+    } else {
+        const int lo = blockIdx.x - ROWS;
+        for (int hi = lt; hi < ROWS; hi += Q_LOGICAL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
+        v = block_reduce_q4(v, sm, Q_LOGICAL);
+        if (threadIdx.x == 0) xyzz_store(cols + lo, v);
+    }
+}
+
+template <int C> __global__ void __launch_bounds__(Q_THREADS) k_final_planes_q(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Xyzz* planes)
+{
+    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols, LOGC = MsmCfg<C>::log_cols;
+    __shared__ Xyzz sm[Q_LOGICAL / 2];
+    const int t = blockIdx.x, lt = threadIdx.x >> 2, q = threadIdx.x & 3;
+    Xyzz v = xyzz_inf();
+    if (t <= LOGC)
+        for (int lo = lt; lo < COLS; lo += Q_LOGICAL)
+            if (((lo + 1) >> t) & 1) v = xyzz_add_q4(v, xyzz_load(cols + lo), q);
+    if (t >= LOGC)
+        for (int hi = lt; hi < ROWS; hi += Q_LOGICAL)
+            if ((hi >> (t - LOGC)) & 1) v = xyzz_add_q4(v, xyzz_load(rows + hi), q);
+    v = block_reduce_q4(v, sm, Q_LOGICAL);
+    if (lt == 0) {
+        for (int k = 0; k < t; k++) v = xyzz_dbl_q4(v, q);
+        if (q == 0) xyzz_store(planes + t, v);
+    }
+}
+__global__ void __launch_bounds__(4 * MSM_MAX_PLANES) k_final_sum_q(const Xyzz* __restrict__ planes, int nplanes, Jacobian* out)
+{
+    __shared__ Xyzz sm[MSM_MAX_PLANES / 2];
+    const int lt = threadIdx.x >> 2;
+    Xyzz v = lt < nplanes ? xyzz_load(planes + lt) : xyzz_inf();
+    int width = 1;
+    while (width < nplanes) width <<= 1; // 15 planes -> 4 levels, not 5
+    v = block_reduce_q4(v, sm, width);
+    if (threadIdx.x == 0) {
+        Jacobian j = xyzz_to_jacobian(v);
+        fe_store<FqP>(&out->x, j.x);
+        fe_store<FqP>(&out->y, j.y);
+        fe_store<FqP>(&out->z, j.z);
+    }
+}
+
 // sum of n Jacobian points (g1_sum, reference c_bind.cpp:39-46): one block, serial per thread then tree.
 __global__ void __launch_bounds__(256, 1) k_g1_sum(const Jacobian* __restrict__ pts, size_t n, Jacobian* out)
 {
@@ -1060,16 +1235,32 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
     }
     {
         ProfScope ps(ctx, "msm_reduce", rst);
-        if (L.lanes > (size_t)2 * K::buckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
-            hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
-                               L.seg, head, tail, buckets, long_count, long_list);
-        else
-            hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
-                               buckets, long_count, long_list);
-        hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
-        hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
-        hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (int)K::planes, (Jacobian*)d_out_jac);
+        // msm_reduce_quad: bit 0 combine, bit 1 row/column sums, bit 2 bit planes, bit 3 plane sum -- each stage either with four lanes per EC
+        // operation (curve_quad.hip.h: the same chain, ~3x shorter in time) or with one (the round-1 kernels, kept for A/B)
+        const int quad = ctx->msm_reduce_quad;
+        if (quad & 1) {
+            if (L.lanes > (size_t)2 * K::buckets)
+                hipLaunchKernelGGL(k_combine_lanes_q<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst,
+                                   offsets, L.seg, head, tail, buckets, long_count, long_list);
+            else
+                hipLaunchKernelGGL(k_combine_q<C>, dim3(grid_for((size_t)K::buckets * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail,
+                                   buckets, long_count, long_list);
+            hipLaunchKernelGGL(k_combine_long_q<C>, dim3(256), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
+        } else {
+            if (L.lanes > (size_t)2 * K::buckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
+                hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
+                                   L.seg, head, tail, buckets, long_count, long_list);
+            else
+                hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
+                                   buckets, long_count, long_list);
+            hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
+        }
+        if (quad & 2) hipLaunchKernelGGL(k_rowcol_q<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(Q_THREADS), 0, rst, buckets, rows, cols);
+        else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
+        if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
+        else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
+        if (quad & 8) hipLaunchKernelGGL(k_final_sum_q, dim3(1), dim3(4 * MSM_MAX_PLANES), 0, rst, planes, (int)K::planes, (Jacobian*)d_out_jac);
+        else hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (int)K::planes, (Jacobian*)d_out_jac);
     }
     if (overlap) {
         BBG_HIP(hipEventRecord(ctx->ev_done[slot], rst));

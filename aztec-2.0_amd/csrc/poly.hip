@@ -93,10 +93,9 @@ struct DpvConsts {
     Fr inv_sub[DPV_MAX_EXT]; // 1 / ((g w_ext^j)^n - 1)
     Fr numer[DPV_MAX_CUT];   // -w_src^-(k+1)
 };
-// context scratch: two evaluation points (zeta, zeta * w), the Z*_H constants, MEV_MAX results, then the partial sums
+// context scratch: two evaluation points (zeta, zeta * w), MEV_MAX results, then the partial sums
 struct PolyHeader {
     PolyScratch ps[2];
-    DpvConsts dpv;
     Fr results[MEV_MAX];
 };
 static int poly_scratch(bbg_ctx* ctx, size_t partials, PolyHeader** hdr, Fr** part)
