@@ -87,9 +87,39 @@ template <int S> __device__ __forceinline__ void p8_butterfly(Fr (&x)[8], const 
 __device__ __forceinline__ constexpr int p8_brev3(int j) { return ((j & 1) << 2) | (j & 2) | ((j >> 2) & 1); }
 
 // one step: FIRST loads from global, LAST stores to global, otherwise through LDS
+// where the LAST step of a pass delivers register j of this thread: the in-tile position pj (bit-reversed on the way out) and column c
+template <int LOGR> __device__ __forceinline__ void p8_last_coords(int tid, int j, int& pj, int& c)
+{
+    constexpr int NSTEPS = (LOGR + 2) / 3, T = NSTEPS - 1;
+    constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    constexpr int LOGW = P8_TILE_LOG - LOGR, W = 1 << LOGW;
+    c = tid & (W - 1);
+    const int q = tid >> LOGW;
+    const int qlo = q & ((1 << F) - 1);
+    pj = (((q >> F) << (F + 3)) | qlo) | (j << F);
+}
+// global index of that output (column pass: also the index into the inter-pass twiddle table; row pass: the natural output index)
+template <int LOGR, bool ROW>
+__device__ __forceinline__ size_t p8_out_index(const PassParams& p, int pj, int c, size_t base, size_t lo0, size_t d1_0, size_t rest, bool twiddle)
+{
+    const uint32_t i = __brev((uint32_t)pj) >> (32 - LOGR);
+    if (!ROW) return (twiddle ? lo0 : base) + ((size_t)i << p.logS) + c;
+    size_t acc = 0;
+    int shift = 0;
+    if (p.nmid == 1) {
+        acc = rest;
+        shift = p.logMid[0];
+    } else if (p.nmid == 2) {
+        const size_t d3 = rest & (((size_t)1 << p.logMid[1]) - 1), d2 = rest >> p.logMid[1];
+        acc = d2 + (d3 << p.logMid[0]);
+        shift = p.logMid[0] + p.logMid[1];
+    }
+    return (d1_0 + c) + (acc << p.logR1) + ((size_t)i << (p.logR1 + shift));
+}
+
 template <int LOGR, bool ROW, int T>
 __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* plo, uint4* phi, const Fr* __restrict__ tw, size_t base,
-                                        size_t lo0, size_t d1_0, size_t rest, int logRestCount)
+                                        size_t lo0, size_t d1_0, size_t rest, int logRestCount, const Fr (&outmul)[8], bool have_outmul)
 {
     constexpr int NSTEPS = (LOGR + 2) / 3;
     constexpr bool FIRST = (T == 0), LAST = (T == NSTEPS - 1);
@@ -162,26 +192,9 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
         if (!LAST) {
             p8_lds_store(plo, phi, p8_addr(pj, c, LOGW), x[j]);
         } else {
-            const uint32_t i = __brev((uint32_t)pj) >> (32 - LOGR);
             Fr v = x[j];
-            size_t dst;
-            if (!ROW) {
-                if (p.tw_inter) v = fe_mul(v, fe_load<FrP>(p.tw_inter + ((size_t)i << p.logS) + lo0 + c));
-                dst = base + ((size_t)i << p.logS) + c;
-            } else {
-                size_t acc = 0;
-                int shift = 0;
-                if (p.nmid == 1) {
-                    acc = rest;
-                    shift = p.logMid[0];
-                } else if (p.nmid == 2) {
-                    const size_t d3 = rest & (((size_t)1 << p.logMid[1]) - 1), d2 = rest >> p.logMid[1];
-                    acc = d2 + (d3 << p.logMid[0]);
-                    shift = p.logMid[0] + p.logMid[1];
-                }
-                dst = (d1_0 + c) + (acc << p.logR1) + ((size_t)i << (p.logR1 + shift));
-                if (p.post) v = fe_mul(v, fe_load<FrP>(p.post + dst));
-            }
+            if (have_outmul) v = fe_mul(v, outmul[j]); // inter-pass twiddle (column pass) / post-scale table (row pass), fetched steps ago
+            const size_t dst = p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false);
             fe_store<FrP>(p.out + dst, v);
         }
     }
@@ -209,19 +222,36 @@ template <int LOGR, bool ROW> __global__ void __launch_bounds__(256) k_ntt_pass8
         d1_0 = (tile >> logRestCount) << LOGW;
     }
     const Fr* tw = p.tw_radix; // w_R^x, x < R
-    Fr x[8];
-    p8_step<LOGR, ROW, 0>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount);
+    Fr x[8], outmul[8];
+    // The multiplier each output takes on its way out (inter-pass twiddle / post table) is a 32-byte HBM read per element whose address
+    // is known from the start.  Fetched here -- behind the data loads, ahead of all the arithmetic -- instead of one at a time in the
+    // last step, where with two waves per SIMD nothing covers the latency.  64 VGPRs; occupancy is bounded by LDS (2 blocks per CU).
+    const Fr* mul_table = ROW ? p.post : p.tw_inter;
+    const bool have_outmul = mul_table != nullptr;
+    auto fetch_outmul = [&]() {
+        if (have_outmul) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int pj, c;
+                p8_last_coords<LOGR>(threadIdx.x, j, pj, c);
+                outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, true));
+            }
+        }
+    };
+    if constexpr (NSTEPS == 1) fetch_outmul();
+    p8_step<LOGR, ROW, 0>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 1 && have_outmul);
     if constexpr (NSTEPS > 1) {
+        fetch_outmul();
         __syncthreads();
-        p8_step<LOGR, ROW, 1>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount);
+        p8_step<LOGR, ROW, 1>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 2 && have_outmul);
     }
     if constexpr (NSTEPS > 2) {
         __syncthreads();
-        p8_step<LOGR, ROW, 2>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount);
+        p8_step<LOGR, ROW, 2>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 3 && have_outmul);
     }
     if constexpr (NSTEPS > 3) {
         __syncthreads();
-        p8_step<LOGR, ROW, 3>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount);
+        p8_step<LOGR, ROW, 3>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 4 && have_outmul);
     }
 }
 
