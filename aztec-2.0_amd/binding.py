@@ -102,6 +102,7 @@ def load_library():
         "bbg_profile_enable": (cint, [vp, cint]),
         "bbg_profile_get": (cint, [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(sz)]),
         "bbg_prover_create": (cint, [vp, vp, ctypes.c_uint, cint, vp, ctypes.POINTER(vp)]),
+        "bbg_prover_create_flavour": (cint, [vp, vp, ctypes.c_uint, cint, vp, ctypes.POINTER(vp)]),
         "bbg_prover_destroy": (None, [vp]),
         "bbg_prover_set_key_poly": (cint, [vp, cint, cint, vp]),
         "bbg_prover_finalize_key": (cint, [vp]),
@@ -141,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
     "bbg_dev_upload", "bbg_dev_download", "bbg_set_option", "bbg_field_op", "bbg_profile_enable", "bbg_profile_get",
     "bbg_srs_write_transcript", "bbg_transcript_checksum", "bbg_srs_register_transcript_buffer",
-    "bbg_prover_create", "bbg_prover_destroy", "bbg_prover_set_key_poly", "bbg_prover_finalize_key", "bbg_prover_round1", "bbg_prover_round3",
+    "bbg_prover_create", "bbg_prover_create_flavour", "bbg_prover_destroy", "bbg_prover_set_key_poly", "bbg_prover_finalize_key", "bbg_prover_round1", "bbg_prover_round3",
     "bbg_prover_round4", "bbg_prover_evaluate", "bbg_prover_linearise", "bbg_prover_round6", "bbg_prover_read_poly",
     "bbg_multi_create", "bbg_multi_destroy", "bbg_multi_count", "bbg_multi_ctx", "bbg_multi_sync", "bbg_multi_srs_register",
     "bbg_multi_srs_synth_hashed", "bbg_multi_srs_num_points", "bbg_multi_msm", "bbg_multi_ntt_device", "bbg_multi_ntt",
@@ -306,8 +307,10 @@ class Bbg:
         self._ck(self.lib.bbg_permutation_grand_product_device(self.ctx, w, s_, log2n, ch.ctypes.data, ctypes.c_void_p(d_z)))
 
     def quotient_widget_device(self, widget, d_polys, log2_large, challenges, d_quotient):
-        """d_polys: list of BBG_QP_COUNT device addresses (0 = not supplied); challenges: (9, 4) uint64.  Returns the next alpha_base."""
-        arr = (ctypes.c_void_p * len(d_polys))(*[ctypes.c_void_p(int(p)) if p else None for p in d_polys])
+        """d_polys: list of BBG_QP_COUNT device addresses (0 = not supplied), BBG_QP_EXT_COUNT = 23 for the MiMC widget (7);
+        challenges: (9, 4) uint64.  Returns the next alpha_base."""
+        padded = list(d_polys) + [0] * max(0, 23 - len(d_polys))  # the library may read the extended table: never hand it a short array
+        arr = (ctypes.c_void_p * len(padded))(*[ctypes.c_void_p(int(p)) if p else None for p in padded])
         ch = np.ascontiguousarray(challenges, dtype=np.uint64)
         assert ch.shape == (9, 4)
         out = np.zeros(4, dtype=np.uint64)

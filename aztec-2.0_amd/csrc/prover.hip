@@ -56,12 +56,13 @@ struct bbg_prover {
     bbg_srs* srs = nullptr;
     unsigned log2n = 0;
     int width = 4;
+    int flavour = BBG_FLAVOUR_TURBO;
     size_t n = 0;
     uint64_t gens[16] = { 0 };   // g, k1, k2, k3 (Montgomery)
     uint64_t beta[4] = { 0 }, gamma[4] = { 0 };
     // per proving key
-    void* key_coeff[BBG_QP_COUNT] = {};
-    void* key_coset[BBG_QP_COUNT] = {};
+    void* key_coeff[BBG_QP_EXT_COUNT] = {}; // indexed by key_slot(id)
+    void* key_coset[BBG_QP_EXT_COUNT] = {};
     void* sigma_lagrange[4] = {};
     bool key_final = false;
     // per proof
@@ -127,6 +128,15 @@ int to_coset(bbg_prover* p, const void* d_coeff, void* d_out, hipStream_t st)
     return ntt_coset_extend(p->ctx, d_coeff, p->n, d_out, p->log2n + 2, st); // no staging copy, no zero fill, g^j fused into the first load
 }
 
+// slot of a key polynomial id in key_coeff / key_coset (the widget table's index), -1 for ids that are not key polynomials
+int key_slot(int id)
+{
+    if (id > BBG_QP_Z && id < BBG_QP_COUNT) return id;
+    if (id == BBG_PP_Q_MIMC_COEFFICIENT) return BBG_QP_EXT_Q_MIMC_COEFFICIENT;
+    if (id == BBG_PP_Q_MIMC_SELECTOR) return BBG_QP_EXT_Q_MIMC_SELECTOR;
+    return -1;
+}
+
 // device address and length of a polynomial id (bbg_quotient_poly / bbg_prover_poly) in coefficient form
 int coeff_poly(const bbg_prover* p, int id, const void** ptr, size_t* len)
 {
@@ -143,6 +153,7 @@ int coeff_poly(const bbg_prover* p, int id, const void** ptr, size_t* len)
     else if (id == BBG_PP_LINEAR) *ptr = p->linear;
     else if (id == BBG_PP_OPENING) *ptr = p->opening[0];
     else if (id == BBG_PP_SHIFTED_OPENING) *ptr = p->opening[1];
+    else if (id == BBG_PP_Q_MIMC_COEFFICIENT || id == BBG_PP_Q_MIMC_SELECTOR) *ptr = p->key_coeff[key_slot(id)];
     else *ptr = nullptr;
     if (!*ptr) { set_error("bbg_prover: polynomial id not available in coefficient form (unknown id, or never registered)"); return BBG_E_INVALID; }
     return BBG_OK;
@@ -154,9 +165,19 @@ extern "C" {
 
 int bbg_prover_create(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int program_width, const uint64_t* generators, bbg_prover** out)
 {
+    if (program_width != 3 && program_width != 4) { set_error("bbg_prover_create: program_width must be 3 (StandardPLONK) or 4 (TurboPLONK)"); return BBG_E_INVALID; }
+    return bbg_prover_create_flavour(ctx, srs, log2n, program_width == 4 ? BBG_FLAVOUR_TURBO : BBG_FLAVOUR_STANDARD, generators, out);
+}
+
+int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int flavour, const uint64_t* generators, bbg_prover** out)
+{
     if (!ctx || !srs || !generators || !out) { set_error("bbg_prover_create: null argument"); return BBG_E_INVALID; }
     BBG_HIP(hipSetDevice(ctx->device));
-    if (program_width != 3 && program_width != 4) { set_error("bbg_prover_create: program_width must be 3 (StandardPLONK) or 4 (TurboPLONK)"); return BBG_E_INVALID; }
+    if (flavour != BBG_FLAVOUR_TURBO && flavour != BBG_FLAVOUR_STANDARD && flavour != BBG_FLAVOUR_MIMC) {
+        set_error("bbg_prover_create_flavour: unknown flavour");
+        return BBG_E_INVALID;
+    }
+    const int program_width = flavour == BBG_FLAVOUR_TURBO ? 4 : 3;
     if (log2n < 3 || log2n > 26) { set_error("bbg_prover_create: need 3 <= log2n <= 26 (the quotient lives on the 4n domain)"); return BBG_E_INVALID; }
     const size_t n = (size_t)1 << log2n;
     if (srs->s.n < n + (program_width == 3 ? 1 : 0)) {
@@ -169,6 +190,7 @@ int bbg_prover_create(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int program_wi
     p->srs = srs;
     p->log2n = log2n;
     p->width = program_width;
+    p->flavour = flavour;
     p->n = n;
     memcpy(p->gens, generators, sizeof(p->gens));
     int rc = BBG_OK;
@@ -218,14 +240,15 @@ int bbg_prover_set_key_poly(bbg_prover* p, int id, int form, const uint64_t* val
 {
     CHECK_P(p);
     if (!values) { set_error("bbg_prover_set_key_poly: null values"); return BBG_E_INVALID; }
-    if (id <= BBG_QP_Z || id >= BBG_QP_COUNT) { set_error("bbg_prover_set_key_poly: id must be a selector / permutation / L_1 polynomial"); return BBG_E_INVALID; }
+    const int ks = key_slot(id);
+    if (ks < 0) { set_error("bbg_prover_set_key_poly: id must be a selector / permutation / L_1 polynomial"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
     const size_t n = p->n;
     void** slot = nullptr;
     size_t count = n;
-    if (form == BBG_FORM_COEFF && id != BBG_QP_LAGRANGE_1) slot = &p->key_coeff[id];
+    if (form == BBG_FORM_COEFF && id != BBG_QP_LAGRANGE_1) slot = &p->key_coeff[ks];
     else if (form == BBG_FORM_LAGRANGE && id >= BBG_QP_SIGMA_1 && id <= BBG_QP_SIGMA_4) slot = &p->sigma_lagrange[id - BBG_QP_SIGMA_1];
-    else if (form == BBG_FORM_COSET) { slot = &p->key_coset[id]; count = 4 * n; }
+    else if (form == BBG_FORM_COSET) { slot = &p->key_coset[ks]; count = 4 * n; }
     if (!slot) { set_error("bbg_prover_set_key_poly: this polynomial is not kept in that form"); return BBG_E_INVALID; }
     if (!*slot) {
         int rc = dev_alloc(p, slot, count * 32);
@@ -244,8 +267,8 @@ int bbg_prover_finalize_key(bbg_prover* p)
     hipStream_t st = p->ctx->stream;
     const size_t n = p->n;
     int rc = BBG_OK;
-    for (int id = BBG_QP_SIGMA_1; id < BBG_QP_LAGRANGE_1 && !rc; id++) {
-        if (!p->key_coeff[id]) continue;
+    for (int id = BBG_QP_SIGMA_1; id < BBG_QP_EXT_COUNT && !rc; id++) { // slots: the widget table's indices
+        if (id == BBG_QP_LAGRANGE_1 || !p->key_coeff[id]) continue;
         if (!p->key_coset[id]) { // coefficient form -> values on the 4n coset (what compute_proving_key's selector FFTs hold)
             rc = dev_alloc(p, &p->key_coset[id], 4 * n * 32);
             if (!rc) rc = to_coset(p, p->key_coeff[id], p->key_coset[id], st);
@@ -353,8 +376,8 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
     hipStream_t st = p->ctx->stream;
     AsyncReduce ar(p->ctx);
     const size_t n = p->n;
-    const void* polys[BBG_QP_COUNT];
-    for (int k = 0; k < BBG_QP_COUNT; k++) polys[k] = p->key_coset[k];
+    const void* polys[BBG_QP_EXT_COUNT];
+    for (int k = 0; k < BBG_QP_EXT_COUNT; k++) polys[k] = p->key_coset[k];
     for (int k = 0; k < 4; k++) polys[BBG_QP_W_1 + k] = k < p->width ? p->coset[k] : nullptr;
     polys[BBG_QP_Z] = p->coset[4];
     uint64_t ch[36];
@@ -367,8 +390,10 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
     static const int TURBO[5] = { BBG_WIDGET_PERMUTATION, BBG_WIDGET_TURBO_ARITHMETIC, BBG_WIDGET_TURBO_FIXED_BASE, BBG_WIDGET_TURBO_RANGE,
                                   BBG_WIDGET_TURBO_LOGIC };                                        // turbo_composer.cpp:735-752
     static const int STANDARD[2] = { BBG_WIDGET_PERMUTATION_3, BBG_WIDGET_ARITHMETIC };            // standard_composer.cpp:569-577
-    int rc = quotient_widgets_chain(p->ctx, p->width == 4 ? TURBO : STANDARD, p->width == 4 ? 5 : 2, polys, p->log2n + 2, ch, p->quotient,
-                                    nullptr, st);
+    static const int MIMC[3] = { BBG_WIDGET_PERMUTATION_3, BBG_WIDGET_MIMC, BBG_WIDGET_ARITHMETIC }; // mimc_composer.cpp:285-294
+    const int* widgets = p->flavour == BBG_FLAVOUR_TURBO ? TURBO : p->flavour == BBG_FLAVOUR_MIMC ? MIMC : STANDARD;
+    const int widget_count = p->flavour == BBG_FLAVOUR_TURBO ? 5 : p->flavour == BBG_FLAVOUR_MIMC ? 3 : 2;
+    int rc = quotient_widgets_chain(p->ctx, widgets, widget_count, polys, p->log2n + 2, ch, p->quotient, nullptr, st);
     if (!rc) rc = poly_divide_pseudo_vanishing(p->ctx, p->quotient, p->log2n, p->log2n + 2, 4, st);
     if (!rc) rc = ntt_run(p->ctx, p->quotient, p->log2n + 2, BBG_COSET_IFFT, 0, nullptr, st);
     // T_1 .. T_width: n coefficients each; t_high of StandardPLONK has n + 1 (compute_quotient_pre_commitment, prover.cpp:117-137)
@@ -499,7 +524,7 @@ int bbg_prover_read_poly(bbg_prover* p, int id, int form, uint64_t* out, size_t 
     } else if (form == BBG_FORM_COSET) {
         len = 4 * p->n;
         if (id >= BBG_QP_W_1 && id <= BBG_QP_Z) src = p->coset[id];
-        else if (id > BBG_QP_Z && id < BBG_QP_COUNT) src = p->key_coset[id];
+        else if (key_slot(id) >= 0) src = p->key_coset[key_slot(id)];
     }
     if (!src || count > len) { set_error("bbg_prover_read_poly: polynomial not available in that form, or count too large"); return BBG_E_INVALID; }
     BBG_HIP(hipMemcpyAsync(out, src, count * 32, hipMemcpyDeviceToHost, p->ctx->stream));

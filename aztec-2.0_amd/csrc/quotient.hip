@@ -22,8 +22,11 @@
 namespace bbg {
 
 enum { QP_W1 = 0, QP_W2, QP_W3, QP_W4, QP_Z, QP_S1, QP_S2, QP_S3, QP_S4, QP_Q1, QP_Q2, QP_Q3, QP_Q4, QP_Q5, QP_QM, QP_QC,
-       QP_QARITH, QP_QECC, QP_QRANGE, QP_QLOGIC, QP_L1, QP_COUNT };
-static_assert(QP_COUNT == BBG_QP_COUNT, "include/bbg.h and quotient.hip disagree on the polynomial table");
+       QP_QARITH, QP_QECC, QP_QRANGE, QP_QLOGIC, QP_L1, QP_COUNT,
+       QP_QMIMC_C = QP_COUNT, QP_QMIMC_S, QP_EXT_COUNT }; // the MiMC widget's two selectors: the extended table (bbg.h)
+static_assert(QP_COUNT == BBG_QP_COUNT && QP_EXT_COUNT == BBG_QP_EXT_COUNT && QP_QMIMC_C == BBG_QP_EXT_Q_MIMC_COEFFICIENT,
+              "include/bbg.h and quotient.hip disagree on the polynomial table");
+constexpr int WIDGET_COUNT = 8;
 
 struct QuotientSetup {
     Fr ap[7];       // alpha_base * alpha^k
@@ -32,10 +35,10 @@ struct QuotientSetup {
     Fr beta_g;      // beta * g (g = the small domain's coset generator): beta*g*w^i is the identity-permutation term
     Fr k1, k2, k3;  // coset generators of the wire columns 2..4 (fr::coset_generator(0..2))
     Fr one, c2, c3, c6, c7, c17, c81, c83;
-    Fr alpha_out[7]; // per widget: the alpha_base the next widget starts from
+    Fr alpha_out[WIDGET_COUNT]; // per widget: the alpha_base the next widget starts from
 };
 struct QuotientArgs {
-    const Fr* p[QP_COUNT];
+    const Fr* p[QP_EXT_COUNT];
     Fr* quotient;
     uint32_t mask; // 4n - 1
     const QuotientSetup* s;
@@ -92,6 +95,7 @@ __global__ void k_quotient_setup(QuotientSetup* s, QuotientChallenges in, const 
     s->alpha_out[4] = fe_mul(s->ap[3], alpha);       // logic: 4
     s->alpha_out[5] = s->alpha_out[0];               // permutation, 3 wires
     s->alpha_out[6] = s->ap[1];                      // standard arithmetic: 1 relation
+    s->alpha_out[7] = s->ap[2];                      // MiMC: 2 relations
 }
 
 #define QLOAD(id, idx) fe_load<FrP>(a.p[id] + (idx))
@@ -163,6 +167,22 @@ __global__ void __launch_bounds__(256) k_quotient_standard_arith(QuotientArgs a)
     gate = fe_add(gate, QLOAD(QP_QC, i));
     const Fr q = fe_load<FrP>(a.quotient + i);
     fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(gate, s.ap[0])));
+}
+
+// ---- MiMC round gate (mimc_widget.hpp:17-52), T = w1 + w3 + q_mimc_coefficient:
+//   q_mimc_selector alpha_base [ (T^3 - w2) + alpha (w2^2 T - w3(wX)) ]         (w2 = the cube, w3(wX) = the next round's input)
+__global__ void __launch_bounds__(256) k_quotient_mimc(QuotientArgs a)
+{
+    const QuotientSetup& s = *a.s;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const Fr w2 = QLOAD(QP_W2, i);
+    const Fr t = fe_add(fe_add(QLOAD(QP_W1, i), QLOAD(QP_W3, i)), QLOAD(QP_QMIMC_C, i));
+    const Fr cube = fe_sub(fe_mul(fe_sqr(t), t), w2);
+    const Fr out = fe_sub(fe_mul(fe_sqr(w2), t), QLOAD(QP_W3, (i + 4) & a.mask));
+    const Fr id = fe_add(fe_mul(cube, s.ap[0]), fe_mul(out, s.ap[1]));
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(id, QLOAD(QP_QMIMC_S, i))));
 }
 
 // ---- turbo arithmetic gate:
@@ -579,7 +599,7 @@ int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const vo
 }
 
 // which polynomials each widget reads (a null pointer for one of them is an error; the others may be null)
-static const uint32_t WIDGET_NEEDS[7] = {
+static const uint32_t WIDGET_NEEDS[WIDGET_COUNT] = {
     (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) |
         (1u << QP_S4) | (1u << QP_L1),
     (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_Q4) |
@@ -590,6 +610,7 @@ static const uint32_t WIDGET_NEEDS[7] = {
     (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_W4) | (1u << QP_QC) | (1u << QP_QLOGIC),
     (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Z) | (1u << QP_S1) | (1u << QP_S2) | (1u << QP_S3) | (1u << QP_L1),
     (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_Q1) | (1u << QP_Q2) | (1u << QP_Q3) | (1u << QP_QM) | (1u << QP_QC),
+    (1u << QP_W1) | (1u << QP_W2) | (1u << QP_W3) | (1u << QP_QMIMC_C) | (1u << QP_QMIMC_S),
 };
 
 static int launch_widget(bbg_ctx* ctx, int widget, const QuotientArgs& a, size_t m, hipStream_t st)
@@ -599,6 +620,7 @@ static int launch_widget(bbg_ctx* ctx, int widget, const QuotientArgs& a, size_t
     case 0: hipLaunchKernelGGL(k_quotient_permutation<4>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
     case 5: hipLaunchKernelGGL(k_quotient_permutation<3>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
     case 6: hipLaunchKernelGGL(k_quotient_standard_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL(k_quotient_mimc, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     case 1: hipLaunchKernelGGL(k_quotient_turbo_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
     case 2:
         hipLaunchKernelGGL(k_quotient_turbo_fixed_base_linear, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
@@ -622,10 +644,14 @@ int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const vo
     if (log2_large < 3 || log2_large > 28) { set_error("bbg_quotient_widget_device: need 3 <= log2 of the 4n domain <= 28"); return BBG_E_INVALID; }
     if (!d_polys || !challenges || !d_quotient || !widgets) { set_error("bbg_quotient_widget_device: null argument"); return BBG_E_INVALID; }
     QuotientArgs a;
-    for (int k = 0; k < QP_COUNT; k++) a.p[k] = (const Fr*)d_polys[k];
+    bool extended = false; // d_polys has BBG_QP_EXT_COUNT entries only when a widget that reads the extension is asked for
     for (int w = 0; w < count; w++) {
-        if (widgets[w] < 0 || widgets[w] > 6) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
-        for (int k = 0; k < QP_COUNT; k++)
+        if (widgets[w] < 0 || widgets[w] >= WIDGET_COUNT) { set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID; }
+        extended = extended || (WIDGET_NEEDS[widgets[w]] >> QP_COUNT) != 0;
+    }
+    for (int k = 0; k < QP_EXT_COUNT; k++) a.p[k] = (k < QP_COUNT || extended) ? (const Fr*)d_polys[k] : nullptr;
+    for (int w = 0; w < count; w++) {
+        for (int k = 0; k < QP_EXT_COUNT; k++)
             if (((WIDGET_NEEDS[widgets[w]] >> k) & 1u) && !a.p[k]) {
                 set_error("bbg_quotient_widget_device: a polynomial this widget reads is null");
                 return BBG_E_INVALID;

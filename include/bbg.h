@@ -188,7 +188,10 @@ enum bbg_quotient_poly { /* index into d_polys[]; entries a widget does not read
     BBG_QP_SIGMA_1, BBG_QP_SIGMA_2, BBG_QP_SIGMA_3, BBG_QP_SIGMA_4,
     BBG_QP_Q_1, BBG_QP_Q_2, BBG_QP_Q_3, BBG_QP_Q_4, BBG_QP_Q_5, BBG_QP_Q_M, BBG_QP_Q_C,
     BBG_QP_Q_ARITH, BBG_QP_Q_FIXED_BASE, BBG_QP_Q_RANGE, BBG_QP_Q_LOGIC, BBG_QP_LAGRANGE_1,
-    BBG_QP_COUNT
+    BBG_QP_COUNT,
+    /* extension read only by BBG_WIDGET_MIMC: d_polys then has BBG_QP_EXT_COUNT entries (the first BBG_QP_COUNT as above) */
+    BBG_QP_EXT_Q_MIMC_COEFFICIENT = BBG_QP_COUNT, BBG_QP_EXT_Q_MIMC_SELECTOR,
+    BBG_QP_EXT_COUNT
 };
 enum bbg_quotient_widget {
     BBG_WIDGET_PERMUTATION = 0,      /* ProverPermutationWidget<4,false> (permutation_widget_impl.hpp:316-420): ASSIGNS the quotient */
@@ -197,7 +200,8 @@ enum bbg_quotient_widget {
     BBG_WIDGET_TURBO_RANGE = 3,      /* TurboRangeKernel */
     BBG_WIDGET_TURBO_LOGIC = 4,      /* TurboLogicKernel */
     BBG_WIDGET_PERMUTATION_3 = 5,    /* StandardPLONK: ProverPermutationWidget<3,false> (w_4 / sigma_4 not read): ASSIGNS */
-    BBG_WIDGET_ARITHMETIC = 6        /* StandardPLONK: ArithmeticKernel (arithmetic_widget.hpp): accumulates */
+    BBG_WIDGET_ARITHMETIC = 6,       /* StandardPLONK: ArithmeticKernel (arithmetic_widget.hpp): accumulates */
+    BBG_WIDGET_MIMC = 7              /* MiMCComposer: MiMCKernel (mimc_widget.hpp:17-52) over w_1..w_3 and the two BBG_QP_EXT selectors: accumulates */
 };
 /* challenges: 9 Montgomery Fr (4 limbs each) on the host -- alpha_base (this widget's starting power of alpha), alpha,
  * beta, gamma, public_input_delta, g (the small domain's coset generator), k1, k2, k3 (fr::coset_generator(0..2)).
@@ -233,15 +237,23 @@ enum bbg_prover_poly { /* continues enum bbg_quotient_poly: the polynomials a pr
     BBG_PP_T_1, BBG_PP_T_2, BBG_PP_T_3, BBG_PP_T_4, /* t_low, t_mid, t_high, t_higher: slices of n coefficients of t(X) */
     BBG_PP_LINEAR,                  /* r(X), the linearisation polynomial                                               */
     BBG_PP_OPENING, BBG_PP_SHIFTED_OPENING, /* W_zeta(X), W_zeta_omega(X)                                               */
+    BBG_PP_Q_MIMC_COEFFICIENT, BBG_PP_Q_MIMC_SELECTOR, /* key polynomials of the MiMC flavour (set_key_poly / evaluate / linearise / round 6 ids) */
     BBG_PP_COUNT
+};
+enum bbg_prover_flavour { /* the widget list of round 4, in the prover's order */
+    BBG_FLAVOUR_TURBO = 0,    /* width 4: permutation<4>, turbo arithmetic, fixed base, range, logic (turbo_composer.cpp:735-752) */
+    BBG_FLAVOUR_STANDARD = 1, /* width 3: permutation<3>, arithmetic (standard_composer.cpp:562-582)                             */
+    BBG_FLAVOUR_MIMC = 2      /* width 3: permutation<3>, MiMC, arithmetic (MiMCComposer::preprocess, mimc_composer.cpp:277-302)  */
 };
 /* program_width: 4 = TurboPLONK (ProverPermutationWidget<4> + turbo arithmetic / fixed base / range / logic widgets,
  * turbo_composer.cpp:735-752), 3 = StandardPLONK (ProverPermutationWidget<3> + arithmetic widget, standard_composer.cpp:562-582).
  * generators: 4 Montgomery Fr -- the small domain's coset generator g and fr::coset_generator(0..2) = k1, k2, k3.
  * srs must hold n points (n + 1 for StandardPLONK).  The srs and the context must outlive the handle. */
 int bbg_prover_create(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int program_width, const uint64_t* generators, bbg_prover** out);
+/* The same with the flavour named (bbg_prover_create(4) = TURBO, (3) = STANDARD). */
+int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int flavour, const uint64_t* generators, bbg_prover** out);
 void bbg_prover_destroy(bbg_prover* p);
-/* Per proving key.  id: BBG_QP_SIGMA_1 .. BBG_QP_LAGRANGE_1.  form BBG_FORM_COEFF (n values; what proving_key::constraint_selectors /
+/* Per proving key.  id: BBG_QP_SIGMA_1 .. BBG_QP_LAGRANGE_1, BBG_PP_Q_MIMC_*.  form BBG_FORM_COEFF (n values; what proving_key::constraint_selectors /
  * permutation_selectors hold) is sufficient: bbg_prover_finalize_key derives sigma's Lagrange form, every 4n-coset form and L_1 on the
  * device.  A caller may instead hand over its own BBG_FORM_LAGRANGE (sigma) / BBG_FORM_COSET arrays.  The array is copied before
  * the call returns.  Re-registering a polynomial replaces it (call finalize again). */

@@ -1042,7 +1042,7 @@ static fe fr_quad(fe d) /* D (D-1)(D-2)(D-3) */
 int oracle_quotient_widget(int widget, const uint64_t* const* polys, unsigned log2_large, const uint64_t* challenges, uint64_t* quotient,
                            uint64_t* alpha_out)
 {
-    if (widget < 0 || widget > 6 || log2_large < 3) return -1;
+    if (widget < 0 || widget > 7 || log2_large < 3) return -1;
     const size_t m = (size_t)1 << log2_large, mask = m - 1;
     fe ch[9];
     for (int k = 0; k < 9; k++) { memcpy(ch[k].d, challenges + 4 * k, 32); ch[k] = fe_canon(&FR, ch[k]); }
@@ -1089,6 +1089,17 @@ int oracle_quotient_widget(int widget, const uint64_t* const* polys, unsigned lo
             memcpy(quotient + 4 * i, q.d, 32);
         }
         next = ap[1];
+    } else if (widget == 7) { /* MiMC round gate (mimc_widget.hpp:17-52): polys[21] = q_mimc_coefficient, polys[22] = q_mimc_selector */
+        for (size_t i = 0; i < m; i++) {
+            const fe w2 = fr_ld(W2, i);
+            const fe t0 = FA(FA(fr_ld(W1, i), fr_ld(W3, i)), fr_ld(polys[21], i));
+            const fe t1 = FS(FM(FM(t0, t0), t0), w2);                         /* (w1 + w3 + c)^3 - w2 */
+            const fe t2 = FS(FM(FM(w2, w2), t0), fr_ld(W3, (i + 4) & mask));  /* w2^2 (w1 + w3 + c) - w3(wX) */
+            const fe t3 = FA(FM(t1, ap[0]), FM(t2, ap[1]));
+            fe q = FA(fr_ld(quotient, i), FM(t3, fr_ld(polys[22], i)));
+            memcpy(quotient + 4 * i, q.d, 32);
+        }
+        next = ap[2]; /* two relations */
     } else {
         for (size_t i = 0; i < m; i++) {
             const size_t ish = (i + 4) & mask;

@@ -227,10 +227,11 @@ class Oracle:
         return dest, f
 
     def quotient_widget(self, widget, polys, log2_large, challenges, quotient):
-        """polys: list of 21 (m, 4) arrays in bbg_quotient_poly order; challenges (9, 4); quotient (m, 4) updated in place.
-        Returns the next alpha_base (canonical)."""
+        """polys: list of 21 (m, 4) arrays in bbg_quotient_poly order (23 for widget 7 = MiMC: + q_mimc_coefficient, q_mimc_selector);
+        challenges (9, 4); quotient (m, 4) updated in place.  Returns the next alpha_base (canonical)."""
         arrs = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
-        ptrs = (ctypes.c_void_p * 21)(*[a.ctypes.data for a in arrs])
+        assert len(arrs) >= (23 if widget == 7 else 21)
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         ch = np.ascontiguousarray(challenges, dtype=np.uint64)
         out = np.zeros(4, dtype=np.uint64)
         assert quotient.flags["C_CONTIGUOUS"] and quotient.dtype == np.uint64
@@ -507,7 +508,8 @@ class RefProver:
                                   ctypes.c_void_p)
 
     def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False, flavour=0):
-        """flavour 0 = TurboPLONK (TurboComposer / TurboProver), 1 = StandardPLONK (StandardComposer / Prover) over the same circuit."""
+        """flavour 0 = TurboPLONK (TurboComposer / TurboProver), 1 = StandardPLONK (StandardComposer / Prover) over the same circuit,
+        2 = MiMCComposer (MiMC rounds + the arithmetic chain; Prover with the MiMC widget)."""
         if not prover_available() or (gpu_linked and not os.path.exists(PROVER_GPU_SO)):
             raise RuntimeError("oracle/_ref/libbbprover[_gpu].so not available on this machine")
         L = self.lib = ctypes.CDLL(PROVER_GPU_SO if gpu_linked else PROVER_SO, mode=os.RTLD_NOW)
@@ -761,8 +763,9 @@ class RefWidgets:
     LABELS = ["w_1_fft", "w_2_fft", "w_3_fft", "w_4_fft", "z_fft", "sigma_1_fft", "sigma_2_fft", "sigma_3_fft", "sigma_4_fft",
               "q_1_fft", "q_2_fft", "q_3_fft", "q_4_fft", "q_5_fft", "q_m_fft", "q_c_fft", "q_arith_fft", "q_ecc_1_fft",
               "q_range_fft", "q_logic_fft", "lagrange_1"]
+    MIMC_LABELS = LABELS + ["q_mimc_coefficient_fft", "q_mimc_selector_fft"]  # include/bbg.h's extended table (BBG_QP_EXT_*)
 
-    def __init__(self, prover, standard=None):
+    def __init__(self, prover, standard=None, flavour=None):
         """prover: a RefProver (TurboPLONK widgets 0..4).  standard=(num_gates, points, x_mont): instead build a StandardPLONK key
         through the same library; its widgets are 0 = permutation over three wires, 1 = arithmetic."""
         self.prover = prover  # keeps the session (proving key) alive
@@ -776,7 +779,10 @@ class RefWidgets:
         L.refw_run_widget.argtypes = [vp, cint, vp, vp]; L.refw_run_widget.restype = cint
         L.refw_new_standard.argtypes = [sz, vp, sz, vp]; L.refw_new_standard.restype = vp
         L.refw_circuit_size.argtypes = [vp]; L.refw_circuit_size.restype = sz
-        if standard is None:
+        L.refw_new_flavour.argtypes = [vp, cint]; L.refw_new_flavour.restype = vp
+        if flavour is not None:  # the widget objects of `prover`'s own session (RefProver(flavour=...)): 2 = permutation<3>, MiMC, arithmetic
+            self.h = L.refw_new_flavour(prover.h, flavour)
+        elif standard is None:
             self.h = L.refw_new(prover.h)
         else:
             gates, pts, x = standard

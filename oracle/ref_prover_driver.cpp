@@ -28,6 +28,7 @@
 #include <ecc/curves/bn254/pairing.hpp>
 #include <ecc/curves/bn254/scalar_multiplication/pippenger.hpp>
 #include <ecc/curves/bn254/scalar_multiplication/scalar_multiplication.hpp>
+#include <plonk/composer/mimc_composer.hpp>
 #include <plonk/composer/standard_composer.hpp>
 #include <plonk/composer/turbo_composer.hpp>
 #include <plonk/proof_system/prover/prover.hpp>
@@ -167,6 +168,36 @@ template <typename Composer> void build_circuit(Composer& c, size_t num_gates, u
         xi = si;
     }
 }
+// MiMCComposer: rounds of the MiMC permutation x <- (x + k + c_i)^7 as in the reference's own test (mimc_composer.test.cpp:7-41), one
+// create_mimc_gate per round, followed by the arithmetic chain above so that the arithmetic widget has work too.
+void build_mimc_circuit(waffle::MiMCComposer& c, size_t num_gates, uint64_t seed)
+{
+    auto next = [&seed]() {
+        seed += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    };
+    auto next_fr = [&]() { return fr{ next(), next(), next(), next() & 0x0fffffffffffffffULL }.to_montgomery_form(); };
+    const size_t rounds = num_gates / 2;
+    fr x = next_fr();
+    const fr k = next_fr();
+    uint32_t x_in = c.add_public_variable(x);
+    const uint32_t k_idx = c.add_variable(k);
+    for (size_t i = 0; i < rounds; i++) {
+        const fr ci = next_fr();
+        const fr t0 = (x + k) + ci;
+        const fr cubed = t0.sqr() * t0;
+        const uint32_t cubed_idx = c.add_variable(cubed);
+        const fr out = cubed.sqr() * t0;
+        const uint32_t out_idx = c.add_variable(out);
+        c.create_mimc_gate({ x_in, cubed_idx, k_idx, out_idx, ci });
+        x_in = out_idx;
+        x = out;
+    }
+    build_circuit(c, num_gates - rounds, seed);
+}
 
 
 #ifdef BBG_DRIVER_WITH_SHIM
@@ -269,6 +300,7 @@ template <typename Composer, typename Prover, typename Verifier> struct SessionT
 };
 using TurboSession = SessionT<waffle::TurboComposer, waffle::TurboProver, waffle::TurboVerifier>;
 using StandardSession = SessionT<waffle::StandardComposer, waffle::Prover, waffle::Verifier>;
+using MiMCSession = SessionT<waffle::MiMCComposer, waffle::Prover, waffle::MiMCVerifier>;
 
 } // namespace
 
@@ -276,17 +308,26 @@ extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num
 
 // points: num_points affine Montgomery points [x^i]G (64 B each); x_mont: the secret as a Montgomery Fr (4 limbs).
 // flavour 0 = TurboPLONK (TurboComposer::create_prover, turbo_composer.cpp:727), 1 = StandardPLONK (StandardComposer::create_prover,
-// standard_composer.cpp:562): the same arithmetic circuit through the other composer.
+// standard_composer.cpp:562): the same arithmetic circuit through the other composer; 2 = MiMCComposer::preprocess
+// (mimc_composer.cpp:277): MiMC rounds + the arithmetic chain.
 template <typename S, typename Composer> static Session* new_session(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const fr& x)
 {
     auto s = std::make_unique<S>();
-    if constexpr (std::is_same<Composer, waffle::TurboComposer>::value)
-        s->composer = std::make_unique<Composer>(std::shared_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
-    else
-        s->composer = std::make_unique<Composer>(std::unique_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
-    build_circuit(*s->composer, num_gates, circuit_seed);
     using ProverT = typename std::remove_reference<decltype(*s->prover)>::type;
-    s->prover = std::make_unique<ProverT>(s->composer->create_prover());
+    if constexpr (std::is_same<Composer, waffle::MiMCComposer>::value) {
+        // MiMCComposer has no constructor taking a factory (mimc_composer.hpp:40-48); the member it would set is public (composer_base.hpp:348)
+        s->composer = std::make_unique<Composer>(num_gates);
+        s->composer->crs_factory_ = std::shared_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x));
+        build_mimc_circuit(*s->composer, num_gates, circuit_seed);
+        s->prover = std::make_unique<ProverT>(s->composer->preprocess());
+    } else {
+        if constexpr (std::is_same<Composer, waffle::TurboComposer>::value)
+            s->composer = std::make_unique<Composer>(std::shared_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
+        else
+            s->composer = std::make_unique<Composer>(std::unique_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
+        build_circuit(*s->composer, num_gates, circuit_seed);
+        s->prover = std::make_unique<ProverT>(s->composer->create_prover());
+    }
     if (bbg_shim_register_point_table) // the Pippenger-constructor hook of INTEGRATION.md: upload the SRS once, up front
         bbg_shim_register_point_table(s->prover->key->reference_string->get_monomials(), s->prover->get_circuit_size() + 1);
     return s.release();
@@ -312,6 +353,7 @@ void* refp_new_flavour(int flavour, size_t num_gates, uint64_t circuit_seed, con
         fr x{ x_mont[0], x_mont[1], x_mont[2], x_mont[3] };
         if (flavour == 0) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 1) return new_session<StandardSession, waffle::StandardComposer>(num_gates, circuit_seed, points, num_points, x);
+        if (flavour == 2) return new_session<MiMCSession, waffle::MiMCComposer>(num_gates, circuit_seed, points, num_points, x);
         return nullptr;
     } catch (...) {
         return nullptr;
@@ -611,6 +653,19 @@ struct WidgetHarness {
         , transcript(dummy_transcript(waffle::TurboComposer::create_manifest(0), waffle::turbo_settings::hash_type,
                                       waffle::turbo_settings::num_challenge_bytes, 4, true))
     {}
+    // flavour 2: the session of a MiMCComposer prover -- random_widgets[0] = ProverPermutationWidget<3, false>, transition_widgets =
+    // { ProverMiMCWidget, ProverArithmeticWidget } (mimc_composer.cpp:285-294)
+    WidgetHarness(Session* s, int flavour)
+        : key(s->view().key.get())
+        , random_widgets(&s->view().random_widgets)
+        , transition_widgets(&s->view().transition_widgets)
+        , transcript(flavour == 2   ? dummy_transcript(waffle::MiMCComposer::create_manifest(0), waffle::standard_settings::hash_type,
+                                                       waffle::standard_settings::num_challenge_bytes, 3, true)
+                     : flavour == 1 ? dummy_transcript(waffle::StandardComposer::create_manifest(0), waffle::standard_settings::hash_type,
+                                                       waffle::standard_settings::num_challenge_bytes, 3, true)
+                                    : dummy_transcript(waffle::TurboComposer::create_manifest(0), waffle::turbo_settings::hash_type,
+                                                       waffle::turbo_settings::num_challenge_bytes, 4, true))
+    {}
     WidgetHarness(std::unique_ptr<StdSession> s)
         : key(s->prover->key.get())
         , random_widgets(&s->prover->random_widgets)
@@ -640,6 +695,16 @@ void* refw_new(void* session)
 {
     try {
         return new WidgetHarness((Session*)session);
+    } catch (...) {
+        return nullptr;
+    }
+}
+// the widgets of a session created with refp_new_flavour(flavour, ...)
+void* refw_new_flavour(void* session, int flavour)
+{
+    try {
+        if (flavour < 0 || flavour > 2) return nullptr;
+        return new WidgetHarness((Session*)session, flavour);
     } catch (...) {
         return nullptr;
     }

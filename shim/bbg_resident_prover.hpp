@@ -37,6 +37,13 @@
 #include <plonk/proof_system/prover/prover.hpp>
 #include <plonk/proof_system/public_inputs/public_inputs.hpp>
 #include <plonk/proof_system/types/program_settings.hpp>
+#include <plonk/proof_system/widgets/random_widgets/permutation_widget.hpp>
+#include <plonk/proof_system/widgets/transition_widgets/arithmetic_widget.hpp>
+#include <plonk/proof_system/widgets/transition_widgets/mimc_widget.hpp>
+#include <plonk/proof_system/widgets/transition_widgets/turbo_arithmetic_widget.hpp>
+#include <plonk/proof_system/widgets/transition_widgets/turbo_fixed_base_widget.hpp>
+#include <plonk/proof_system/widgets/transition_widgets/turbo_logic_widget.hpp>
+#include <plonk/proof_system/widgets/transition_widgets/turbo_range_widget.hpp>
 #include <polynomials/polynomial_arithmetic.hpp>
 
 #include "../include/bbg.h"
@@ -105,6 +112,8 @@ inline int device_poly_id(waffle::PolynomialIndex index)
     case PolynomialIndex::Q_FIXED_BASE_SELECTOR: return BBG_QP_Q_FIXED_BASE;
     case PolynomialIndex::Q_RANGE_SELECTOR: return BBG_QP_Q_RANGE;
     case PolynomialIndex::Q_LOGIC_SELECTOR: return BBG_QP_Q_LOGIC;
+    case PolynomialIndex::Q_MIMC_COEFFICIENT: return BBG_PP_Q_MIMC_COEFFICIENT;
+    case PolynomialIndex::Q_MIMC_SELECTOR: return BBG_PP_Q_MIMC_SELECTOR;
     default: return -1;
     }
 }
@@ -121,9 +130,12 @@ class ResidentKey {
         const size_t n = key_->n;
         bbg_srs* srs = bbg_shim_srs_for(key_->reference_string->get_monomials(), n + (program_width == 3 ? 1 : 0));
         const fr gens[4] = { key_->small_domain.generator, fr::coset_generator(0), fr::coset_generator(1), fr::coset_generator(2) };
-        if (bbg_prover_create(bbg_shim_context(), srs, (unsigned)key_->small_domain.log2_size, (int)program_width,
-                              reinterpret_cast<const uint64_t*>(gens), &handle_) != BBG_OK)
-            resident_fail("bbg_prover_create");
+        // the widget list of round 4: a width-3 key with the MiMC selectors belongs to MiMCComposer (mimc_composer.hpp:10-26)
+        const int flavour = program_width == 4 ? BBG_FLAVOUR_TURBO
+                            : key_->constraint_selectors.count("q_mimc_selector") ? BBG_FLAVOUR_MIMC : BBG_FLAVOUR_STANDARD;
+        if (bbg_prover_create_flavour(bbg_shim_context(), srs, (unsigned)key_->small_domain.log2_size, flavour,
+                                      reinterpret_cast<const uint64_t*>(gens), &handle_) != BBG_OK)
+            resident_fail("bbg_prover_create_flavour");
         for (const auto& info : key_->polynomial_manifest) {
             if (info.source == waffle::PolynomialSource::WITNESS) continue;
             const int id = device_poly_id(info.index);
@@ -242,8 +254,9 @@ template <size_t program_width, typename Prover> fr permutation_linear_scalars(P
 
 } // namespace detail
 
-// Is this prover one of the two flavours the device rounds implement (widget lists of TurboComposer::create_prover,
-// turbo_composer.cpp:735-752, and StandardComposer::create_prover, standard_composer.cpp:562-582)?
+// Is this prover one of the three flavours the device rounds implement (widget lists of TurboComposer::create_prover,
+// turbo_composer.cpp:735-752, StandardComposer::create_prover, standard_composer.cpp:562-582, and MiMCComposer::preprocess,
+// mimc_composer.cpp:277-302) -- i.e. every prover the reference's composers build?
 template <typename settings> bool resident_supported(waffle::ProverBase<settings>& p)
 {
     using namespace waffle;
@@ -256,8 +269,11 @@ template <typename settings> bool resident_supported(waffle::ProverBase<settings
                dynamic_cast<ProverTurboRangeWidget<settings>*>(p.transition_widgets[2].get()) &&
                dynamic_cast<ProverTurboLogicWidget<settings>*>(p.transition_widgets[3].get());
     } else if constexpr (W == 3) {
-        if (!dynamic_cast<ProverPermutationWidget<3, false>*>(p.random_widgets[0].get()) || p.transition_widgets.size() != 1) return false;
-        return dynamic_cast<ProverArithmeticWidget<settings>*>(p.transition_widgets[0].get()) != nullptr;
+        if (!dynamic_cast<ProverPermutationWidget<3, false>*>(p.random_widgets[0].get())) return false;
+        if (p.transition_widgets.size() == 1) return dynamic_cast<ProverArithmeticWidget<settings>*>(p.transition_widgets[0].get()) != nullptr;
+        return p.transition_widgets.size() == 2 && dynamic_cast<ProverMiMCWidget<settings>*>(p.transition_widgets[0].get()) &&
+               dynamic_cast<ProverArithmeticWidget<settings>*>(p.transition_widgets[1].get()) &&
+               p.key->constraint_selectors.count("q_mimc_selector");
     }
     return false;
 }
@@ -270,7 +286,7 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
     constexpr size_t W = settings::program_width;
     constexpr size_t CUT = settings::num_roots_cut_out_of_vanishing_polynomial;
     if (p.key.get() != rk.key().get() || rk.program_width() != W) throw std::runtime_error("bbg_shim::construct_proof: prover and ResidentKey belong to different proving keys");
-    if (!resident_supported(p)) throw std::runtime_error("bbg_shim::construct_proof: unsupported widget set (TurboPLONK / StandardPLONK only)");
+    if (!resident_supported(p)) throw std::runtime_error("bbg_shim::construct_proof: unsupported widget set (TurboPLONK / StandardPLONK / MiMC composer provers only)");
     bbg_prover* dev = rk.handle();
     auto& transcript = p.transcript;
     auto* key = p.key.get();
@@ -354,7 +370,8 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
                      detail::linear_scalars_of<ProverTurboRangeWidget<settings>>(w, p, alpha_base, scalars) ||
                      detail::linear_scalars_of<ProverTurboLogicWidget<settings>>(w, p, alpha_base, scalars);
             else
-                ok = detail::linear_scalars_of<ProverArithmeticWidget<settings>>(w, p, alpha_base, scalars);
+                ok = detail::linear_scalars_of<ProverArithmeticWidget<settings>>(w, p, alpha_base, scalars) ||
+                     detail::linear_scalars_of<ProverMiMCWidget<settings>>(w, p, alpha_base, scalars);
             if (!ok) throw std::runtime_error("bbg_shim::construct_proof: unknown transition widget");
         }
         std::vector<int> lin_ids;

@@ -500,7 +500,9 @@ def test_round_kernel_error_paths(pkg, bbg):
     ch9 = pkg.synthetic_scalars(1, 9)
     ptrs = [buf.data_ptr()] * 21
     with pytest.raises(pkg.BbgError):
-        bbg.quotient_widget_device(7, ptrs, 6, ch9, buf.data_ptr())      # unknown widget
+        bbg.quotient_widget_device(8, ptrs, 6, ch9, buf.data_ptr())      # unknown widget
+    with pytest.raises(pkg.BbgError):
+        bbg.quotient_widget_device(7, ptrs, 6, ch9, buf.data_ptr())      # MiMC without its two selectors (extended table empty)
     with pytest.raises(pkg.BbgError):
         bbg.quotient_widget_device(0, ptrs, 2, ch9, buf.data_ptr())      # domain too small for the shifted rows
     missing = list(ptrs)
@@ -604,14 +606,14 @@ def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0, widgets=(0, 1, 2,
 
 @pytest.mark.parametrize("log2_large", [3, 5, 8, 13])
 def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large):
-    """All five widgets against the oracle's restatement (itself pinned by the reference goldens) on arbitrary challenge values
-    -- public_input_delta, g, k1..k3 are NOT the transcript / field constants here -- and on the smallest legal domain."""
+    """All eight widgets against the oracle's restatement (itself pinned by the reference goldens / live reference proofs) on arbitrary
+    challenge values -- public_input_delta, g, k1..k3 are NOT the transcript / field constants here -- and on the smallest legal domain."""
     m = 1 << log2_large
-    polys = [pkg.synthetic_scalars(5000 + 31 * log2_large + k, m) for k in range(21)]
+    polys = [pkg.synthetic_scalars(5000 + 31 * log2_large + k, m) for k in range(23)]
     ch9 = pkg.synthetic_scalars(6000 + log2_large, 9)
     quot = np.zeros((m, 4), dtype=np.uint64)
     alpha_base = ch9[0].copy()
-    order = (0, 1, 2, 3, 4, 5, 6)  # the StandardPLONK pair (5 assigns again, 6 accumulates) after the TurboPLONK five
+    order = (0, 1, 2, 3, 4, 5, 7, 6)  # after the TurboPLONK five: MiMCComposer's list (5 assigns again; MiMC and arithmetic accumulate)
     for widget, (alpha_out, q) in zip(order, _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, ch9[0], order)):
         ch = ch9.copy()
         ch[0] = alpha_base
@@ -1003,13 +1005,13 @@ def _powers_srs(oracle, count):
     return x, oracle.srs_powers(x, count)
 
 
-@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (0, 13), (1, 13)])
+@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (2, 9), (0, 13), (1, 13), (2, 13)])
 def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavour, log2_gates):
     """shim/bbg_resident_prover.hpp + bbg_prover_* (every O(n) step of the proof on the device, C++ host, no Python in the
     product path) against the reference CPU prover on the SAME randomness: the reference's construct_proof runs round by round
     on the host and the blinding scalars it draws are recorded; the resident prover replays them over a second session of the
-    same circuit.  Transcript, commitments, evaluations -- the proof bytes -- must be IDENTICAL, for TurboPLONK and
-    StandardPLONK, and the reference verifier must accept.  The device-derived forms of the proving key's polynomials (sigma
+    same circuit.  Transcript, commitments, evaluations -- the proof bytes -- must be IDENTICAL, for the provers of all three
+    composers of the reference (TurboComposer, StandardComposer, MiMCComposer), and the reference verifier must accept.  The device-derived forms of the proving key's polynomials (sigma
     in Lagrange base, 4n-coset forms, L_1) must equal the arrays the reference's compute_proving_key produced."""
     from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
     if not prover_available() or not os.path.exists(PROVER_GPU_SO):
@@ -1035,7 +1037,7 @@ def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavou
         P.free()
 
 
-@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("flavour", [0, 1, 2])
 def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     """INTEGRATION.md 2a for both composers: TurboComposer::create_prover (turbo_composer.cpp:727) and
     StandardComposer::create_prover (standard_composer.cpp:562) produce provers whose construct_proof(), UNMODIFIED and called
@@ -1046,7 +1048,7 @@ def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     x, pts = _powers_srs(oracle, (2 << 12) + 2)
     P = RefProver(1 << 12, 31, pts, x, gpu_linked=True, flavour=flavour)
     proof = P.prove_reference()
-    assert len(proof) == (1216 if flavour == 0 else 832) and P.verify() == 1
+    assert len(proof) == (1216, 832, 896)[flavour] and P.verify() == 1
     P.free()
 
 
@@ -1105,6 +1107,8 @@ def test_prover_handle_error_paths(pkg, bbg):
     assert lib.bbg_prover_create(bbg.ctx, srs.handle, 6, 5, gens.ctypes.data, ctypes.byref(h)) != 0        # width
     assert lib.bbg_prover_create(bbg.ctx, srs.handle, 7, 4, gens.ctypes.data, ctypes.byref(h)) != 0        # SRS too short
     assert lib.bbg_prover_create(bbg.ctx, srs.handle, 6, 3, gens.ctypes.data, ctypes.byref(h)) != 0        # StandardPLONK needs n + 1 points
+    assert lib.bbg_prover_create_flavour(bbg.ctx, srs.handle, 6, 3, gens.ctypes.data, ctypes.byref(h)) != 0 # unknown flavour
+    assert lib.bbg_prover_create_flavour(bbg.ctx, srs.handle, 6, 2, gens.ctypes.data, ctypes.byref(h)) != 0 # MiMC (width 3) needs n + 1 points
     assert lib.bbg_prover_create(bbg.ctx, srs.handle, 6, 4, gens.ctypes.data, ctypes.byref(h)) == 0
     a = pkg.synthetic_scalars(9, 64)
     out = np.zeros((4, 12), dtype=np.uint64)

@@ -320,7 +320,7 @@ def test_quotient_widgets_oracle_vs_reference_golden(oracle):
 
 def test_quotient_widgets_and_grand_product_oracle_vs_reference_live(oracle):
     """Where the reference build is present: the oracle's widget restatement against the reference's widget OBJECTS on fresh
-    seeds (TurboPLONK five + StandardPLONK pair), and oracle_permutation_z against the z of a real proof's round 3."""
+    seeds (TurboPLONK five + StandardPLONK pair + MiMCComposer's three), and oracle_permutation_z against the z of a real proof's round 3."""
     import ctypes
     from oracle.oracle import RefProver, RefWidgets, prover_available
     import __graft_entry__ as ge
@@ -350,6 +350,27 @@ def test_quotient_widgets_and_grand_product_oracle_vs_reference_live(oracle):
             assert np.array_equal(alpha_or, oracle.canon(0, alpha_ref.reshape(1, 4))[0]), lib_widget
             assert np.array_equal(oracle.canon(0, quot), oracle.canon(0, W.get_poly("quotient_large", m))), lib_widget
         W.free()
+    # MiMCComposer's prover (mimc_composer.cpp:277-302): permutation over three wires, the MiMC widget, the arithmetic widget
+    M = RefProver(n - 24, 22, pts, x, flavour=2)
+    W = RefWidgets(M, flavour=2)
+    m = W.m
+    polys = [pkg.synthetic_scalars(41337 + 7 * k, m) for k in range(len(RefWidgets.MIMC_LABELS))]
+    for label, a in zip(RefWidgets.MIMC_LABELS, polys):
+        if W.has_poly(label):
+            W.set_poly(label, a)
+    ch = W.challenges()
+    ch9 = np.stack([ch[0], ch[0], ch[1], ch[2], ch[3], ch[7], ch[4], ch[5], ch[6]])
+    quot = np.zeros((m, 4), dtype=np.uint64)
+    alpha_ref = alpha_or = ch[0]
+    for ref_widget, lib_widget in ((0, 5), (1, 7), (2, 6)):
+        alpha_ref = W.run(ref_widget, alpha_ref)
+        c = ch9.copy()
+        c[0] = alpha_or
+        alpha_or = oracle.quotient_widget(lib_widget, polys, m.bit_length() - 1, c, quot)
+        assert np.array_equal(alpha_or, oracle.canon(0, alpha_ref.reshape(1, 4))[0]), lib_widget
+        assert np.array_equal(oracle.canon(0, quot), oracle.canon(0, W.get_poly("quotient_large", m))), lib_widget
+    W.free()
+    M.free()
     # round 3 of a real proof: rows 0 .. n-4 of the reference's z
     for k in range(3):
         P.lib.refp_execute_round(P.h, k)
