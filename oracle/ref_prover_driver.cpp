@@ -215,6 +215,9 @@ struct Replay { // blinding scalars recorded from a reference proof, handed out 
 };
 #endif
 
+template <typename S> constexpr size_t width_of_settings(const waffle::ProverBase<S>*) { return S::program_width; }
+template <typename S> constexpr bool linearised_settings(const waffle::ProverBase<S>*) { return S::use_linearisation; }
+
 template <typename Composer, typename Prover, typename Verifier> struct SessionT : Session {
     std::unique_ptr<Composer> composer;
     std::unique_ptr<Prover> prover;
@@ -241,12 +244,26 @@ template <typename Composer, typename Prover, typename Verifier> struct SessionT
     std::vector<uint8_t> export_proof() override { return prover->export_proof().proof_data; }
     int verify(const std::vector<uint8_t>& proof_data) override
     {
-        Verifier verifier = composer->create_verifier();
+        Verifier verifier = make_verifier();
         waffle::plonk_proof pr{ proof_data };
         return verifier.verify_proof(pr) ? 1 : 0;
     }
     size_t program_width() const override { return width_of(); }
-    static constexpr size_t width_of() { return std::is_same<Prover, waffle::TurboProver>::value ? 4 : 3; }
+    static constexpr size_t width_of() { return width_of_settings((const Prover*)nullptr); }
+    static constexpr bool unrolled() { return !linearised_settings((const Prover*)nullptr); }
+    // the "unrolled" provers / verifiers (create_unrolled_prover, turbo_composer.cpp:762, standard_composer.cpp:540: every polynomial
+    // opened, no linearisation polynomial, Pedersen-Blake2s transcript) are what the rollup circuits use (rollup/proofs/*)
+    Verifier make_verifier()
+    {
+        if constexpr (unrolled()) return composer->create_unrolled_verifier();
+        else return composer->create_verifier();
+    }
+    Prover make_prover()
+    {
+        if constexpr (std::is_same<Composer, waffle::MiMCComposer>::value) return composer->preprocess();
+        else if constexpr (unrolled()) return composer->create_unrolled_prover();
+        else return composer->create_prover();
+    }
 #ifdef BBG_DRIVER_WITH_SHIM
     std::unique_ptr<bbg_shim::ResidentKey> resident_key;
     double resident_key_create() override
@@ -301,6 +318,8 @@ template <typename Composer, typename Prover, typename Verifier> struct SessionT
 using TurboSession = SessionT<waffle::TurboComposer, waffle::TurboProver, waffle::TurboVerifier>;
 using StandardSession = SessionT<waffle::StandardComposer, waffle::Prover, waffle::Verifier>;
 using MiMCSession = SessionT<waffle::MiMCComposer, waffle::Prover, waffle::MiMCVerifier>;
+using UnrolledTurboSession = SessionT<waffle::TurboComposer, waffle::UnrolledTurboProver, waffle::UnrolledTurboVerifier>;
+using UnrolledStandardSession = SessionT<waffle::StandardComposer, waffle::UnrolledProver, waffle::UnrolledVerifier>;
 
 } // namespace
 
@@ -309,7 +328,8 @@ extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num
 // points: num_points affine Montgomery points [x^i]G (64 B each); x_mont: the secret as a Montgomery Fr (4 limbs).
 // flavour 0 = TurboPLONK (TurboComposer::create_prover, turbo_composer.cpp:727), 1 = StandardPLONK (StandardComposer::create_prover,
 // standard_composer.cpp:562): the same arithmetic circuit through the other composer; 2 = MiMCComposer::preprocess
-// (mimc_composer.cpp:277): MiMC rounds + the arithmetic chain.
+// (mimc_composer.cpp:277): MiMC rounds + the arithmetic chain; 3 / 4 = the unrolled provers of the Turbo / Standard composer
+// (create_unrolled_prover).
 template <typename S, typename Composer> static Session* new_session(size_t num_gates, uint64_t circuit_seed, const uint64_t* points, size_t num_points, const fr& x)
 {
     auto s = std::make_unique<S>();
@@ -319,14 +339,14 @@ template <typename S, typename Composer> static Session* new_session(size_t num_
         s->composer = std::make_unique<Composer>(num_gates);
         s->composer->crs_factory_ = std::shared_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x));
         build_mimc_circuit(*s->composer, num_gates, circuit_seed);
-        s->prover = std::make_unique<ProverT>(s->composer->preprocess());
+        s->prover = std::make_unique<ProverT>(s->make_prover());
     } else {
         if constexpr (std::is_same<Composer, waffle::TurboComposer>::value)
             s->composer = std::make_unique<Composer>(std::shared_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
         else
             s->composer = std::make_unique<Composer>(std::unique_ptr<waffle::ReferenceStringFactory>(new DriverCrsFactory(points, num_points, x)), num_gates);
         build_circuit(*s->composer, num_gates, circuit_seed);
-        s->prover = std::make_unique<ProverT>(s->composer->create_prover());
+        s->prover = std::make_unique<ProverT>(s->make_prover());
     }
     if (bbg_shim_register_point_table) // the Pippenger-constructor hook of INTEGRATION.md: upload the SRS once, up front
         bbg_shim_register_point_table(s->prover->key->reference_string->get_monomials(), s->prover->get_circuit_size() + 1);
@@ -354,6 +374,8 @@ void* refp_new_flavour(int flavour, size_t num_gates, uint64_t circuit_seed, con
         if (flavour == 0) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 1) return new_session<StandardSession, waffle::StandardComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 2) return new_session<MiMCSession, waffle::MiMCComposer>(num_gates, circuit_seed, points, num_points, x);
+        if (flavour == 3) return new_session<UnrolledTurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
+        if (flavour == 4) return new_session<UnrolledStandardSession, waffle::StandardComposer>(num_gates, circuit_seed, points, num_points, x);
         return nullptr;
     } catch (...) {
         return nullptr;

@@ -261,7 +261,7 @@ template <typename settings> bool resident_supported(waffle::ProverBase<settings
 {
     using namespace waffle;
     constexpr size_t W = settings::program_width;
-    if (!settings::use_linearisation || settings::uses_quotient_mid || p.random_widgets.size() != 1) return false;
+    if (settings::uses_quotient_mid || p.random_widgets.size() != 1) return false; // linearised and "unrolled" (all polynomials opened) alike
     if constexpr (W == 4) {
         if (!dynamic_cast<ProverPermutationWidget<4, false>*>(p.random_widgets[0].get()) || p.transition_widgets.size() != 4) return false;
         return dynamic_cast<ProverTurboArithmeticWidget<settings>*>(p.transition_widgets[0].get()) &&
@@ -348,7 +348,8 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
         std::vector<std::string> labels;
         for (const auto& info : key->polynomial_manifest) {
             const std::string label(info.polynomial_label);
-            if (!info.is_linearised) { ids.push_back(device_poly_id(info.index)); shifted.push_back(0); labels.push_back(label); }
+            // the unrolled provers (use_linearisation = false: what the rollup circuits use, rollup/proofs/*) evaluate EVERY polynomial
+            if (!info.is_linearised || !settings::use_linearisation) { ids.push_back(device_poly_id(info.index)); shifted.push_back(0); labels.push_back(label); }
             if (info.requires_shifted_evaluation) { ids.push_back(device_poly_id(info.index)); shifted.push_back(1); labels.push_back(label + "_omega"); }
         }
         ids.push_back(BBG_PP_QUOTIENT); // t_eval = quotient_large.evaluate(zeta, 4n) (prover.cpp:397)
@@ -358,30 +359,32 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
             resident_fail("bbg_prover_evaluate");
         for (size_t k = 0; k < labels.size(); ++k) transcript.add_element(labels[k], evals[k].to_buffer());
         const fr t_eval = evals.back();
-        // r(X): the permutation widget assigns, the transition widgets accumulate (:399-405)
-        std::map<int, fr> scalars;
-        fr alpha_base = detail::permutation_linear_scalars<W>(p, alpha, scalars);
-        for (auto& widget : p.transition_widgets) {
-            auto* w = widget.get();
-            bool ok;
-            if constexpr (W == 4)
-                ok = detail::linear_scalars_of<ProverTurboArithmeticWidget<settings>>(w, p, alpha_base, scalars) ||
-                     detail::linear_scalars_of<ProverTurboFixedBaseWidget<settings>>(w, p, alpha_base, scalars) ||
-                     detail::linear_scalars_of<ProverTurboRangeWidget<settings>>(w, p, alpha_base, scalars) ||
-                     detail::linear_scalars_of<ProverTurboLogicWidget<settings>>(w, p, alpha_base, scalars);
-            else
-                ok = detail::linear_scalars_of<ProverArithmeticWidget<settings>>(w, p, alpha_base, scalars) ||
-                     detail::linear_scalars_of<ProverMiMCWidget<settings>>(w, p, alpha_base, scalars);
-            if (!ok) throw std::runtime_error("bbg_shim::construct_proof: unknown transition widget");
+        if constexpr (settings::use_linearisation) {
+            // r(X): the permutation widget assigns, the transition widgets accumulate (:399-405)
+            std::map<int, fr> scalars;
+            fr alpha_base = detail::permutation_linear_scalars<W>(p, alpha, scalars);
+            for (auto& widget : p.transition_widgets) {
+                auto* w = widget.get();
+                bool ok;
+                if constexpr (W == 4)
+                    ok = detail::linear_scalars_of<ProverTurboArithmeticWidget<settings>>(w, p, alpha_base, scalars) ||
+                         detail::linear_scalars_of<ProverTurboFixedBaseWidget<settings>>(w, p, alpha_base, scalars) ||
+                         detail::linear_scalars_of<ProverTurboRangeWidget<settings>>(w, p, alpha_base, scalars) ||
+                         detail::linear_scalars_of<ProverTurboLogicWidget<settings>>(w, p, alpha_base, scalars);
+                else
+                    ok = detail::linear_scalars_of<ProverArithmeticWidget<settings>>(w, p, alpha_base, scalars) ||
+                         detail::linear_scalars_of<ProverMiMCWidget<settings>>(w, p, alpha_base, scalars);
+                if (!ok) throw std::runtime_error("bbg_shim::construct_proof: unknown transition widget");
+            }
+            std::vector<int> lin_ids;
+            std::vector<fr> lin_scalars;
+            for (const auto& kv : scalars) { lin_ids.push_back(kv.first); lin_scalars.push_back(kv.second); }
+            fr r_eval;
+            if (bbg_prover_linearise(dev, lin_ids.size(), lin_ids.data(), reinterpret_cast<const uint64_t*>(lin_scalars.data()), detail::limbs(zeta),
+                                     reinterpret_cast<uint64_t*>(&r_eval)) != BBG_OK)
+                resident_fail("bbg_prover_linearise");
+            transcript.add_element("r", r_eval.to_buffer());
         }
-        std::vector<int> lin_ids;
-        std::vector<fr> lin_scalars;
-        for (const auto& kv : scalars) { lin_ids.push_back(kv.first); lin_scalars.push_back(kv.second); }
-        fr r_eval;
-        if (bbg_prover_linearise(dev, lin_ids.size(), lin_ids.data(), reinterpret_cast<const uint64_t*>(lin_scalars.data()), detail::limbs(zeta),
-                                 reinterpret_cast<uint64_t*>(&r_eval)) != BBG_OK)
-            resident_fail("bbg_prover_linearise");
-        transcript.add_element("r", r_eval.to_buffer());
         transcript.add_element("t", t_eval.to_buffer());
     }
     // ---- round 6 (:412-418, KateCommitmentScheme::batch_open kate_commitment_scheme.cpp:133-236)
@@ -391,7 +394,10 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
         std::vector<fr> nu_zeta, nu_omega;
         for (const auto& info : key->polynomial_manifest) {
             const std::string label(info.polynomial_label);
-            if (!info.is_linearised) { at_zeta.push_back(device_poly_id(info.index)); nu_zeta.push_back(transcript.get_challenge_field_element_from_map("nu", label)); }
+            if (!info.is_linearised || !settings::use_linearisation) {
+                at_zeta.push_back(device_poly_id(info.index));
+                nu_zeta.push_back(transcript.get_challenge_field_element_from_map("nu", label));
+            }
             if (info.requires_shifted_evaluation) {
                 at_omega.push_back(device_poly_id(info.index));
                 nu_omega.push_back(transcript.get_challenge_field_element_from_map("nu", label + "_omega"));
@@ -404,8 +410,10 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
             nu_zeta.push_back(scalar);
             if (i == W - 1) top_scalar = scalar;
         }
-        at_zeta.push_back(BBG_PP_LINEAR);
-        nu_zeta.push_back(transcript.get_challenge_field_element_from_map("nu", "r"));
+        if constexpr (settings::use_linearisation) { // [r(X), nu_r] only where the proof system has a linearisation polynomial (:211-215)
+            at_zeta.push_back(BBG_PP_LINEAR);
+            nu_zeta.push_back(transcript.get_challenge_field_element_from_map("nu", "r"));
+        }
         const fr zeta_omega = zeta * key->small_domain.root;
         if (bbg_prover_round6(dev, at_zeta.size(), at_zeta.data(), reinterpret_cast<const uint64_t*>(nu_zeta.data()), at_omega.size(), at_omega.data(),
                               reinterpret_cast<const uint64_t*>(nu_omega.data()), detail::limbs(zeta), detail::limbs(zeta_omega),

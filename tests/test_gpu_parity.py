@@ -1005,13 +1005,15 @@ def _powers_srs(oracle, count):
     return x, oracle.srs_powers(x, count)
 
 
-@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (2, 9), (0, 13), (1, 13), (2, 13)])
+@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (2, 9), (3, 9), (4, 9), (0, 13), (1, 13), (2, 13), (3, 13), (4, 13)])
 def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavour, log2_gates):
     """shim/bbg_resident_prover.hpp + bbg_prover_* (every O(n) step of the proof on the device, C++ host, no Python in the
     product path) against the reference CPU prover on the SAME randomness: the reference's construct_proof runs round by round
     on the host and the blinding scalars it draws are recorded; the resident prover replays them over a second session of the
     same circuit.  Transcript, commitments, evaluations -- the proof bytes -- must be IDENTICAL, for the provers of all three
-    composers of the reference (TurboComposer, StandardComposer, MiMCComposer), and the reference verifier must accept.  The device-derived forms of the proving key's polynomials (sigma
+    composers of the reference (TurboComposer, StandardComposer, MiMCComposer: flavours 0, 1, 2) and for the UNROLLED Turbo / Standard
+    provers (3, 4: create_unrolled_prover -- no linearisation polynomial, every polynomial opened, Pedersen-Blake2s transcript; what
+    the rollup circuits use), and the reference verifier must accept.  The device-derived forms of the proving key's polynomials (sigma
     in Lagrange base, 4n-coset forms, L_1) must equal the arrays the reference's compute_proving_key produced."""
     from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
     if not prover_available() or not os.path.exists(PROVER_GPU_SO):
@@ -1037,7 +1039,7 @@ def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavou
         P.free()
 
 
-@pytest.mark.parametrize("flavour", [0, 1, 2])
+@pytest.mark.parametrize("flavour", [0, 1, 2, 3, 4])
 def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     """INTEGRATION.md 2a for both composers: TurboComposer::create_prover (turbo_composer.cpp:727) and
     StandardComposer::create_prover (standard_composer.cpp:562) produce provers whose construct_proof(), UNMODIFIED and called
@@ -1048,7 +1050,7 @@ def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     x, pts = _powers_srs(oracle, (2 << 12) + 2)
     P = RefProver(1 << 12, 31, pts, x, gpu_linked=True, flavour=flavour)
     proof = P.prove_reference()
-    assert len(proof) == (1216, 832, 896)[flavour] and P.verify() == 1
+    assert len(proof) == (1216, 832, 896, 1504, 1024)[flavour] and P.verify() == 1
     P.free()
 
 
