@@ -141,8 +141,13 @@ struct Session {
     std::string error;
 };
 
-// A satisfiable arithmetic circuit of ~num_gates gates: a chain x_{k+1} = x_k * y_k + x_k with fresh y_k, laid out as one
-// multiplication gate and one addition gate per step (TurboComposer::create_mul_gate / create_add_gate).
+// A satisfiable circuit of ~num_gates gates: a chain x_{k+1} = x_k * y_k + x_k with fresh y_k, laid out as one multiplication gate and
+// one addition gate per step (create_mul_gate / create_add_gate).  Through the TurboComposer it is preceded (from 256 gates up) by
+// range constraints and AND / XOR constraints on 32-bit values (create_range_constraint, create_and_constraint,
+// create_xor_constraint: the range and logic widgets get non-zero selectors, satisfied), and -- `unsatisfied_fixed_base`, flavour 5 --
+// by fixed-base gates over ARBITRARY witnesses: that proof cannot verify, but every selector of the fixed-base widget is non-zero, so
+// its quotient and linearisation terms are compared byte for byte between the two provers.
+static bool g_unsatisfied_fixed_base = false;
 template <typename Composer> void build_circuit(Composer& c, size_t num_gates, uint64_t seed)
 {
     auto next = [&seed]() {
@@ -152,11 +157,33 @@ template <typename Composer> void build_circuit(Composer& c, size_t num_gates, u
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
         return z ^ (z >> 31);
     };
+    auto next_fr = [&]() { return fr{ next(), next(), next(), next() & 0x0fffffffffffffffULL }.to_montgomery_form(); };
+    const size_t before = c.get_num_gates();
+    if constexpr (std::is_same<Composer, waffle::TurboComposer>::value) {
+        if (num_gates >= 256) {
+            for (int k = 0; k < 2; k++) {
+                const uint64_t a = next() & 0xffffffffULL, b = next() & 0xffffffffULL;
+                const uint32_t ai = c.add_variable(fr(a).to_montgomery_form()), bi = c.add_variable(fr(b).to_montgomery_form());
+                c.create_range_constraint(ai, 32);
+                c.create_and_constraint(ai, bi, 32);
+                c.create_xor_constraint(bi, ai, 32);
+            }
+            if (g_unsatisfied_fixed_base) {
+                for (int k = 0; k < 8; k++) {
+                    waffle::fixed_group_add_quad q{ c.add_variable(next_fr()), c.add_variable(next_fr()), c.add_variable(next_fr()),
+                                                    c.add_variable(next_fr()), next_fr(), next_fr(), next_fr(), next_fr() };
+                    if (k == 0) c.create_fixed_group_add_gate_with_init(q, { next_fr(), next_fr(), next_fr(), next_fr() });
+                    else c.create_fixed_group_add_gate(q);
+                }
+            }
+        }
+    }
+    const size_t used = c.get_num_gates() - before;
     fr x = fr(next() | 1).to_montgomery_form();
     uint32_t xi = c.add_variable(x);
-    const size_t steps = num_gates / 2;
+    const size_t steps = (num_gates > used ? num_gates - used : 0) / 2;
     for (size_t k = 0; k < steps; k++) {
-        fr y = fr{ next(), next(), next(), next() & 0x0fffffffffffffffULL }.to_montgomery_form();
+        fr y = next_fr();
         uint32_t yi = c.add_variable(y);
         fr m = x * y;
         uint32_t mi = c.add_variable(m);
@@ -168,6 +195,7 @@ template <typename Composer> void build_circuit(Composer& c, size_t num_gates, u
         xi = si;
     }
 }
+
 // MiMCComposer: rounds of the MiMC permutation x <- (x + k + c_i)^7 as in the reference's own test (mimc_composer.test.cpp:7-41), one
 // create_mimc_gate per round, followed by the arithmetic chain above so that the arithmetic widget has work too.
 void build_mimc_circuit(waffle::MiMCComposer& c, size_t num_gates, uint64_t seed)
@@ -371,7 +399,8 @@ void* refp_new_flavour(int flavour, size_t num_gates, uint64_t circuit_seed, con
 {
     try {
         fr x{ x_mont[0], x_mont[1], x_mont[2], x_mont[3] };
-        if (flavour == 0) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
+        g_unsatisfied_fixed_base = flavour == 5; // 5 = TurboPLONK over a circuit that also has (unsatisfied) fixed-base gates
+        if (flavour == 0 || flavour == 5) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 1) return new_session<StandardSession, waffle::StandardComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 2) return new_session<MiMCSession, waffle::MiMCComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 3) return new_session<UnrolledTurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);

@@ -1039,6 +1039,27 @@ def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavou
         P.free()
 
 
+@pytest.mark.parametrize("log2_gates", [9, 12])
+def test_resident_prover_with_every_turbo_widget_active(pkg, oracle, bbg, log2_gates):
+    """The Turbo circuits of the tests above carry satisfied range and AND / XOR constraints besides their arithmetic gates; the
+    fixed-base widget's selectors are non-zero only here: flavour 5 adds fixed-base gates over ARBITRARY witnesses.  Such a proof
+    cannot verify (the reference prover does not care, prover.cpp never checks the witness) -- what is asserted is that the resident
+    prover emits the reference prover's bytes on the same randomness: quotient and linearisation terms of all four Turbo widgets."""
+    from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
+    if not prover_available() or not os.path.exists(PROVER_GPU_SO):
+        pytest.skip("oracle/_ref/libbbprover_gpu.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << log2_gates) + 2)
+    A = RefProver(1 << log2_gates, 77, pts, x, flavour=5)
+    proof_cpu, blind = A.prove_recording()
+    assert A.verify() == 0
+    B = RefProver(1 << log2_gates, 77, pts, x, gpu_linked=True, flavour=5)
+    assert B.resident_check_key() == 0
+    proof_gpu, _ = B.prove_resident(blind)
+    assert proof_gpu == proof_cpu
+    A.free()
+    B.free()
+
+
 @pytest.mark.parametrize("flavour", [0, 1, 2, 3, 4])
 def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     """INTEGRATION.md 2a for both composers: TurboComposer::create_prover (turbo_composer.cpp:727) and
