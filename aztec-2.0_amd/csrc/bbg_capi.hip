@@ -143,6 +143,11 @@ void bbg_destroy(bbg_ctx* ctx)
             (void)hipEventDestroy(ctx->ev_done[k]);
         }
     }
+    if (ctx->upload_stream) {
+        (void)hipStreamDestroy(ctx->upload_stream);
+        (void)hipEventDestroy(ctx->ev_upload_go);
+        for (int k = 0; k < bbg_ctx::UPLOAD_PIECES; k++) (void)hipEventDestroy(ctx->ev_upload[k]);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -210,6 +215,11 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
             }
             ctx->aux_stream = nullptr;
         }
+        return BBG_OK;
+    }
+    if (!strcmp(key, "msm_upload_pieces")) { // bbg_msm: pieces the host scalars travel in (1 = one copy in front of the MSM)
+        if (value < 1 || value > bbg_ctx::UPLOAD_PIECES) { set_error("bbg_set_option: msm_upload_pieces must be 1..4"); return BBG_E_INVALID; }
+        ctx->msm_upload_pieces = (int)value;
         return BBG_OK;
     }
     if (!strcmp(key, "msm_reduce_quad")) {
@@ -617,8 +627,7 @@ int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, si
     int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, n * 32 + 256);
     if (rc) return rc;
     char* st = (char*)ctx->staging;
-    if (n) BBG_HIP(hipMemcpyAsync(st + 256, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    rc = msm_run(ctx, srs->s, st + 256, from, n, st, ctx->stream);
+    rc = msm_run(ctx, srs->s, st + 256, from, n, st, ctx->stream, scalars); // uploads the scalars itself, in pieces, under its first pass
     if (rc) return rc;
     rc = msm_join(ctx, ctx->stream);
     if (rc) return rc;

@@ -89,6 +89,11 @@ struct bbg_ctx {
     hipStream_t aux_stream = nullptr; // = aux_streams[0] (non-null once the streams exist)
     hipStream_t aux_streams[MSM_SLOTS] = {};
     hipEvent_t ev_acc[MSM_SLOTS] = {}, ev_done[MSM_SLOTS] = {};
+    // host-buffer MSM (bbg_msm): the scalars travel in pieces on their own stream, the counting pass of a piece starts when it has landed
+    static constexpr int UPLOAD_PIECES = 4;
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t ev_upload[UPLOAD_PIECES] = {}, ev_upload_go = nullptr;
+    int msm_upload_pieces = 1; // option "msm_upload_pieces": 1 = one copy in front of the MSM (default: measured FASTER, profiles/r02_host_msm_ab.txt)
     bool ev_done_valid[MSM_SLOTS] = {};
     unsigned long msm_seq = 0;
     size_t msm_layout_n = 0; // (n, window width) of the layout the scratch arena currently holds: a change of either moves
@@ -156,8 +161,10 @@ int ntt_root_pow(bbg_ctx* ctx, unsigned log2n, uint64_t e, int inverse, uint64_t
 int ntt_fr_pow(bbg_ctx* ctx, const uint64_t* base, uint64_t e, uint64_t* out, hipStream_t stream);
 int ntt_cross_dft(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2G, size_t len, unsigned log2n, int inverse, hipStream_t stream);
 int field_op_device(int which, int op, const void* a, const void* b, void* out, size_t n, hipStream_t stream);
+// h_scalars (optional): the n scalars are still on the HOST and d_scalars is where they belong on the device -- msm_run uploads them
+// itself, piece by piece, overlapped with its first pass
 int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
-            hipStream_t stream);
+            hipStream_t stream, const void* h_scalars = nullptr);
 int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
 int msm_join(bbg_ctx* ctx, hipStream_t stream);
 int msm_debug_idx_mask(uint32_t mask);

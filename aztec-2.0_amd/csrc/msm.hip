@@ -1135,7 +1135,7 @@ int srs_synth_hashed(bbg_ctx*, uint64_t seed, size_t n, void* d_points, hipStrea
 
 template <int C>
 static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
-                     hipStream_t st)
+                     hipStream_t st, const void* h_scalars)
 {
     using K = MsmCfg<C>;
     MsmLayout L;
@@ -1185,6 +1185,9 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
     // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM MSM_SLOTS calls ago
     if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[slot], 0));
     const uint32_t* svals;
+    const int pieces = (h_scalars && ctx->msm_sort == 1 && n >= ((size_t)1 << 16)) ? ctx->msm_upload_pieces : 1;
+    if (h_scalars && pieces <= 1) // small n / library sort / option: one copy in front of everything
+        BBG_HIP(hipMemcpyAsync((void*)d_scalars, h_scalars, n * 32, hipMemcpyHostToDevice, st));
     if (ctx->msm_sort == 1) {
         // fused recode + MSD partition sort (keys0 area = 64-bit entries, vals0 = final values, keys1 head = partition tables)
         uint64_t* entries = (uint64_t*)keys0; // keys0 and keys1 are adjacent: 2 x 4 x 16n bytes = 8 x 16n
@@ -1195,7 +1198,32 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
         {
             ProfScope ps(ctx, "msm_recode", st);
             BBG_HIP(hipMemsetAsync(part_count, 0, SORT_PAD * 4, st));
-            hipLaunchKernelGGL(k_sortA_count<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
+            if (pieces > 1) {
+                // The counting pass is a histogram (global atomics): it does not care in which order, or in how many launches, it
+                // sees the scalars.  So the 32n bytes travel in pieces on their own stream and each piece is counted as soon as it has
+                // landed -- the only part of the MSM that can start before ALL scalars are there (the scatter needs the totals).
+                if (!ctx->upload_stream) {
+                    BBG_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+                    BBG_HIP(hipEventCreateWithFlags(&ctx->ev_upload_go, hipEventDisableTiming));
+                    for (int k = 0; k < bbg_ctx::UPLOAD_PIECES; k++) BBG_HIP(hipEventCreateWithFlags(&ctx->ev_upload[k], hipEventDisableTiming));
+                }
+                BBG_HIP(hipEventRecord(ctx->ev_upload_go, st)); // whatever `st` still does with the staging area comes first
+                BBG_HIP(hipStreamWaitEvent(ctx->upload_stream, ctx->ev_upload_go, 0));
+                const size_t blocks_per_piece = ((size_t)nblk + pieces - 1) / pieces;
+                for (int k = 0; k < pieces; k++) {
+                    const size_t lo = (size_t)k * blocks_per_piece * SORT_BLOCK;
+                    if (lo >= n) break;
+                    const size_t len = n - lo < blocks_per_piece * SORT_BLOCK ? n - lo : blocks_per_piece * SORT_BLOCK;
+                    BBG_HIP(hipMemcpyAsync((char*)d_scalars + lo * 32, (const char*)h_scalars + lo * 32, len * 32, hipMemcpyHostToDevice,
+                                           ctx->upload_stream));
+                    BBG_HIP(hipEventRecord(ctx->ev_upload[k], ctx->upload_stream));
+                    BBG_HIP(hipStreamWaitEvent(st, ctx->ev_upload[k], 0));
+                    hipLaunchKernelGGL(k_sortA_count<C>, dim3(grid_for(len, SORT_BLOCK)), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars + lo, len,
+                                       part_count);
+                }
+            } else {
+                hipLaunchKernelGGL(k_sortA_count<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
+            }
             hipLaunchKernelGGL(k_sortA_scan<C>, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets);
         }
         {
@@ -1271,7 +1299,7 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
 }
 
 
-int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st)
+int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st, const void* h_scalars)
 {
     if (from > srs.n || n > srs.n - from) {
         set_error("bbg_msm: range [from, from+n) exceeds the registered SRS");
@@ -1303,8 +1331,8 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
             return rc;
         }
     }
-    if (c == 20) return msm_run_c<20>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st);
-    return msm_run_c<16>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st);
+    if (c == 20) return msm_run_c<20>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st, h_scalars);
+    return msm_run_c<16>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st, h_scalars);
 }
 
 // makes the context stream wait for every reduce phase queued on the auxiliary stream (no host sync)
