@@ -24,7 +24,10 @@ sizes = [int(a) for a in sys.argv[1:]] or [16, 18, 20]
 x = O.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
 pts = O.srs_powers(x, (1 << max(sizes)) + 2)
 for lg in sizes:
-    for flavour, name in ((0, "TurboPLONK"), (1, "StandardPLONK")):
+    flavours = ((0, "TurboPLONK"), (1, "StandardPLONK"))
+    if os.environ.get("BBG_ALL_FLAVOURS"):  # + MiMCComposer's prover and the unrolled provers (what the rollup circuits use)
+        flavours += ((2, "MiMC (Standard + MiMC widget)"), (3, "UnrolledTurbo"), (4, "UnrolledStandard"))
+    for flavour, name in flavours:
         gates = (1 << lg) - 64
         A = RefProver(gates, 11, pts, x, flavour=flavour)
         t0 = time.perf_counter(); cpu, blind = A.prove_recording(); t_cpu = time.perf_counter() - t0
