@@ -265,24 +265,56 @@ def main():
     # ---- CPU baseline + bit-exact check against it (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, value)
+    # The extras below must never cost the run its line: each runs under a guard (exception -> {"error": ...}; no answer within
+    # the limit, e.g. a rank stuck in a collective -> {"error": "timeout"}, the line is printed and the process leaves without
+    # waiting for the stuck call).
+    stuck = []
+
+    def guarded(name, fn, limit_s):
+        import threading
+        box = {}
+
+        def run():
+            try:
+                torch.cuda.set_device(dev)
+                box["value"] = fn()
+            except BaseException as e:  # noqa: BLE001 -- reported in the line, never raised
+                box["error"] = "%s: %s" % (type(e).__name__, e)
+
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(limit_s)
+        if th.is_alive():
+            stuck.append(name)
+            return {"error": "timeout after %d s" % limit_s}
+        return box["value"] if "value" in box else {"error": box.get("error", "no result")}
+
     # ---- BASELINE config 4 (TurboPLONK prover sequence) on the resident prover rounds, one GPU
     if rank == 0 and world == 1 and not args.no_prover_shaped and lg >= 10:
-        extra["prover_shaped"] = prover_shaped(pkg, bbg, srs, lg)
-        if "cpu_baseline" in out and out["cpu_baseline"].get("kind") == "reference":
-            ref_ms = reference_prover_sequence(srs, scalars, coeffs, lg)
-            out["cpu_baseline"]["prover_shaped_ms"] = ref_ms
-            extra["prover_shaped"]["reference_same_sequence_ms"] = ref_ms["total_ms"]
-            extra["prover_shaped"]["speedup_vs_reference_sequence"] = round(ref_ms["total_ms"] / extra["prover_shaped"]["proof_ms"], 1)
+        extra["prover_shaped"] = guarded("prover_shaped", lambda: prover_shaped(pkg, bbg, srs, lg), 300)
+        if "error" not in extra["prover_shaped"] and "cpu_baseline" in out and out["cpu_baseline"].get("kind") == "reference":
+            # the reference binary stays on the MAIN thread: its OpenMP pippenger keeps per-thread state sized by the team it first saw,
+            # and a call from another host thread (another OpenMP root) corrupts memory -- measured: SIGSEGV
+            try:
+                ref_ms = reference_prover_sequence(srs, scalars, coeffs, lg)
+            except Exception as e:  # noqa: BLE001
+                ref_ms = {"error": "%s: %s" % (type(e).__name__, e)}
+            if "error" not in ref_ms:
+                out["cpu_baseline"]["prover_shaped_ms"] = ref_ms
+                extra["prover_shaped"]["reference_same_sequence_ms"] = ref_ms["total_ms"]
+                extra["prover_shaped"]["speedup_vs_reference_sequence"] = round(ref_ms["total_ms"] / extra["prover_shaped"]["proof_ms"], 1)
     # ---- BASELINE config 5: ONE 2^24 MSM + ONE 2^24 coset NTT over the N GPUs (strong scaling: total work fixed as N grows)
-    if not args.no_config5:
+    if not args.no_config5 and not stuck:
         srs.free()
         srs = None
-        c5 = config5(pkg, par, bbg, dist, dev, rank, world, args.config5_log2n)
+        c5 = guarded("config5", lambda: config5(pkg, par, bbg, dist, dev, rank, world, args.config5_log2n), 300)
         if rank == 0:
             extra["config5"] = c5
     if rank == 0:
         sys.stdout.flush()
         os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())
+    if stuck:
+        os._exit(0)  # a guarded extra never returned: do not wait for it (or for the process group) on the way out
     if srs is not None:
         srs.free()
     bbg.close()
