@@ -23,7 +23,7 @@ def build_library(force=False):
     """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run(["make", "-C", CSRC, "-j4"], check=True)
+    subprocess.run(["make", "-C", CSRC, "-j8"], check=True)
     return LIB_PATH
 
 
