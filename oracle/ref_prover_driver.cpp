@@ -180,7 +180,7 @@ template <typename Composer> void build_circuit(Composer& c, size_t num_gates, u
     }
     const size_t used = c.get_num_gates() - before;
     fr x = fr(next() | 1).to_montgomery_form();
-    uint32_t xi = c.add_variable(x);
+    uint32_t xi = c.add_public_variable(x); // one public input: public_input_delta != 1 in the permutation argument of every flavour
     const size_t steps = (num_gates > used ? num_gates - used : 0) / 2;
     for (size_t k = 0; k < steps; k++) {
         fr y = next_fr();
