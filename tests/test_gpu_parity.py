@@ -22,6 +22,19 @@ def test_native_library_loaded(pkg, bbg):
     assert "libbbg.so" in maps, "the HIP extension is not the code that ran"
 
 
+def test_quad_ec_operations_device_check():
+    """curve_quad.hip.h (four lanes per EC operation, the MSM reduce phase) against curve.hip.h's one-lane formulas ON THE DEVICE, in the
+    shapes the reduce kernels use: all lanes active, quads of one wave taking different branches, runtime-length doubling chains run by
+    one quad, loops (where a compiler-built switch over the lane role once selected the wrong operand: DESIGN 3.6)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_micro", "quad_check")
+    if not os.path.exists(exe):
+        pytest.fail("bench_micro/quad_check has not been built: run __graft_entry__.build()")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "failure mask 0x0 (PASS)" in out, out[-600:]
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_field_ops(pkg, oracle, bbg, which):
     a = pkg.synthetic_scalars(11, 20000)
