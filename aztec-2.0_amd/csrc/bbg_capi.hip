@@ -245,6 +245,9 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     } else if (!strcmp(key, "ntt_kernel")) {
         if (value != 1 && value != 2) { set_error("ntt_kernel must be 1 or 2"); return BBG_E_INVALID; }
         ctx->ntt_kernel = (int)value;
+    } else if (!strcmp(key, "ntt_big_tile")) {
+        if (value < 0 || value > 2) { set_error("ntt_big_tile must be 0, 1 or 2"); return BBG_E_INVALID; }
+        ctx->ntt_big_tile = (int)value;
     } else if (!strcmp(key, "ntt_max_logr8")) {
         if (value < 6 || value > 11) { set_error("ntt_max_logr8 must be 6..11"); return BBG_E_INVALID; }
         ctx->ntt_max_logr8 = (int)value;

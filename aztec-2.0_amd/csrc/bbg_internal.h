@@ -30,6 +30,7 @@ struct NttDomain {
     unsigned log2n = 0;
     int passes = 0;
     bool use_pass8 = false; // register-resident radix-8 pass kernel (ntt_pass8.hip.h) vs the radix-2-in-LDS one
+    int tile_log8 = 11;     // its tile: 2^11 elements (256 threads) or 2^12 (512 threads: 2^21 / 2^22 in two passes)
     bool inv_scaled = false; // the inverse inter-pass twiddles of pass 0 carry n^-1: ifft needs no scaling sweep
     int logR[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
     int logW[NTT_MAX_PASSES] = { 0, 0, 0, 0 };
@@ -113,6 +114,7 @@ struct bbg_ctx {
     int ntt_max_logr = 7;
     int ntt_kernel = 2;      // 2 = k_ntt_pass8 where applicable (n >= 2^11), 1 = k_ntt_pass only
     int ntt_max_logr8 = 10;  // max log-radix per pass for k_ntt_pass8
+    int ntt_big_tile = 1;    // option "ntt_big_tile": 1 = 2^21 as TWO passes over 4096-element tiles instead of three over 2048; 2 = 2^22 as well; 0 = never
     bool ntt_attr8_set = false, ntt_attr_set = false; // dynamic-LDS attributes of the pass kernels set on this context's device
 };
 

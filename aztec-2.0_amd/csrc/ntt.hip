@@ -343,6 +343,21 @@ static void plan_passes(bbg_ctx* ctx, NttDomain& d)
 {
     const int L = (int)d.log2n;
     d.use_pass8 = false;
+    d.tile_log8 = P8_TILE_LOG;
+    if (ctx->ntt_kernel == 2 && ((ctx->ntt_big_tile >= 1 && L == 21) || (ctx->ntt_big_tile >= 2 && L == 22))) {
+        // 4096-element tiles (512 threads): radix 2^11 x 2^10 in TWO passes, W = 2 / 4 columns per tile -- one whole pass over the array (and
+        // its inter-pass twiddle table) less than the 2048-tile plan's three passes, paid for with 64-byte instead of 256-byte global runs.
+        // Measured (HIP events, 50 back-to-back transforms): 2^21 0.2537 vs 0.2604 ms (kept, default); 2^22 (2^11 x 2^11, W = 2 in both
+        // passes) 0.518 vs 0.502 ms (option value 2 only).
+        d.passes = 2;
+        d.logR[0] = 11;
+        d.logR[1] = L - 11;
+        d.logW[0] = P8_TILE_LOG_BIG - d.logR[0];
+        d.logW[1] = P8_TILE_LOG_BIG - d.logR[1];
+        d.tile_log8 = P8_TILE_LOG_BIG;
+        d.use_pass8 = true;
+        return;
+    }
     if (ctx->ntt_kernel == 2 && L >= P8_TILE_LOG) {
         // register-resident radix-8 kernel: 2048-element tiles, log-radix 3..11 per pass, balanced split
         int maxr = ctx->ntt_max_logr8;
@@ -507,9 +522,16 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
         if (!attr8) {
             BBG_HIP(p8_attr<3>()); BBG_HIP(p8_attr<4>()); BBG_HIP(p8_attr<5>()); BBG_HIP(p8_attr<6>()); BBG_HIP(p8_attr<7>());
             BBG_HIP(p8_attr<8>()); BBG_HIP(p8_attr<9>()); BBG_HIP(p8_attr<10>()); BBG_HIP(p8_attr<11>());
+            BBG_HIP((p8_attr<10, P8_TILE_LOG_BIG>())); BBG_HIP((p8_attr<11, P8_TILE_LOG_BIG>()));
             attr8 = true;
         }
         ProfScope ps(ctx, "ntt_pass", st);
+        if (d.tile_log8 == P8_TILE_LOG_BIG) {
+            if (p.logR == 11) p8_launch<11, P8_TILE_LOG_BIG>(p, tiles, st);
+            else if (p.logR == 10) p8_launch<10, P8_TILE_LOG_BIG>(p, tiles, st);
+            else { set_error("ntt: bad pass8 radix for the 4096-element tile"); return BBG_E_INVALID; }
+            return BBG_OK;
+        }
         switch (p.logR) {
         case 3: p8_launch<3>(p, tiles, st); break;
         case 4: p8_launch<4>(p, tiles, st); break;

@@ -15,9 +15,10 @@
 
 namespace bbg {
 
-constexpr int P8_TILE_LOG = 11;                       // 2048 elements per tile = 256 threads x 8
-constexpr int P8_PLANE = 2048 + (2048 >> 4) * 2;      // uint4 slots per plane incl. padding (2 per 16)
-constexpr size_t P8_LDS_BYTES = (size_t)2 * P8_PLANE * 16;
+constexpr int P8_TILE_LOG = 11;                       // 2048 elements per tile = 256 threads x 8 (the default tile)
+constexpr int P8_TILE_LOG_BIG = 12;                   // 4096 elements = 512 threads x 8: 2^21 / 2^22 in TWO passes of >= 64-byte runs (r2)
+template <int TL> constexpr int p8_plane() { return (1 << TL) + ((1 << TL) >> 4) * 2; } // uint4 slots per plane incl. padding (2 per 16)
+template <int TL> constexpr size_t p8_lds_bytes() { return (size_t)2 * p8_plane<TL>() * 16; }
 
 __device__ __forceinline__ int p8_addr(int p, int c, int logW) // padded LDS slot of tile element (p, c)
 {
@@ -88,11 +89,11 @@ __device__ __forceinline__ constexpr int p8_brev3(int j) { return ((j & 1) << 2)
 
 // one step: FIRST loads from global, LAST stores to global, otherwise through LDS
 // where the LAST step of a pass delivers register j of this thread: the in-tile position pj (bit-reversed on the way out) and column c
-template <int LOGR> __device__ __forceinline__ void p8_last_coords(int tid, int j, int& pj, int& c)
+template <int LOGR, int TL> __device__ __forceinline__ void p8_last_coords(int tid, int j, int& pj, int& c)
 {
     constexpr int NSTEPS = (LOGR + 2) / 3, T = NSTEPS - 1;
     constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
-    constexpr int LOGW = P8_TILE_LOG - LOGR, W = 1 << LOGW;
+    constexpr int LOGW = TL - LOGR, W = 1 << LOGW;
     c = tid & (W - 1);
     const int q = tid >> LOGW;
     const int qlo = q & ((1 << F) - 1);
@@ -117,7 +118,7 @@ __device__ __forceinline__ size_t p8_out_index(const PassParams& p, int pj, int 
     return (d1_0 + c) + (acc << p.logR1) + ((size_t)i << (p.logR1 + shift));
 }
 
-template <int LOGR, bool ROW, int T>
+template <int LOGR, bool ROW, int T, int TL>
 __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* plo, uint4* phi, const Fr* __restrict__ tw, size_t base,
                                         size_t lo0, size_t d1_0, size_t rest, int logRestCount, const Fr (&outmul)[8], bool have_outmul)
 {
@@ -125,7 +126,7 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
     constexpr bool FIRST = (T == 0), LAST = (T == NSTEPS - 1);
     constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
     constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
-    constexpr int LOGW = P8_TILE_LOG - LOGR, W = 1 << LOGW;
+    constexpr int LOGW = TL - LOGR, W = 1 << LOGW;
     constexpr int QBITS = LOGR - 3;
     const int tid = threadIdx.x;
     int c, q;
@@ -200,13 +201,13 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
     }
 }
 
-template <int LOGR, bool ROW> __global__ void __launch_bounds__(256) k_ntt_pass8(PassParams p)
+template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3)) k_ntt_pass8(PassParams p)
 {
     extern __shared__ uint4 lds[];
     uint4* plo = lds;
-    uint4* phi = lds + P8_PLANE;
+    uint4* phi = lds + p8_plane<TL>();
     constexpr int NSTEPS = (LOGR + 2) / 3;
-    constexpr int LOGW = P8_TILE_LOG - LOGR;
+    constexpr int LOGW = TL - LOGR;
     const size_t tile = blockIdx.x;
     size_t base = 0, lo0 = 0, d1_0 = 0, rest = 0;
     int logRestCount = 0;
@@ -233,38 +234,38 @@ template <int LOGR, bool ROW> __global__ void __launch_bounds__(256) k_ntt_pass8
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 int pj, c;
-                p8_last_coords<LOGR>(threadIdx.x, j, pj, c);
+                p8_last_coords<LOGR, TL>(threadIdx.x, j, pj, c);
                 outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, true));
             }
         }
     };
     if constexpr (NSTEPS == 1) fetch_outmul();
-    p8_step<LOGR, ROW, 0>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 1 && have_outmul);
+    p8_step<LOGR, ROW, 0, TL>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 1 && have_outmul);
     if constexpr (NSTEPS > 1) {
         fetch_outmul();
         __syncthreads();
-        p8_step<LOGR, ROW, 1>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 2 && have_outmul);
+        p8_step<LOGR, ROW, 1, TL>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 2 && have_outmul);
     }
     if constexpr (NSTEPS > 2) {
         __syncthreads();
-        p8_step<LOGR, ROW, 2>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 3 && have_outmul);
+        p8_step<LOGR, ROW, 2, TL>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 3 && have_outmul);
     }
     if constexpr (NSTEPS > 3) {
         __syncthreads();
-        p8_step<LOGR, ROW, 3>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 4 && have_outmul);
+        p8_step<LOGR, ROW, 3, TL>(x, p, plo, phi, tw, base, lo0, d1_0, rest, logRestCount, outmul, NSTEPS == 4 && have_outmul);
     }
 }
 
-template <int LOGR> static void p8_launch(const PassParams& p, size_t tiles, hipStream_t st)
+template <int LOGR, int TL = P8_TILE_LOG> static void p8_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {
-    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8<LOGR, true>), dim3((unsigned)tiles), dim3(256), P8_LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((k_ntt_pass8<LOGR, false>), dim3((unsigned)tiles), dim3(256), P8_LDS_BYTES, st, p);
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);
+    else hipLaunchKernelGGL((k_ntt_pass8<LOGR, false, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);
 }
-template <int LOGR> static hipError_t p8_attr()
+template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p8_attr()
 {
-    hipError_t e = hipFuncSetAttribute((const void*)k_ntt_pass8<LOGR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_ntt_pass8<LOGR, true, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p8_lds_bytes<TL>());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_ntt_pass8<LOGR, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_BYTES);
+    return hipFuncSetAttribute((const void*)k_ntt_pass8<LOGR, false, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p8_lds_bytes<TL>());
 }
 
 } // namespace bbg

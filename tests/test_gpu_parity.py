@@ -105,6 +105,25 @@ def test_ntt_pass_plans(pkg, oracle, bbg, tile, maxr):
         bbg.set_option("ntt_max_logr", 7)
 
 
+def test_ntt_big_tile_plans_agree(pkg, oracle, bbg):
+    """2^21 / 2^22 through the 4096-element-tile plan (two passes; default for 2^21, option value 2 for 2^22) and through the 2048-tile plan
+    (three passes): the same values, forward / inverse / coset, bit for bit."""
+    import torch
+    for lg in (21, 22):
+        n = 1 << lg
+        src = torch.from_numpy(pkg.synthetic_scalars(900 + lg, n).view(np.int64).reshape(-1)).cuda()
+        for op in (0, 1, 2, 3):
+            outs = []
+            for big in (0, 2):
+                bbg.set_option("ntt_big_tile", big)
+                a = src.clone()
+                bbg.ntt_device(a.data_ptr(), lg, op)
+                bbg.sync()
+                outs.append(oracle.canon(0, a.cpu().numpy().view(np.uint64).reshape(-1, 4)))
+            assert np.array_equal(outs[0], outs[1]), (lg, op)
+    bbg.set_option("ntt_big_tile", 1)
+
+
 @pytest.mark.parametrize("maxr8", [6, 7, 8, 9, 10, 11])
 def test_ntt_pass8_plans(pkg, oracle, bbg, maxr8):
     """k_ntt_pass8 (register radix-8 steps) under every per-pass radix limit: 1, 2, 3 and 4-pass decompositions with
@@ -142,7 +161,7 @@ def test_fft_matches_horner(pkg, oracle, bbg):
         z = oracle.fe_mul(0, z, w)[0]
 
 
-@pytest.mark.parametrize("lg", [18, 20, 22, 24])
+@pytest.mark.parametrize("lg", [18, 20, 21, 22, 24])
 def test_ntt_full_size_properties(pkg, oracle, bbg, lg):
     """BASELINE config 2 sizes: round trips (basic_fft / fft_coset_ifft_consistency, polynomial_arithmetic.test.cpp:70-134),
     linearity, and the n / 2n cross-domain consistency of :136-177, all bit-exact on canonical values."""
