@@ -148,6 +148,7 @@ struct Session {
 // by fixed-base gates over ARBITRARY witnesses: that proof cannot verify, but every selector of the fixed-base widget is non-zero, so
 // its quotient and linearisation terms are compared byte for byte between the two provers.
 static bool g_unsatisfied_fixed_base = false;
+static bool g_arithmetic_only = false; // flavour 6: a TurboComposer circuit with add / mul gates only (q_range = q_logic = q_ecc = 0)
 template <typename Composer> void build_circuit(Composer& c, size_t num_gates, uint64_t seed)
 {
     auto next = [&seed]() {
@@ -160,7 +161,7 @@ template <typename Composer> void build_circuit(Composer& c, size_t num_gates, u
     auto next_fr = [&]() { return fr{ next(), next(), next(), next() & 0x0fffffffffffffffULL }.to_montgomery_form(); };
     const size_t before = c.get_num_gates();
     if constexpr (std::is_same<Composer, waffle::TurboComposer>::value) {
-        if (num_gates >= 256) {
+        if (num_gates >= 256 && !g_arithmetic_only) {
             for (int k = 0; k < 2; k++) {
                 const uint64_t a = next() & 0xffffffffULL, b = next() & 0xffffffffULL;
                 const uint32_t ai = c.add_variable(fr(a).to_montgomery_form()), bi = c.add_variable(fr(b).to_montgomery_form());
@@ -400,7 +401,8 @@ void* refp_new_flavour(int flavour, size_t num_gates, uint64_t circuit_seed, con
     try {
         fr x{ x_mont[0], x_mont[1], x_mont[2], x_mont[3] };
         g_unsatisfied_fixed_base = flavour == 5; // 5 = TurboPLONK over a circuit that also has (unsatisfied) fixed-base gates
-        if (flavour == 0 || flavour == 5) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
+        g_arithmetic_only = flavour == 6;        // 6 = TurboPLONK, arithmetic gates only (three gate selectors are zero on every gate row)
+        if (flavour == 0 || flavour == 5 || flavour == 6) return new_session<TurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 1) return new_session<StandardSession, waffle::StandardComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 2) return new_session<MiMCSession, waffle::MiMCComposer>(num_gates, circuit_seed, points, num_points, x);
         if (flavour == 3) return new_session<UnrolledTurboSession, waffle::TurboComposer>(num_gates, circuit_seed, points, num_points, x);

@@ -1037,7 +1037,7 @@ def _powers_srs(oracle, count):
     return x, oracle.srs_powers(x, count)
 
 
-@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (2, 9), (3, 9), (4, 9), (0, 13), (1, 13), (2, 13), (3, 13), (4, 13)])
+@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (2, 9), (3, 9), (4, 9), (6, 9), (0, 13), (1, 13), (2, 13), (3, 13), (4, 13), (6, 13)])
 def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavour, log2_gates):
     """shim/bbg_resident_prover.hpp + bbg_prover_* (every O(n) step of the proof on the device, C++ host, no Python in the
     product path) against the reference CPU prover on the SAME randomness: the reference's construct_proof runs round by round
@@ -1045,7 +1045,8 @@ def test_resident_prover_reproduces_the_reference_proof(pkg, oracle, bbg, flavou
     same circuit.  Transcript, commitments, evaluations -- the proof bytes -- must be IDENTICAL, for the provers of all three
     composers of the reference (TurboComposer, StandardComposer, MiMCComposer: flavours 0, 1, 2) and for the UNROLLED Turbo / Standard
     provers (3, 4: create_unrolled_prover -- no linearisation polynomial, every polynomial opened, Pedersen-Blake2s transcript; what
-    the rollup circuits use), and the reference verifier must accept.  The device-derived forms of the proving key's polynomials (sigma
+    the rollup circuits use), and the reference verifier must accept.  Flavour 6 = TurboPLONK over an arithmetic-only circuit (the fixed-base /
+    range / logic selectors vanish on every gate row; the reference still sets their last row to 1, composer_base.cpp:186).  The device-derived forms of the proving key's polynomials (sigma
     in Lagrange base, 4n-coset forms, L_1) must equal the arrays the reference's compute_proving_key produced."""
     from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
     if not prover_available() or not os.path.exists(PROVER_GPU_SO):

@@ -25,8 +25,12 @@ x = O.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint6
 pts = O.srs_powers(x, (1 << max(sizes)) + 2)
 for lg in sizes:
     flavours = ((0, "TurboPLONK"), (1, "StandardPLONK"))
-    if os.environ.get("BBG_ALL_FLAVOURS"):  # + MiMCComposer's prover and the unrolled provers (what the rollup circuits use)
-        flavours += ((2, "MiMC (Standard + MiMC widget)"), (3, "UnrolledTurbo"), (4, "UnrolledStandard"))
+    if os.environ.get("BBG_ONLY_FLAVOURS"):
+        names = {0: "TurboPLONK", 1: "StandardPLONK", 2: "MiMC", 3: "UnrolledTurbo", 4: "UnrolledStandard", 6: "TurboPLONK arithmetic-only"}
+        flavours = tuple((int(f), names[int(f)]) for f in os.environ["BBG_ONLY_FLAVOURS"].split(","))
+    elif os.environ.get("BBG_ALL_FLAVOURS"):  # + MiMCComposer's prover and the unrolled provers (what the rollup circuits use)
+        flavours += ((2, "MiMC (Standard + MiMC widget)"), (3, "UnrolledTurbo"), (4, "UnrolledStandard"),
+                     (6, "TurboPLONK, arithmetic gates only"))
     for flavour, name in flavours:
         gates = (1 << lg) - 64
         A = RefProver(gates, 11, pts, x, flavour=flavour)
