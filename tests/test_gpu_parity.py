@@ -381,6 +381,29 @@ def test_msm_sort_paths_agree(pkg, oracle, bbg, srs16):
         bbg.set_option("msm_window", 0)
 
 
+def test_msm_option_matrix_is_bit_identical(pkg, oracle, bbg, srs16):
+    """The A/B options of the MSM (bbg.h: msm_reduce_quad stage masks, msm_upload_pieces, msm_async_reduce) change how the work is
+    issued, never the point: every combination against the oracle, at sizes on both sides of the lane-group combine."""
+    srs = srs16
+    pts = srs.read(0, 1 << 16)
+    try:
+        for n in (1, 257, 4096, 1 << 16):
+            sc = pkg.synthetic_scalars(4242 + n, n)
+            want = oracle.pippenger(sc, pts[:n])
+            for quad in (0, 15, 5, 10):
+                for pieces in (1, 4):
+                    for overlap in (0, 1):
+                        bbg.set_option("msm_reduce_quad", quad)
+                        bbg.set_option("msm_upload_pieces", pieces)
+                        bbg.set_option("msm_async_reduce", overlap)
+                        got = oracle.jac_to_affine(bbg.msm(srs, sc))
+                        assert np.array_equal(got, want), (n, quad, pieces, overlap)
+    finally:
+        bbg.set_option("msm_reduce_quad", 15)
+        bbg.set_option("msm_upload_pieces", 1)
+        bbg.set_option("msm_async_reduce", 0)
+
+
 def test_msm_window20_vs_oracle(pkg, oracle, bbg, golden, srs16):
     """The 20-bit-window configuration (automatic from n = 2^20) forced at small sizes: oracle parity, `from` offsets,
     the reference's golden results and the mixed-width scalar distribution."""
