@@ -35,7 +35,7 @@ namespace bbg {
 
 // Window width C is a per-call choice between two compiled configurations (msm_pick_window): C = 16 (16 windows, 2^15
 // buckets) and C = 20 (13 windows, 2^19 buckets).  Wider windows trade 19 % of the mixed additions for a 16x larger
-// bucket reduction, which pays from n = 2^21 upwards.  Each width has its own window tables T[w][i] = 2^(C w) P_i.
+// bucket reduction, which pays from n = 2^20 upwards (r2; 2^21 in round 1).  Each width has its own window tables T[w][i] = 2^(C w) P_i.
 template <int C> struct MsmCfg {
     static constexpr int c = C;
     static constexpr int windows = (254 + C) / C;      // C * windows >= 255: 254 scalar bits + the recoding carry
@@ -1097,11 +1097,14 @@ int msm_windows_for(int c) { return c == 20 ? MsmCfg<20>::windows : MsmCfg<16>::
 // Window width for an n-term MSM (0 = automatic).  2^19 buckets cost ~0.25 ms of extra reduction and sort work against
 // 19 % fewer mixed additions.  Measured (interleaved A/B, pipelined, profiles/r01_msm_size_sweep.txt): n = 2^20 1.70 vs
 // 1.75 ms MSM-only but 1.85 vs 1.80 ms for the MSM + NTT bench step (the longer reduce phase competes with the NTT);
-// n = 2^21 3.03 vs 3.22 ms; n = 2^22 6.0 vs 6.5 ms.  Hence 20 bits from 2^21 terms.
+// n = 2^21 3.03 vs 3.22 ms; n = 2^22 6.0 vs 6.5 ms.  Hence 20 bits from 2^21 terms in round 1.
+// Round 2 (reduce trees with four lanes per EC operation, combine with one; profiles/r02_reduce_ab.txt, r02_window_sweep.txt): n = 2^20
+// 1.573 vs 1.608 ms pipelined, 1.727 vs 1.741 stand-alone, and the MSM + NTT bench step 1.71 vs 1.78 ms (613 vs 588 Mscalar-mul/s); n = 2^19
+// 1.04 vs 0.90 ms.  Hence 20 bits from 2^20 terms.
 int msm_pick_window(const bbg_ctx* ctx, size_t n)
 {
     if (ctx->msm_window == 16 || ctx->msm_window == 20) return ctx->msm_window;
-    return n >= ((size_t)1 << 21) ? 20 : 16;
+    return n >= ((size_t)1 << 20) ? 20 : 16; // r2 (one-lane combine + four-lane trees): the crossover moved from 2^21 down to 2^20
 }
 
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st)

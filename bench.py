@@ -226,6 +226,8 @@ def main():
                 "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
+    msm_windows = (20 if (args.msm_window == 20 or (args.msm_window == 0 and n >= (1 << 20))) else 16)
+    msm_windows = 13.0 if msm_windows == 20 else 16.0
     pass_ms = avg("ntt_pass")
     ntt_alg = 64.0 * n
     ntt_passes = prof["ntt_pass"][1] / max(1, args.steps)
@@ -244,8 +246,10 @@ def main():
         "timed_blocks_ms": [round(b[0] * 1e3, 3) for b in blocks], "reported_block": "median",
         "valu_issue": valu_issue(acc_ms, ntt_ms),
         "alu": {"unit": "T v_mad_u64_u32/s", "peak_measured": MAD_PEAK_TOPS,
-                # 16 windows x n mixed additions x 10 Fq mul x 136 mads ; n/2*(lg - passes) + n*(passes-1) Fr mul x 136
-                "msm_accumulate": round(16.0 * n * 10 * 136 / (acc_ms * 1e-3) / 1e12, 2),
+                # windows x n mixed additions x 10 Fq mul x 136 mads (13 windows of 20 bits from n = 2^20, else 16 of 16 bits);
+                # n/2*(lg - passes) + n*(passes-1) Fr mul x 136
+                "msm_windows": msm_windows,
+                "msm_accumulate": round(msm_windows * n * 10 * 136 / (acc_ms * 1e-3) / 1e12, 2),
                 "ntt": round((n / 2 * (lg - ntt_passes) + n * (ntt_passes - 1)) * 136 / (ntt_ms * 1e-3) / 1e12, 2)},
     }
 

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 pkg = ge.load_package()
 bbg = pkg.Bbg(0)
 bbg.set_stream(torch.cuda.current_stream().cuda_stream)
-LO, HI = 18, 22
+LO, HI = 17, 22
 N = 1 << HI
 srs = bbg.srs_synth_hashed(0xBB254, N)
 sc = pkg.synthetic_scalars(7, N)
