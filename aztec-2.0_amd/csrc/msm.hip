@@ -924,21 +924,23 @@ k_combine_long_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz*
     }
 }
 
-template <int C> __global__ void __launch_bounds__(Q_THREADS) k_rowcol_q(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
+// QL logical lanes (4 QL threads) per row / column: each lane first sums its share serially, then a tree of log2 QL levels.  Fewer lanes =
+// more serial additions but fewer idle tree slots and fewer waves per SIMD (a tree level costs ~2.7 us with one wave per SIMD, ~7 with three).
+template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
 {
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
-    __shared__ Xyzz sm[Q_LOGICAL / 2];
+    __shared__ Xyzz sm[QL / 2];
     const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
     Xyzz v = xyzz_inf();
     if (blockIdx.x < ROWS) {
         const int hi = blockIdx.x;
-        for (int lo = lt; lo < COLS; lo += Q_LOGICAL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
-        v = block_reduce_q4(v, sm, Q_LOGICAL);
+        for (int lo = lt; lo < COLS; lo += QL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
+        v = block_reduce_q4(v, sm, QL);
         if (threadIdx.x == 0) xyzz_store(rows + hi, v);
     } else {
         const int lo = blockIdx.x - ROWS;
-        for (int hi = lt; hi < ROWS; hi += Q_LOGICAL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
-        v = block_reduce_q4(v, sm, Q_LOGICAL);
+        for (int hi = lt; hi < ROWS; hi += QL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
+        v = block_reduce_q4(v, sm, QL);
         if (threadIdx.x == 0) xyzz_store(cols + lo, v);
     }
 }
@@ -1286,7 +1288,9 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
                                    buckets, long_count, long_list);
             hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
         }
-        if (quad & 2) hipLaunchKernelGGL(k_rowcol_q<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(Q_THREADS), 0, rst, buckets, rows, cols);
+        // 64 logical lanes per row / column (measured against 128 / 32 / 16: reduce phase 0.458 / 0.49 / 0.53 / 0.55 ms at 2^20 stand-alone,
+        // 0.154 / 0.165 / 0.164 / 0.184 at 2^10; bench step equal for 64 and 128, worse below)
+        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, 64>), dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
         else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
         if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
         else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
