@@ -46,6 +46,16 @@ __device__ __forceinline__ Fq quad_pick(const QuadRole& w, const Fq& a0, const F
     return quad_pick2(w.high, quad_pick2(w.odd, a0, a1), quad_pick2(w.odd, a2, a3));
 }
 
+// the point held by lane K of the quad, in every lane of the quad
+template <int K> __device__ __forceinline__ Xyzz quad_bcast_point(const Xyzz& p)
+{
+    Xyzz r;
+    r.x = quad_bcast<K>(p.x);
+    r.y = quad_bcast<K>(p.y);
+    r.zz = quad_bcast<K>(p.zz);
+    r.zzz = quad_bcast<K>(p.zzz);
+    return r;
+}
 // 2P; all four lanes of the quad pass the same p and receive the same result.  q = lane index within the quad.
 __device__ __forceinline__ Xyzz xyzz_dbl_q4(const Xyzz& p, int q)
 {
@@ -98,6 +108,14 @@ __device__ __forceinline__ Xyzz xyzz_add_q4(const Xyzz& a, const Xyzz& b, int q)
     r.zz = ZZ3;
     r.zzz = quad_bcast<3>(m);
     return r;
+}
+
+// (p0 + p1) + (p2 + p3) for the four DIFFERENT points p held by the lanes of a quad; every lane receives the sum
+__device__ __forceinline__ Xyzz quad_sum4(const Xyzz& p, int q)
+{
+    const Xyzz a = xyzz_add_q4(quad_bcast_point<0>(p), quad_bcast_point<1>(p), q);
+    const Xyzz b = xyzz_add_q4(quad_bcast_point<2>(p), quad_bcast_point<3>(p), q);
+    return xyzz_add_q4(a, b, q);
 }
 
 } // namespace bbg

@@ -930,17 +930,20 @@ template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(co
 {
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[QL / 2];
-    const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
-    Xyzz v = xyzz_inf();
+    const int q = threadIdx.x & 3;
+    // serial phase: every THREAD sums its own share with one-lane additions (a quad-cooperative addition costs 1.55x the instructions of a
+    // one-lane one -- it buys latency, and there is none to buy while all four lanes have items of their own); then the four partial sums of
+    // a quad are added with four-lane operations, then the tree over the QL quads
+    Xyzz s = xyzz_inf();
     if (blockIdx.x < ROWS) {
         const int hi = blockIdx.x;
-        for (int lo = lt; lo < COLS; lo += QL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
-        v = block_reduce_q4(v, sm, QL);
+        for (int lo = threadIdx.x; lo < COLS; lo += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
+        Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
         if (threadIdx.x == 0) xyzz_store(rows + hi, v);
     } else {
         const int lo = blockIdx.x - ROWS;
-        for (int hi = lt; hi < ROWS; hi += QL) v = xyzz_add_q4(v, xyzz_load(buckets + (size_t)hi * COLS + lo), q);
-        v = block_reduce_q4(v, sm, QL);
+        for (int hi = threadIdx.x; hi < ROWS; hi += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
+        Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
         if (threadIdx.x == 0) xyzz_store(cols + lo, v);
     }
 }
