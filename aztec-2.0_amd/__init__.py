@@ -8,4 +8,4 @@ There is deliberately NO CPU fallback here: if the library or a gfx950 device is
 Nothing in this package imports or calls anything under ``oracle/`` (the checker).
 """
 from .binding import Bbg, BbgError, LIB_PATH, build_library, load_library  # noqa: F401
-from .inputs import splitmix64_limbs, synthetic_scalars  # noqa: F401
+from .inputs import fr_reduce_once, splitmix64_limbs, synthetic_scalars, synthetic_scalars_strided  # noqa: F401

@@ -68,6 +68,7 @@ def load_library():
         "bbg_srs_num_points": (sz, [vp]),
         "bbg_srs_read": (cint, [vp, sz, sz, vp]),
         "bbg_srs_free": (None, [vp]),
+        "bbg_srs_retain": (cint, [vp]),
         "bbg_msm": (cint, [vp, vp, vp, sz, sz, vp]),
         "bbg_msm_device": (cint, [vp, vp, vp, sz, sz, vp]),
         "bbg_g1_sum": (cint, [vp, vp, sz, vp]),
@@ -136,7 +137,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
-    "bbg_srs_free", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device", "bbg_permutation_grand_product_device", "bbg_poly_evaluate", "bbg_kate_opening",
+    "bbg_srs_free", "bbg_srs_retain", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device", "bbg_permutation_grand_product_device", "bbg_poly_evaluate", "bbg_kate_opening",
     "bbg_divide_by_pseudo_vanishing",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",

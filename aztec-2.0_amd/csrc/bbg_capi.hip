@@ -234,11 +234,13 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     }
     if (!strcmp(key, "msm_sort")) {
         if (value != 0 && value != 1) { set_error("msm_sort must be 0 or 1"); return BBG_E_INVALID; }
+#ifndef BBG_ROCPRIM_SORT
+        if (value == 0) { set_error("msm_sort = 0 (rocPRIM radix sort, A/B only) needs a library built with `make ROCPRIM_SORT=1`"); return BBG_E_INVALID; }
+#endif
         BBG_HIP(hipDeviceSynchronize());
         ctx->msm_sort = (int)value;
         return BBG_OK;
     }
-    if (!strcmp(key, "msm_debug_idx_mask")) return msm_debug_idx_mask((uint32_t)value);
     if (!strcmp(key, "ntt_tile_log")) {
         if (value < 9 || value > 12) { set_error("ntt_tile_log must be 9..12"); return BBG_E_INVALID; }
         ctx->ntt_tile_log = (int)value;
@@ -603,9 +605,17 @@ int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points)
     return BBG_OK;
 }
 
+int bbg_srs_retain(bbg_srs* srs)
+{
+    if (!srs) { set_error("bbg_srs_retain: null handle"); return BBG_E_INVALID; }
+    srs->refs.fetch_add(1);
+    return BBG_OK;
+}
+
 void bbg_srs_free(bbg_srs* srs)
 {
     if (!srs) return;
+    if (srs->refs.fetch_sub(1) > 1) return; // another owner (a bbg_prover, a second cache entry) still uses it
     (void)hipSetDevice(srs->s.device); // the handle's own record: the context may already be gone (bbg_destroy before bbg_srs_free)
     (void)hipDeviceSynchronize();
     if (srs->s.table16) (void)hipFree(srs->s.table16);

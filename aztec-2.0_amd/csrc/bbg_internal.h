@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -121,6 +122,9 @@ struct bbg_ctx {
 struct bbg_srs {
     bbg::Srs s;
     bbg_ctx* ctx = nullptr;
+    // owners of the handle: the creator plus every bbg_prover built on it (bbg_srs_retain); bbg_srs_free drops one and releases the device
+    // memory with the last -- a cache that replaces an entry (shim/bbg_barretenberg_shim.cpp) cannot pull the SRS from under a live prover
+    std::atomic<int> refs{ 1 };
 };
 
 namespace bbg {
@@ -169,7 +173,6 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
             hipStream_t stream, const void* h_scalars = nullptr);
 int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
 int msm_join(bbg_ctx* ctx, hipStream_t stream);
-int msm_debug_idx_mask(uint32_t mask);
 int srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, void* d_points, hipStream_t stream);
 int g1_sum_device(bbg_ctx* ctx, const void* d_jacs, size_t n, void* d_out, hipStream_t stream);
 } // namespace bbg

@@ -29,7 +29,9 @@
 #include "curve_quad.hip.h"
 
 #include <cstring>
+#ifdef BBG_ROCPRIM_SORT // A/B build only (make ROCPRIM_SORT=1): k_recode + rocPRIM radix sort + k_offsets instead of the partition sort
 #include <rocprim/device/device_radix_sort.hpp>
+#endif
 
 namespace bbg {
 
@@ -208,6 +210,7 @@ __device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, si
         signs |= neg << w;
     }
 }
+#ifdef BBG_ROCPRIM_SORT
 template <int C>
 __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* keys, uint32_t* vals)
 {
@@ -221,6 +224,8 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, 
         vals[(size_t)w * n + i] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
     }
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------- fused recode + two-level partition sort
 // Replaces k_recode + the 2-pass library radix sort + k_offsets (0.42 ms at 2^20) with an MSD partition that exploits what
@@ -513,6 +518,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     }
 }
 
+#ifdef BBG_ROCPRIM_SORT
 // offsets[b] = first sorted position with key >= b, for b = 0 .. MSM_BUCKETS + 1
 template <int C> __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint32_t* offsets)
 {
@@ -534,6 +540,8 @@ template <int C> __global__ void k_offsets(const uint32_t* __restrict__ keys, si
     }
 }
 
+#endif
+
 // ---------------------------------------------------------------------------------- bucket accumulation
 // Load-balanced: the sorted entry array (without the key-0 prefix) is cut into segments of MSM_SEG entries, one lane
 // per segment, regardless of bucket boundaries -- every lane does the same number of mixed additions (a per-bucket
@@ -547,10 +555,9 @@ template <int C> __global__ void k_offsets(const uint32_t* __restrict__ keys, si
 constexpr uint32_t MSM_SEG_MIN = 8, MSM_SEG_DEFAULT = 64; // segment length is chosen per call (msm_seg_len)
 constexpr int MSM_LONG_SPAN = 48; // buckets spanning more lanes than this are summed by a whole block
 
-__device__ uint32_t g_debug_idx_mask = 0xffffffffu; // experiments only: confine the gathers to a cache-resident subset
 __device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ table, size_t n_srs, uint32_t v)
 {
-    return aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1) & g_debug_idx_mask));
+    return aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
 }
 
 template <int C> __global__ void __launch_bounds__(256)
@@ -1070,11 +1077,15 @@ template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L
     L.seg = msm_seg_len(L.entries, K::buckets);
     L.lanes = (L.entries + L.seg - 1) / L.seg;
     size_t tmp = 0;
+#ifdef BBG_ROCPRIM_SORT
     if (library_sort) { // only the A/B path (msm_sort = 0) needs rocPRIM's temporary storage: the default path neither queries nor reserves it
         rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)C);
         if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs(size query)", __FILE__, __LINE__);
     }
+#else
+    (void)library_sort;
+#endif
     L.sort_bytes = tmp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -1241,6 +1252,7 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
         }
         svals = vals0;
     } else {
+#ifdef BBG_ROCPRIM_SORT
         {
             ProfScope ps(ctx, "msm_recode", st);
             hipLaunchKernelGGL(k_recode<C>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
@@ -1258,6 +1270,10 @@ static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const vo
             ProfScope ps(ctx, "msm_offsets", st);
             hipLaunchKernelGGL(k_offsets<C>, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
         }
+#else
+        set_error("msm_sort = 0 needs a library built with ROCPRIM_SORT=1");
+        return BBG_E_INVALID;
+#endif
     }
     {
         ProfScope ps(ctx, "msm_accumulate", st);
@@ -1346,11 +1362,6 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
 }
 
 // makes the context stream wait for every reduce phase queued on the auxiliary stream (no host sync)
-int msm_debug_idx_mask(uint32_t mask)
-{
-    BBG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_debug_idx_mask), &mask, 4));
-    return BBG_OK;
-}
 int msm_join(bbg_ctx* ctx, hipStream_t st)
 {
     for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++)

@@ -83,11 +83,20 @@ void free_srs(bbg_multi* m)
 }
 int ensure_ntt_buffers(bbg_multi* m, size_t bytes)
 {
+    bool grow = false;
+    for (int g = 0; g < m->G; g++) grow = grow || m->ntt_bytes[(size_t)g] < bytes;
+    if (!grow) return BBG_OK;
+    // bbg_multi_ntt_device is asynchronous: peer copies queued by OTHER devices' streams for a transform still in flight target this
+    // context's d_recv, so every device of the group is drained before any buffer is released (a growth happens once per size)
+    for (int g = 0; g < m->G; g++) {
+        int rc = set_dev(m->ctx[(size_t)g]);
+        if (rc) return rc;
+        BBG_HIP(hipDeviceSynchronize());
+    }
     for (int g = 0; g < m->G; g++) {
         if (m->ntt_bytes[(size_t)g] >= bytes) continue;
         int rc = set_dev(m->ctx[(size_t)g]);
         if (rc) return rc;
-        BBG_HIP(hipDeviceSynchronize());
         for (void** b : { &m->d_x[(size_t)g], &m->d_recv[(size_t)g], &m->d_out[(size_t)g] }) {
             if (*b) BBG_HIP(hipFree(*b));
             *b = nullptr;

@@ -475,9 +475,17 @@ int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src,
     if (it != ctx->dpv_consts.end()) {
         dc = (DpvConsts*)it->second;
     } else {
+        // built on the stream of THIS call and completed before the pointer is published: a later call on any other stream can use the
+        // cached constants without an ordering of its own, and a failed set-up leaves no entry behind (one-off, once per key)
         BBG_HIP(hipMalloc((void**)&dc, sizeof(DpvConsts)));
-        ctx->dpv_consts[key] = dc;
         hipLaunchKernelGGL(k_dpv_setup, dim3(1), dim3(64), 0, st, dc, (const DomainConsts*)csrc, (const DomainConsts*)cext, (int)log2_src, ext, (int)roots_cut);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            (void)hipFree(dc);
+            return hip_fail(e, "k_dpv_setup", __FILE__, __LINE__);
+        }
+        ctx->dpv_consts[key] = dc;
     }
     hipLaunchKernelGGL(k_dpv_apply, dim3(grid_for((n + PV_E - 1) / PV_E, 256)), dim3(256), 0, st, (Fr*)d_evals, n, dc, (const DomainConsts*)ctgt, ext - 1,
                        (int)roots_cut);

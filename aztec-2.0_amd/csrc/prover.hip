@@ -53,7 +53,8 @@ constexpr size_t PIN_AFFINE = 0, PIN_EVAL = 2048, PIN_BLIND = 3072, PIN_BYTES = 
 
 struct bbg_prover {
     bbg_ctx* ctx = nullptr;
-    bbg_srs* srs = nullptr;
+    bbg_srs* srs = nullptr; // retained (bbg_srs_retain) for the lifetime of the handle
+    int device = 0;
     unsigned log2n = 0;
     int width = 4;
     int flavour = BBG_FLAVOUR_TURBO;
@@ -64,6 +65,12 @@ struct bbg_prover {
     void* key_coeff[BBG_QP_EXT_COUNT] = {}; // indexed by key_slot(id)
     void* key_coset[BBG_QP_EXT_COUNT] = {};
     void* sigma_lagrange[4] = {};
+    // generation of the coefficient form each slot holds, and the generation the other forms were derived from (or supplied at): a form
+    // older than its coefficients is stale and finalize re-derives it in place -- re-registering a selector on a live handle replaces
+    // EVERY form of it (bbg.h), not only the one rounds 5 / 6 read
+    unsigned coeff_gen[BBG_QP_EXT_COUNT] = {};
+    unsigned coset_gen[BBG_QP_EXT_COUNT] = {};
+    unsigned sigma_lagrange_gen[4] = {};
     bool key_final = false;
     // per proof
     void* wire_lagrange[4] = {};
@@ -180,6 +187,10 @@ int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int fl
     const int program_width = flavour == BBG_FLAVOUR_TURBO ? 4 : 3;
     if (log2n < 3 || log2n > 26) { set_error("bbg_prover_create: need 3 <= log2n <= 26 (the quotient lives on the 4n domain)"); return BBG_E_INVALID; }
     const size_t n = (size_t)1 << log2n;
+    if (srs->s.device != ctx->device) {
+        set_error("bbg_prover_create: the SRS lives on another device than the context (register it on this context)");
+        return BBG_E_INVALID;
+    }
     if (srs->s.n < n + (program_width == 3 ? 1 : 0)) {
         set_error("bbg_prover_create: the SRS needs n points (n + 1 for StandardPLONK: t_high has n + 1 coefficients)");
         return BBG_E_INVALID;
@@ -188,6 +199,8 @@ int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int fl
     bbg_prover* p = new bbg_prover;
     p->ctx = ctx;
     p->srs = srs;
+    srs->refs.fetch_add(1); // released in bbg_prover_destroy
+    p->device = ctx->device;
     p->log2n = log2n;
     p->width = program_width;
     p->flavour = flavour;
@@ -226,9 +239,10 @@ int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int fl
 void bbg_prover_destroy(bbg_prover* p)
 {
     if (!p) return;
-    (void)hipSetDevice(p->srs ? p->srs->s.device : 0);
+    (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     for (void* a : p->allocs) (void)hipFree(a);
+    if (p->srs) bbg_srs_free(p->srs);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     for (int k = 0; k < 4; k++)
@@ -256,6 +270,9 @@ int bbg_prover_set_key_poly(bbg_prover* p, int id, int form, const uint64_t* val
     }
     BBG_HIP(hipMemcpyAsync(*slot, values, count * 32, hipMemcpyHostToDevice, p->ctx->stream));
     BBG_HIP(hipStreamSynchronize(p->ctx->stream)); // the caller's array may go away as soon as this returns
+    if (form == BBG_FORM_COEFF) p->coeff_gen[ks]++;                                              // every other form of this id is now stale
+    else if (form == BBG_FORM_COSET) p->coset_gen[ks] = p->coeff_gen[ks];                        // supplied for the current coefficients
+    else p->sigma_lagrange_gen[id - BBG_QP_SIGMA_1] = p->coeff_gen[ks];
     p->key_final = false;
     return BBG_OK;
 }
@@ -269,15 +286,18 @@ int bbg_prover_finalize_key(bbg_prover* p)
     int rc = BBG_OK;
     for (int id = BBG_QP_SIGMA_1; id < BBG_QP_EXT_COUNT && !rc; id++) { // slots: the widget table's indices
         if (id == BBG_QP_LAGRANGE_1 || !p->key_coeff[id]) continue;
-        if (!p->key_coset[id]) { // coefficient form -> values on the 4n coset (what compute_proving_key's selector FFTs hold)
-            rc = dev_alloc(p, &p->key_coset[id], 4 * n * 32);
+        if (!p->key_coset[id] || p->coset_gen[id] != p->coeff_gen[id]) { // coefficient form -> values on the 4n coset (compute_proving_key's selector FFTs)
+            if (!p->key_coset[id]) rc = dev_alloc(p, &p->key_coset[id], 4 * n * 32);
             if (!rc) rc = to_coset(p, p->key_coeff[id], p->key_coset[id], st);
+            if (!rc) p->coset_gen[id] = p->coeff_gen[id];
         }
-        if (!rc && id <= BBG_QP_SIGMA_4 && !p->sigma_lagrange[id - BBG_QP_SIGMA_1]) { // sigma in Lagrange base, read by the grand product
+        if (!rc && id <= BBG_QP_SIGMA_4 &&
+            (!p->sigma_lagrange[id - BBG_QP_SIGMA_1] || p->sigma_lagrange_gen[id - BBG_QP_SIGMA_1] != p->coeff_gen[id])) { // sigma in Lagrange base, read by the grand product
             void** slot = &p->sigma_lagrange[id - BBG_QP_SIGMA_1];
-            rc = dev_alloc(p, slot, n * 32);
+            if (!*slot) rc = dev_alloc(p, slot, n * 32);
             if (!rc) BBG_HIP(hipMemcpyAsync(*slot, p->key_coeff[id], n * 32, hipMemcpyDeviceToDevice, st));
             if (!rc) rc = ntt_run(p->ctx, *slot, p->log2n, BBG_FFT, 0, nullptr, st);
+            if (!rc) p->sigma_lagrange_gen[id - BBG_QP_SIGMA_1] = p->coeff_gen[id];
         }
     }
     if (!rc && !p->key_coset[BBG_QP_LAGRANGE_1]) {
@@ -411,6 +431,7 @@ int bbg_prover_evaluate(bbg_prover* p, size_t count, const int* ids, const int* 
 {
     CHECK_P(p);
     if (!ids || !zeta || !out || count == 0 || count > 32) { set_error("bbg_prover_evaluate: bad argument (1..32 evaluations per call)"); return BBG_E_INVALID; }
+    if (p->stage < 4) { set_error("bbg_prover_evaluate: round 4 has not run for this proof (wires / z / quotient are not this proof's yet)"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
     hipStream_t st = p->ctx->stream;
     const void* ptrs[32];

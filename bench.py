@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip extra.config5 (one 2^24 MSM + one 2^24 coset NTT, strong scaling)")
     ap.add_argument("--no-prover-shaped", action="store_true", help="skip extra.prover_shaped (BASELINE config 4 on the resident prover rounds)")
     ap.add_argument("--config5-log2n", type=int, default=24)
+    ap.add_argument("--no-sweeps", action="store_true", help="skip extra.host_path / extra.ntt_sweep / extra.msm_sweep (SURVEY 8d tables)")
     ap.add_argument("--reduce-priority", type=int, default=-1, help="A/B: 1 = low-priority auxiliary stream for the MSM reduce phase (library default), 0 = normal")
     ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, 16 or 20 (A/B runs)")
     args = ap.parse_args()
@@ -307,6 +308,12 @@ def main():
                 out["cpu_baseline"]["prover_shaped_ms"] = ref_ms
                 extra["prover_shaped"]["reference_same_sequence_ms"] = ref_ms["total_ms"]
                 extra["prover_shaped"]["speedup_vs_reference_sequence"] = round(ref_ms["total_ms"] / extra["prover_shaped"]["proof_ms"], 1)
+    extra["step_issue_floor"] = step_issue_floor()
+    if extra["step_issue_floor"]:
+        extra["step_issue_floor_ms"] = extra["step_issue_floor"]["ms"]
+    # ---- the PCIe-inclusive drop-in entry points (host buffers in / out), one GPU
+    if rank == 0 and world == 1 and not args.no_sweeps and not stuck:
+        extra["host_path"] = guarded("host_path", lambda: host_path(pkg, bbg, srs, lg), 120)
     # ---- BASELINE config 5: ONE 2^24 MSM + ONE 2^24 coset NTT over the N GPUs (strong scaling: total work fixed as N grows)
     if not args.no_config5 and not stuck:
         srs.free()
@@ -314,6 +321,14 @@ def main():
         c5 = guarded("config5", lambda: config5(pkg, par, bbg, dist, dev, rank, world, args.config5_log2n), 300)
         if rank == 0:
             extra["config5"] = c5
+    # ---- BASELINE config 2 / 3 across sizes (isolated, one GPU)
+    if rank == 0 and world == 1 and not args.no_sweeps and not stuck:
+        if srs is not None:
+            srs.free()
+            srs = None
+        extra["ntt_sweep"] = guarded("ntt_sweep", lambda: ntt_sweep(pkg, bbg, dev), 120)
+        if not stuck:
+            extra["msm_sweep"] = guarded("msm_sweep", lambda: msm_sweep(pkg, bbg, dev), 180)
     if rank == 0:
         sys.stdout.flush()
         os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())
@@ -326,26 +341,164 @@ def main():
         dist.destroy_process_group()
 
 
+def step_issue_floor():
+    """Sum of SQ_INSTS_VALU over every kernel of ONE step (committed PMC pass of this same bench command) / the chip's VALU issue peak:
+    the time the step's instruction stream needs if every SIMD issued a VALU instruction every 4 clocks."""
+    import re
+    try:
+        lines = open(PMC_PROFILE).read().splitlines()
+    except OSError:
+        return None
+    m = re.search(r"--steps (\d+) --warmup (\d+)", lines[0]) if lines else None
+    launches = (int(m.group(1)) + int(m.group(2))) if m else 4
+    tot, per_kernel = 0.0, {}
+    for line in lines:
+        f = line.split()
+        if len(f) >= 4 and f[-3] == "SQ_INSTS_VALU" and int(f[-2]) >= launches:
+            k = " ".join(f[:-3]).replace("void bbg::", "").replace("bbg::", "")
+            v = float(f[-1]) * int(f[-2]) / launches
+            per_kernel[k] = round(v / 1e6, 2)
+            tot += v
+    if not tot:
+        return None
+    return {"ms": round(tot / (VALU_PEAK_GWAVE * 1e9) * 1e3, 4), "valu_wave_insts_per_step_M": round(tot / 1e6, 1),
+            "per_kernel_M": per_kernel, "peak_G_per_s": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE)}
+
+
+def host_path(pkg, bbg, srs, lg, reps=11):
+    """SURVEY 8(d) drop-in timing: the host-buffer entry points the link-time shim calls (scalars / coefficients in pageable host memory
+    in, result in host memory out: PCIe-inclusive), median of `reps` wall-clock calls.  Never `value`."""
+    import ctypes
+    n = 1 << lg
+    lib, vp = bbg.lib, ctypes.c_void_p
+    hs = pkg.synthetic_scalars(SEED + 3, n)
+    hc = pkg.synthetic_scalars(SEED + 100 + lg, n)
+    out = np.zeros(12, dtype=np.uint64)
+    big = np.zeros((4 * n + 4, 4), dtype=np.uint64)
+
+    def med(fn, k=reps):
+        fn()
+        ts = []
+        for _ in range(k):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+    bbg.set_option("msm_async_reduce", 0)
+    try:
+        r = {"n": "2^%d" % lg, "reps": reps, "timing": "wall clock around the blocking C-ABI call, median",
+             "bbg_msm_ms": med(lambda: bbg._ck(lib.bbg_msm(bbg.ctx, srs.handle, vp(hs.ctypes.data), 0, n, vp(out.ctypes.data)))),
+             "bbg_ntt_ifft_ms": med(lambda: bbg._ck(lib.bbg_ntt(bbg.ctx, vp(hc.ctypes.data), lg, 1, 0, None))),
+             "bbg_coset_fft_extend_4n_ms": med(lambda: bbg._ck(lib.bbg_coset_fft_extend(bbg.ctx, vp(hc.ctypes.data), lg, lg + 2, vp(big.ctypes.data))), 7)}
+    finally:
+        bbg.set_option("msm_async_reduce", 1)
+    r["msm_mscalar_per_s"] = round(n / r["bbg_msm_ms"] / 1e3, 1)
+    return r
+
+
+def ntt_sweep(pkg, bbg, dev, sizes=(18, 19, 20, 21, 22, 23, 24)):
+    """BASELINE config 2: fft / ifft / coset_fft / coset_ifft, device resident, in place, ISOLATED (nothing else on the GPU).  Method (the one
+    every isolated NTT figure in README / DESIGN uses): HIP events on the launch stream around a burst of back-to-back transforms, best of 3
+    bursts, ms per transform."""
+    import torch
+    rows = {}
+    for lg in sizes:
+        n = 1 << lg
+        a = torch.from_numpy(pkg.synthetic_scalars(11, n).view(np.int64).reshape(-1)).to(dev)
+        bbg.ntt_prepare(lg)
+        burst = 50 if lg <= 21 else 12
+        row = []
+        for op in (0, 1, 2, 3):
+            for _ in range(3):
+                bbg.ntt_device(a.data_ptr(), lg, op)
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(burst):
+                    bbg.ntt_device(a.data_ptr(), lg, op)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / burst)
+            row.append(round(best, 4))
+        rows["2^%d" % lg] = {"fft_ms": row[0], "ifft_ms": row[1], "coset_fft_ms": row[2], "coset_ifft_ms": row[3],
+                             "fft_gfield_ops_per_s": round(1.5 * n * lg / row[0] / 1e6, 1), "fft_hbm_frac_64n": round(64.0 * n / (row[0] * 1e-3) / 8e12, 4)}
+        del a
+    return {"method": "HIP events around a burst of back-to-back in-place transforms (50; 12 from 2^22), best of 3 bursts; isolated, device resident", "sizes": rows}
+
+
+def msm_sweep(pkg, bbg, dev, sizes=(16, 20, 22, 24)):
+    """BASELINE config 3 across sizes: n scalars over an n-point hashed SRS (window tables resident), device-resident scalars.
+    standalone = one call + synchronise (wall clock, median of 7); pipelined = a burst of calls with the reduce phase of call i overlapping
+    call i+1 (msm_async_reduce), per call."""
+    import torch
+    rows = {}
+    out = torch.zeros(12, dtype=torch.int64, device=dev)
+    for lg in sizes:
+        n = 1 << lg
+        srs = bbg.srs_synth_hashed(SEED, n)
+        sc = torch.from_numpy(pkg.synthetic_scalars(SEED + 3, n).view(np.int64).reshape(-1)).to(dev)
+
+        def med(fn, reps):
+            fn()
+            bbg.join(); bbg.sync()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                bbg.join(); bbg.sync()
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2] * 1e3
+        bbg.set_option("msm_async_reduce", 0)
+        sa = med(lambda: bbg.msm_device(srs, sc.data_ptr(), n, out.data_ptr()), 7)
+        bbg.set_option("msm_async_reduce", 1)
+        burst = 16 if lg <= 20 else 4
+
+        def run_burst():
+            for _ in range(burst):
+                bbg.msm_device(srs, sc.data_ptr(), n, out.data_ptr())
+        pl = med(run_burst, 5) / burst
+        rows["2^%d" % lg] = {"standalone_ms": round(sa, 3), "pipelined_ms": round(pl, 3), "mscalar_per_s_pipelined": round(n / pl / 1e3, 1)}
+        srs.free()
+        del sc
+    return {"method": "wall clock, device-resident scalars; standalone = call + sync (median of 7), pipelined = burst of 16 (4 from 2^22) calls, per call (median of 5)",
+            "sizes": rows}
+
+
 def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
     """One 2^lg MSM (point-range shards, all-gather of the 96-byte partials + group sum) and one 2^lg coset NTT (residue-class
-    shards, one all-to-all, size-N DFT) over the N ranks; inputs resident; max over ranks; best of `steps`."""
+    shards, one all-to-all, size-N DFT) over the N ranks; inputs resident; max over ranks; best of `steps`.
+
+    Self-checking: the inputs are the seeded ones of tests/golden/msm24.json (hashed SRS 0xBB254, synthetic_scalars(0xBB254 + 24))
+    and tests/golden/ntt_large.json (synthetic_scalars(900 + lg), op coset_fft), both recorded from the compiled REFERENCE, so at
+    lg = 24 rank 0 compares the group sum with the reference's 2^24 result and the SHA-256 of the gathered, canonicalised transform
+    with the reference's digest: `bit_exact_vs_reference`.  Only committed fixture DATA is read; nothing under oracle/ is used."""
+    import hashlib
     import torch
     n = 1 << lg
+    golden_dir = os.path.join(ROOT, "tests", "golden")
+    want_msm = want_ntt = None
+    try:
+        g24 = json.load(open(os.path.join(golden_dir, "msm24.json")))
+        if g24["log2n"] == lg:
+            want_msm = np.frombuffer(bytes.fromhex(g24["result"]), dtype=np.uint64)
+        for rec in json.load(open(os.path.join(golden_dir, "ntt_large.json")))["ntt"]:
+            if rec["log2n"] == lg and rec["op"] == 2 and rec["generator_size"] == 0:
+                want_ntt = rec["sha256"]
+    except (OSError, KeyError, ValueError):
+        pass
     start, count = par.shard_range(n, rank, world)
     srs = bbg.srs_synth_hashed(SEED + start, count)
-    mask = torch.tensor([-1, -1, -1, 0x0FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(SEED + 24 + rank)
-    d_scalars = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device=dev, generator=gen) & mask
+    d_scalars = torch.from_numpy(pkg.synthetic_scalars(SEED + 24, count, start).view(np.int64).reshape(-1)).to(dev)
     m = n // world
-    d_x = torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, device=dev, generator=gen) & mask
-    d_scalars, d_x = d_scalars.reshape(-1), d_x.reshape(-1)
+    d_x = torch.from_numpy(pkg.synthetic_scalars_strided(900 + lg, m, rank, world).view(np.int64).reshape(-1)).to(dev)
     pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev))
     ops = par.BbgNttOps(bbg)
     five = np.array([[5, 0, 0, 0]], dtype=np.uint64)
     shift = bbg.field_op(0, 5, five)[0]  # the coset generator 5 in Montgomery form (fr.hpp:44-59)
     bbg.ntt_prepare(lg - (world.bit_length() - 1))
     work = d_x.clone()
+    last = {}
 
     def fence():
         if dist is not None:
@@ -355,14 +508,15 @@ def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
     def msm_step():
         pipe.count = 0
         pipe.submit(d_scalars, count)
-        pipe.flush()
+        last["msm"] = pipe.flush()
 
     def ntt_step():
         work.copy_(d_x)
         if world > 1:
-            par.ntt_sharded(ops, dist, work, lg, coset_shift=shift)
+            last["ntt"] = par.ntt_sharded(ops, dist, work, lg, coset_shift=shift)
         else:
             bbg.ntt_device(work.data_ptr(), lg, 2)
+            last["ntt"] = work
 
     def best(fn):
         fn()
@@ -382,12 +536,34 @@ def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
         return min(ts)
 
     t_msm, t_ntt = best(msm_step), best(ntt_step)
+    # ---- self-check against the reference's recorded results (after the timed region)
+    check = {"msm": None, "ntt": None, "source": "tests/golden/msm24.json, tests/golden/ntt_large.json (compiled reference)"}
+    if want_msm is not None:
+        jac = last["msm"].cpu().numpy().view(np.uint64).reshape(1, 12)
+        if rank == 0:
+            check["msm"] = bool(np.array_equal(bbg.g1_normalize(jac).reshape(-1), want_msm))
+    if want_ntt is not None:
+        mine = last["ntt"]
+        if world > 1:
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+        else:
+            parts = [mine]
+        if rank == 0:
+            # rank g holds out[t*(m/G) + q] = A[(g*m/G + q) + m*t]  (parallel.ntt_sharded)
+            lenq = m // world
+            nat = np.empty((n, 4), dtype=np.uint64)
+            for g, part in enumerate(parts):
+                o = part.cpu().numpy().view(np.uint64).reshape(world, lenq, 4)
+                for t in range(world):
+                    nat[t * m + g * lenq: t * m + (g + 1) * lenq] = o[t]
+            check["ntt"] = hashlib.sha256(pkg.fr_reduce_once(nat).tobytes()).hexdigest() == want_ntt
     srs.free()
     return {"workload": "ONE 2^%d-point MSM + ONE 2^%d coset NTT over %d GPU(s), strong scaling (north_star's split: point-range MSM shards + "
                         "all-gather of 96-B partials; residue-class NTT shards + one all-to-all)" % (lg, lg, world),
             "n_gpus": world, "msm_ms": round(t_msm * 1e3, 3), "msm_mscalar_per_s": round(n / t_msm / 1e6, 2),
             "ntt_ms": round(t_ntt * 1e3, 3), "ntt_gfield_ops_per_s": round(1.5 * n * lg / t_ntt / 1e9, 2),
-            "ntt_includes_input_restore_copy": True,
+            "ntt_includes_input_restore_copy": True, "bit_exact_vs_reference": check,
             "exchange": {"msm": "all_gather %d x 96 B" % world, "ntt": "all_to_all %.1f MiB per rank" % (32.0 * m * (world - 1) / world / 2**20)}}
 
 

@@ -89,6 +89,9 @@ int bbg_transcript_checksum(const void* data, size_t len, uint8_t out[64]);
 size_t bbg_srs_num_points(const bbg_srs* srs);
 /* Copies points [from, from+count) back to the host (64-byte Montgomery affine each). */
 int bbg_srs_read(bbg_srs* srs, size_t from, size_t count, uint64_t* out_points);
+/* Shared ownership: bbg_srs_retain adds an owner, bbg_srs_free drops one; the device memory goes with the last owner.  bbg_prover_create
+ * retains the SRS it is given (and bbg_prover_destroy releases it), so freeing or replacing a cached SRS never invalidates a live prover. */
+int bbg_srs_retain(bbg_srs* srs);
 void bbg_srs_free(bbg_srs* srs);
 
 /* ---- MSM: replaces scalar_multiplication::pippenger / pippenger_unsafe

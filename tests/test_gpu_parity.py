@@ -14,6 +14,7 @@ import callback_engines  # tests/tools: Python stand-ins for work-queue callback
 pytestmark = pytest.mark.gpu
 
 FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
+MSM_WINDOWS = (16, 20)  # every window width libbbg.so compiles (option msm_window)
 
 
 # ---------------------------------------------------------------------------------------------- fields
@@ -161,14 +162,46 @@ def test_fft_matches_horner(pkg, oracle, bbg):
         z = oracle.fe_mul(0, z, w)[0]
 
 
-@pytest.mark.parametrize("lg", [18, 20, 21, 22, 24])
-def test_ntt_full_size_properties(pkg, oracle, bbg, lg):
-    """BASELINE config 2 sizes: round trips (basic_fft / fft_coset_ifft_consistency, polynomial_arithmetic.test.cpp:70-134),
-    linearity, and the n / 2n cross-domain consistency of :136-177, all bit-exact on canonical values."""
+def _ntt_large_golden():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ntt_large.json")) as f:
+        return json.load(f)["ntt"]
+
+
+@pytest.mark.parametrize("lg", [18, 19, 20, 21, 22, 23, 24])
+def test_ntt_full_size_properties(pkg, oracle, bbg, golden, lg):
+    """BASELINE config 2 sizes.  (i) REFERENCE digests of fft / ifft / coset_fft / coset_ifft (polynomial_arithmetic.cpp:374-410;
+    tests/golden/ntt_large.json for 2^19, 2^21..2^24, golden.json for 2^18 / 2^20), for every tile plan the size can take (2^21 / 2^22:
+    4096-element tiles in two passes and 2048-element tiles in three); (ii) round trips (basic_fft / fft_coset_ifft_consistency,
+    polynomial_arithmetic.test.cpp:70-134); (iii) Horner spot values at omega^i; (iv) linearity.  All bit-exact on canonical values."""
     import torch
     n = 1 << lg
     a = pkg.synthetic_scalars(900 + lg, n)
     ta = torch.from_numpy(a.view(np.int64)).cuda()
+
+    def run(op, src=ta):
+        work = src.clone()
+        bbg.ntt_device(work.data_ptr(), lg, op)
+        bbg.sync()
+        return oracle.canon(0, work.cpu().numpy().view(np.uint64))
+    recs = [r for r in _ntt_large_golden() if r["log2n"] == lg]
+    if recs:
+        assert sorted(r["op"] for r in recs) == [0, 1, 2, 3]
+        for big in ((0, 2) if lg in (21, 22) else (1,)):
+            bbg.set_option("ntt_big_tile", big)
+            try:
+                for rec in recs:
+                    out = run(rec["op"])
+                    for i, want in rec["spots"].items():
+                        assert np.array_equal(out[int(i)], unhex(want)[0]), (lg, rec["op"], big, "spot", i)
+                    assert sha(out) == rec["sha256"], (lg, rec["op"], big)
+            finally:
+                bbg.set_option("ntt_big_tile", 1)
+    else:  # 2^18 / 2^20: the reference digests live in golden.json, recorded over its own seeds
+        grecs = [r for r in golden["ntt"] if r["log2n"] == lg and r["op"] < 4 and r["generator_size"] == 0]
+        assert sorted(r["op"] for r in grecs) == [0, 1, 2, 3]
+        for rec in grecs:
+            c = torch.from_numpy(pkg.synthetic_scalars(rec["seed"], n).view(np.int64)).cuda()
+            assert sha(run(rec["op"], c)) == rec["sha256"], (lg, rec["op"])
     work = ta.clone()
     bbg.ntt_device(work.data_ptr(), lg, FFT)
     bbg.ntt_device(work.data_ptr(), lg, IFFT)
@@ -181,22 +214,18 @@ def test_ntt_full_size_properties(pkg, oracle, bbg, lg):
     bbg.sync()
     assert np.array_equal(oracle.canon(0, work.cpu().numpy().view(np.uint64)), oracle.canon(0, a)), "coset round trip"
     # spot values against Horner evaluation at omega^i (ordering + root choice at full size)
-    work = ta.clone()
-    bbg.ntt_device(work.data_ptr(), lg, FFT)
-    bbg.sync()
-    out = oracle.canon(0, work.cpu().numpy().view(np.uint64))
-    if lg <= 20:
-        w = oracle.root_of_unity(lg)
-        for i in (0, 1, 5, n // 2 + 3, n - 1):
-            # omega^i by square-and-multiply on the oracle side
-            z = oracle.to_mont(0, np.array([1, 0, 0, 0], dtype=np.uint64))[0]
-            base, e = w, i
-            while e:
-                if e & 1:
-                    z = oracle.fe_mul(0, z, base)[0]
-                base = oracle.fe_mul(0, base, base)[0]
-                e >>= 1
-            assert np.array_equal(oracle.poly_eval(a, z), out[i]), i
+    out = run(FFT)
+    w = oracle.root_of_unity(lg)
+    for i in (0, 1, 5, n // 2 + 3, n - 1):
+        # omega^i by square-and-multiply on the oracle side
+        z = oracle.to_mont(0, np.array([1, 0, 0, 0], dtype=np.uint64))[0]
+        base, e = w, i
+        while e:
+            if e & 1:
+                z = oracle.fe_mul(0, z, base)[0]
+            base = oracle.fe_mul(0, base, base)[0]
+            e >>= 1
+        assert np.array_equal(oracle.poly_eval(a, z), out[i]), i
     # linearity: fft(a + b) = fft(a) + fft(b)
     b = pkg.synthetic_scalars(1900 + lg, n)
     s = oracle.fe_add(0, a, b)
@@ -351,26 +380,39 @@ def test_msm_edge_cases(pkg, oracle, bbg, golden, srs16):
         bbg.msm(srs16, sc, start=(1 << 16) - 10)  # range exceeds the SRS
 
 
-def test_msm_sort_paths_agree(pkg, oracle, bbg, srs16):
-    """The fused recode + partition sort (msm_sort=1, default) and the rocPRIM radix-sort path (msm_sort=0) feed the same
-    accumulation; results must be identical on uniform, sparse and heavily skewed digit distributions."""
+def _library_sort_available(pkg, bbg):
+    """msm_sort = 0 (k_recode + rocPRIM radix sort + k_offsets) exists only in A/B builds (make ROCPRIM_SORT=1)."""
+    try:
+        bbg.set_option("msm_sort", 0)
+    except pkg.BbgError as e:
+        assert "ROCPRIM_SORT" in str(e)
+        return False
+    bbg.set_option("msm_sort", 1)
+    return True
+
+
+def test_msm_window_widths_and_sort_paths_agree(pkg, oracle, bbg, srs16):
+    """Every compiled window width (each builds its own window tables on first use), and -- in A/B builds -- the rocPRIM radix-sort
+    path next to the fused recode + partition sort, feed the same accumulation; results must be identical on uniform, sparse and
+    heavily skewed digit distributions."""
     n = 1 << 16
     one = oracle.to_mont(0, np.array([[1, 0, 0, 0]], dtype=np.uint64))
     cases = {
         "uniform": pkg.synthetic_scalars(77, n),
         "mixed": pkg.inputs.mixed_scalars(78, n, lambda p: oracle.to_mont(0, p)),
         "all_one": np.tile(one, (n, 1)),                       # one bucket of one window holds everything
-        "all_equal": np.tile(pkg.synthetic_scalars(79, 1), (n, 1)),  # 16 buckets hold everything
+        "all_equal": np.tile(pkg.synthetic_scalars(79, 1), (n, 1)),  # one bucket per window holds everything
         "ragged": pkg.synthetic_scalars(80, 40001),
         "tiny": pkg.synthetic_scalars(81, 3),
     }
     pts = srs16.read(0, 3)
+    sorts = (1, 0) if _library_sort_available(pkg, bbg) else (1,)
     try:
         for name, sc in cases.items():
             got = []
-            for window in (16, 20):  # both compiled window widths (the second one builds its tables on first use)
+            for window in MSM_WINDOWS:
                 bbg.set_option("msm_window", window)
-                for sort in (1, 0):
+                for sort in sorts:
                     bbg.set_option("msm_sort", sort)
                     got.append(oracle.jac_to_affine(bbg.msm(srs16, sc)))
             for g in got[1:]:
@@ -782,24 +824,6 @@ def test_reference_prover_linked_against_shim(pkg, oracle, bbg):
     P.free()
 
 
-def test_reference_prover_resident_engine(pkg, oracle, bbg):
-    """The fastest configuration measured (profiles/r01_real_prover.txt): the shim-linked prover (inline helpers through --wrap),
-    the work queue through the callbacks, rounds 3, 4 and 6 on the device and the coset-FFT outputs kept resident for the
-    quotient (prover_engine.ResidentEngine).  The reference's TurboVerifier must accept the proof."""
-    from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
-    if not prover_available() or not os.path.exists(PROVER_GPU_SO):
-        pytest.skip("oracle/_ref/libbbprover_gpu.so absent on this machine")
-    x = oracle.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
-    pts = oracle.srs_powers(x, (2 << 13) + 1)
-    P = RefProver(1 << 13, 12, pts, x, gpu_linked=True)
-    srs = bbg.srs_register(P.monomials())
-    proof = P.prove(callback_engines.ResidentEngine(bbg, srs), check=False)  # (per-item check needs the host copies)
-    ok = P.verify()
-    assert len(proof) > 0 and ok == 1, ("resident engine", len(proof), ok, P.counts)
-    srs.free()
-    P.free()
-
-
 def test_reference_prover_round4_on_gpu(pkg, oracle, bbg):
     """execute_fourth_round's quotient (five widgets + divide_by_pseudo_vanishing_polynomial + coset_ifft, prover.cpp:304-343)
     computed on the device inside a REAL proof of the reference prover: the resulting quotient coefficients equal the
@@ -1207,8 +1231,80 @@ def test_prover_handle_error_paths(pkg, bbg):
     ids = (ctypes.c_int * 2)(0, 99)
     ev = np.zeros((2, 4), dtype=np.uint64)
     assert lib.bbg_prover_evaluate(h, 2, ids, None, ch[0].ctypes.data, ev.ctypes.data) != 0                 # unknown polynomial id
+    ids = (ctypes.c_int * 2)(0, 1)
+    assert lib.bbg_prover_evaluate(h, 2, ids, None, ch[0].ctypes.data, ev.ctypes.data) != 0                 # valid ids, but before round 4
+    assert b"round 4" in lib.bbg_last_error()
     lib.bbg_prover_destroy(h)
     srs.free()
+
+
+def _prover_rounds_1_to_4(pkg, bbg, lib, h, n, seed=0):
+    """Rounds 1, 3, 4 on synthetic wires / challenges: every commitment of the quotient path (W_i, Z, T_i) as canonical affine points."""
+    wires = [pkg.synthetic_scalars(600 + seed + k, n) for k in range(4)]
+    wp = (ctypes.c_void_p * 4)(*[w.ctypes.data for w in wires])
+    ch = pkg.synthetic_scalars(700 + seed, 8)
+    com = np.zeros((9, 12), dtype=np.uint64)
+    assert lib.bbg_prover_round1(h, wp, com.ctypes.data) == 0, lib.bbg_last_error()
+    assert lib.bbg_prover_round3(h, ch[0].ctypes.data, ch[1].ctypes.data, ch[2:5].ctypes.data, com[4:].ctypes.data) == 0, lib.bbg_last_error()
+    assert lib.bbg_prover_round4(h, ch[5].ctypes.data, ch[6].ctypes.data, com[5:].ctypes.data) == 0, lib.bbg_last_error()
+    return bbg.g1_normalize(com)
+
+
+def test_prover_key_polynomial_replaced_on_live_handle(pkg, bbg):
+    """re-registering a key polynomial in coefficient form on a finalised handle must replace EVERY derived form of it (the
+    4n coset values rounds 4 reads, sigma's Lagrange form the grand product reads), not only the coefficients rounds 5 / 6 read: the
+    commitments after `set_key_poly + finalize` equal those of a fresh handle built with the new key, and differ from the old key's."""
+    lib = bbg.lib
+    lg, n = 10, 1 << 10
+    srs = bbg.srs_synth_hashed(5, n)
+    gens = np.stack([bbg.field_op(0, 5, np.array([[k, 0, 0, 0]], dtype=np.uint64))[0] for k in (5, 5, 6, 7)])
+
+    def make(overrides):
+        h = ctypes.c_void_p()
+        assert lib.bbg_prover_create(bbg.ctx, srs.handle, lg, 4, gens.ctypes.data, ctypes.byref(h)) == 0
+        for pid in range(5, 20):
+            a = overrides.get(pid, pkg.synthetic_scalars(500 + pid, n))
+            assert lib.bbg_prover_set_key_poly(h, pid, 0, a.ctypes.data) == 0
+        assert lib.bbg_prover_finalize_key(h) == 0
+        return h
+    new_sigma, new_qm = pkg.synthetic_scalars(9001, n), pkg.synthetic_scalars(9002, n)
+    live = make({})
+    old = _prover_rounds_1_to_4(pkg, bbg, lib, live, n)
+    assert lib.bbg_prover_set_key_poly(live, 6, 0, new_sigma.ctypes.data) == 0    # sigma_2: Lagrange form (round 3) + coset form (round 4)
+    assert lib.bbg_prover_set_key_poly(live, 14, 0, new_qm.ctypes.data) == 0      # a selector: coset form (round 4)
+    wires = (ctypes.c_void_p * 4)(*[new_qm.ctypes.data] * 4)
+    scratch = np.zeros((4, 12), dtype=np.uint64)
+    assert lib.bbg_prover_round1(live, wires, scratch.ctypes.data) != 0 and b"finalize" in lib.bbg_last_error()  # a changed key must be finalised again
+    assert lib.bbg_prover_finalize_key(live) == 0
+    got = _prover_rounds_1_to_4(pkg, bbg, lib, live, n)
+    fresh = make({6: new_sigma, 14: new_qm})
+    want = _prover_rounds_1_to_4(pkg, bbg, lib, fresh, n)
+    assert np.array_equal(got, want), "stale derived key forms after re-registration"
+    assert np.array_equal(got[:4], old[:4]) and not np.array_equal(got[4], old[4]) and not np.array_equal(got[5:], old[5:])
+    lib.bbg_prover_destroy(live)
+    lib.bbg_prover_destroy(fresh)
+    srs.free()
+
+
+def test_prover_keeps_its_srs_alive(pkg, bbg):
+    """a bbg_prover shares ownership of its SRS (bbg_srs_retain): the creator freeing its handle -- what the shim's table cache
+    does when a larger table is registered at the same address -- must not pull the window tables from under the live prover."""
+    lib = bbg.lib
+    lg, n = 10, 1 << 10
+    gens = np.stack([bbg.field_op(0, 5, np.array([[k, 0, 0, 0]], dtype=np.uint64))[0] for k in (5, 5, 6, 7)])
+    srs = bbg.srs_synth_hashed(5, n)
+    h = ctypes.c_void_p()
+    assert lib.bbg_prover_create(bbg.ctx, srs.handle, lg, 4, gens.ctypes.data, ctypes.byref(h)) == 0
+    for pid in range(5, 20):
+        assert lib.bbg_prover_set_key_poly(h, pid, 0, pkg.synthetic_scalars(500 + pid, n).ctypes.data) == 0
+    assert lib.bbg_prover_finalize_key(h) == 0
+    before = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
+    srs.free()                                              # the creator lets go; the prover still owns it
+    other = bbg.srs_synth_hashed(77, 4 * n)                 # allocations in between: a freed table would be reused
+    after = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
+    assert np.array_equal(before, after)
+    lib.bbg_prover_destroy(h)                               # drops the last owner
+    other.free()
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU inside the library (SURVEY 8e)
@@ -1300,6 +1396,63 @@ def test_multi_ntt_all_to_all(pkg, oracle, bbg, G, lg):
             assert np.array_equal(oracle.canon(0, got), want), (G, lg, op, "resident form")
         with pytest.raises(pkg.BbgError):
             M.ck(M.lib.bbg_multi_ntt(M.h, a.ctypes.data, lg, 4))  # only the four whole-domain transforms
+    finally:
+        M.close()
+
+
+def test_multi_msm_2_24_eight_shards_vs_reference(pkg, oracle, bbg):
+    """BASELINE config 5's MSM through the in-library split: G = 8 contexts (one per GPU on a node; all on device 0 here), 2^21-point
+    SRS shards, bbg_multi_msm over the 2^24 scalars of tests/golden/msm24.json -- equal to the REFERENCE's own sharded composition
+    (sixteen pippenger_unsafe + g1 sum, pippenger.cpp:27-31, c_bind.cpp:31-46) -- and a (from, range) call that straddles shards."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "msm24.json")) as f:
+        G24 = json.load(f)
+    n = 1 << G24["log2n"]
+    M = _Multi(pkg, [0] * 8)
+    try:
+        M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, G24["srs_seed"], n))
+        assert M.lib.bbg_multi_srs_num_points(M.h) == n
+        sc = pkg.synthetic_scalars(G24["scalar_seed"], n)
+        out = np.zeros(12, dtype=np.uint64)
+        M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
+        assert np.array_equal(oracle.jac_to_affine(out), unhex(G24["result"], 8)[0]), "G = 8 sharded 2^24 MSM differs from the reference"
+        # reference shards 3..4 as ONE call: crosses the boundary between contexts 1 and 2 (2^21 points each)
+        recs = G24["shards"][3:5]
+        lo, cnt = recs[0]["from"], recs[0]["n"] + recs[1]["n"]
+        part = np.ascontiguousarray(sc[lo: lo + cnt])
+        M.ck(M.lib.bbg_multi_msm(M.h, part.ctypes.data, lo, cnt, out.ctypes.data))
+        want = oracle.g1_add(unhex(recs[0]["result"], 8)[0], unhex(recs[1]["result"], 8)[0])
+        assert np.array_equal(oracle.jac_to_affine(out), want)
+    finally:
+        M.close()
+
+
+@pytest.mark.parametrize("G", [8, 2])
+def test_multi_ntt_2_24_vs_reference(pkg, oracle, bbg, G):
+    """BASELINE config 5's transform through the in-library split (residue-class shards, all-to-all, size-G DFT) at 2^24 for fft / ifft /
+    coset_fft / coset_ifft against the REFERENCE digests of the whole transform (tests/golden/ntt_large.json)."""
+    import torch
+    lg = 24
+    n = 1 << lg
+    recs = [r for r in _ntt_large_golden() if r["log2n"] == lg]
+    a = pkg.synthetic_scalars(900 + lg, n)
+    M = _Multi(pkg, [0] * G)
+    try:
+        m, length = n // G, n // G // G
+        for rec in recs:
+            shards = [torch.from_numpy(np.ascontiguousarray(a[g::G]).view(np.int64).reshape(-1)).cuda() for g in range(G)]
+            torch.cuda.synchronize()
+            ptrs = (ctypes.c_void_p * G)(*[t.data_ptr() for t in shards])
+            M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, rec["op"]))
+            M.ck(M.lib.bbg_multi_sync(M.h))
+            got = np.zeros((n, 4), dtype=np.uint64)
+            for r in range(G):
+                o = shards[r].cpu().numpy().view(np.uint64).reshape(G, length, 4)
+                for t in range(G):
+                    got[t * m + r * length: t * m + (r + 1) * length] = o[t]
+            got = oracle.canon(0, got)
+            for i, want in rec["spots"].items():
+                assert np.array_equal(got[int(i)], unhex(want)[0]), (G, rec["op"], "spot", i)
+            assert sha(got) == rec["sha256"], (G, rec["op"])
     finally:
         M.close()
 

@@ -274,25 +274,6 @@ if "grandproduct" in stages:
         B.sync()
         dt = (time.perf_counter() - t0) / 5
         print(f"permutation grand product n=2^{lg}: {dt*1e3:.3f} ms  ({n/dt/1e6:.0f} M rows/s)", flush=True)
-if "msmexp" in stages:
-    import torch
-    n = 1 << 20
-    srs = B.srs_synth_hashed(0xBB254, n)
-    sc = inp.synthetic_scalars(1234, n)
-    ts = torch.from_numpy(sc.view(np.int64)).cuda()
-    out = torch.zeros(12, dtype=torch.int64, device="cuda")
-    for mask in (0xFFFFFFFF, 0xFFFFFFFE, 0xFFFF, 0xFF):
-        B.set_option("msm_sort", 0 if mask == 0xFFFFFFFE else 1)
-        B.set_option("msm_debug_idx_mask", 0xFFFFFFFF if mask == 0xFFFFFFFE else mask)
-        B.msm_device(srs, ts.data_ptr(), n, out.data_ptr()); B.sync()
-        B.profile_enable(True)
-        for _ in range(5):
-            B.msm_device(srs, ts.data_ptr(), n, out.data_ptr())
-        B.sync()
-        print(f"idx mask {mask:#x}:", {k: round(B.profile_get(k)[0] / 5, 4) for k in ("msm_recode", "msm_sort", "msm_offsets", "msm_accumulate", "msm_reduce")}, flush=True)
-        B.profile_enable(False)
-    B.set_option("msm_debug_idx_mask", 0xFFFFFFFF)
-    B.set_option("msm_sort", 1)
 if "tune" in stages:
     import torch
     for lg in (20, 22, 24):

@@ -34,7 +34,6 @@ for c in range(cases):
     else:  # raw 256-bit limbs (un-reduced representatives)
         sc = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * 2 + 1
     B.set_option("msm_window", int(rng.choice([0, 16, 20])))
-    B.set_option("msm_sort", int(rng.integers(0, 2)))
     got = O.jac_to_affine(B.msm(srs, sc, start=start))
     want = O.pippenger(sc, pts[start:start + n])
     if not np.array_equal(got, want):
