@@ -40,6 +40,7 @@ int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t cou
 int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
                     uint64_t* alpha_out, hipStream_t st);
 int msm_windows_for(int c);
+int msm_width_slot(int c);
 int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st);
 
 static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs** out)
@@ -66,7 +67,7 @@ static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs*
             return rc;
         }
         s->s.points = table; // window 0 = the plain points
-        (c == 20 ? s->s.table20 : s->s.table16) = table;
+        s->s.tables[msm_width_slot(c)] = table;
     }
     *out = s;
     return BBG_OK;
@@ -227,8 +228,13 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_reduce_quad = (int)value & 15;
         return BBG_OK;
     }
+    if (!strcmp(key, "msm_reduce_blocks")) {
+        if (value < 0 || value > 65535) { set_error("msm_reduce_blocks must be 0 (one block per unit of work) .. 65535"); return BBG_E_INVALID; }
+        ctx->msm_reduce_blocks = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_window")) {
-        if (value != 0 && value != 16 && value != 20) { set_error("msm_window must be 0 (automatic), 16 or 20"); return BBG_E_INVALID; }
+        if (value != 0 && msm_width_slot((int)value) < 0) { set_error("msm_window must be 0 (automatic) or a compiled width: 16, 17, 19, 20, 22"); return BBG_E_INVALID; }
         ctx->msm_window = (int)value;
         return BBG_OK;
     }
@@ -618,8 +624,8 @@ void bbg_srs_free(bbg_srs* srs)
     if (srs->refs.fetch_sub(1) > 1) return; // another owner (a bbg_prover, a second cache entry) still uses it
     (void)hipSetDevice(srs->s.device); // the handle's own record: the context may already be gone (bbg_destroy before bbg_srs_free)
     (void)hipDeviceSynchronize();
-    if (srs->s.table16) (void)hipFree(srs->s.table16);
-    if (srs->s.table20) (void)hipFree(srs->s.table20);
+    for (void* t : srs->s.tables)
+        if (t) (void)hipFree(t);
     delete srs;
 }
 

@@ -47,8 +47,8 @@ struct NttDomain {
 struct Srs {
     size_t n = 0;          // number of (plain) points
     void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical (= window 0 of a table below)
-    void* table16 = nullptr; // window tables T[w][i] = 2^(16 w) P_i, 16 x n points (msm.hip); built on first use
-    void* table20 = nullptr; // window tables T[w][i] = 2^(20 w) P_i, 13 x n points
+    static constexpr int MAX_WIDTHS = 5;
+    void* tables[MAX_WIDTHS] = {}; // window tables T[w][i] = 2^(C w) P_i per compiled width C (slot = msm_width_slot(C), msm.hip); built on first use
     int device = 0;
 };
 
@@ -103,13 +103,14 @@ struct bbg_ctx {
     int msm_layout_sort = 1; // (the sort path is part of the layout: the library-sort path reserves rocPRIM's temporary storage)
     bool msm_async_reduce = false;
     int msm_reduce_quad = 14;   // reduce stages with four lanes per EC operation (curve_quad.hip.h): bit 0 combine (a THROUGHPUT kernel over all buckets: one lane per operation is cheaper, measured), 1 row/col, 2 planes, 3 sum
+    int msm_reduce_blocks = 0;  // option "msm_reduce_blocks": > 0 = thin launches of the overlapped reduce phase's throughput stages (blocks per kernel)
     bool msm_reduce_low_priority = true; // auxiliary stream created with the lowest priority (option "msm_reduce_priority" = 0 undoes it)
     std::map<uint32_t, void*> dpv_consts; // poly.hip: Z*_H division constants per (src, target, roots cut)
     void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
-    int msm_window = 0; // 0 = automatic (20 from n = 2^21, else 16), or 16 / 20
+    int msm_window = 0; // 0 = automatic (msm_auto_window), or one of the compiled widths (BBG_MSM_WIDTHS)
     int msm_sort = 1; // 1 = fused recode + MSD partition sort (msm.hip), 0 = k_recode + rocPRIM radix sort + k_offsets
     int ntt_tile_log = 10; // log2(elements per LDS tile); 10/7 measured best on MI355X (profiles/r01_ntt_plan_sweep.txt)
     int ntt_max_logr = 7;

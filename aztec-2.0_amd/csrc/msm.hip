@@ -24,76 +24,17 @@
 //
 // All exceptional cases of the group law are handled (the reference's handle_edge_cases = true behaviour), so
 // pippenger_unsafe's "attempted to invert zero" failure mode (:317-318) does not exist here.
-#include "bbg_internal.h"
+#include "msm_cfg.h"
 #include "curve.hip.h"
 #include "curve_quad.hip.h"
 
 #include <cstring>
-#ifdef BBG_ROCPRIM_SORT // A/B build only (make ROCPRIM_SORT=1): k_recode + rocPRIM radix sort + k_offsets instead of the partition sort
-#include <rocprim/device/device_radix_sort.hpp>
-#endif
 
 namespace bbg {
 
-// Window width C is a per-call choice between two compiled configurations (msm_pick_window): C = 16 (16 windows, 2^15
-// buckets) and C = 20 (13 windows, 2^19 buckets).  Wider windows trade 19 % of the mixed additions for a 16x larger
-// bucket reduction, which pays from n = 2^20 upwards (r2; 2^21 in round 1).  Each width has its own window tables T[w][i] = 2^(C w) P_i.
-template <int C> struct MsmCfg {
-    static constexpr int c = C;
-    static constexpr int windows = (254 + C) / C;      // C * windows >= 255: 254 scalar bits + the recoding carry
-    static constexpr int buckets = 1 << (C - 1);       // |digit| in [1, 2^(C-1)]
-    static constexpr int lo_bits = C - 11;             // sort partitions = buckets >> lo_bits (+1) = 1025
-    static constexpr int parts = (buckets >> lo_bits) + 1;
-    static constexpr int log_cols = C / 2;             // bucket index (0-based) = hi * cols + lo
-    static constexpr int log_rows = C - 1 - log_cols;
-    static constexpr int planes = C - 1;               // bit planes of the weight idx + 1 <= 2^(C-1)
-};
-constexpr int MSM_MAX_WINDOWS = 16;
-constexpr int MSM_IDX_BITS = 26;     // point index bits in an entry value (n <= 2^26 per call)
-
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
-// ---------------------------------------------------------------------------------- SRS precomputation
-// table[w * n + i] = 2^(C w) * P_i (affine, canonical).  One thread per point: (windows - 1) x C doublings in XYZZ,
-// then one shared inversion (Montgomery's trick over the Z-products) to normalise.
-template <int C> __global__ void __launch_bounds__(128) k_precompute_tables(const Affine* __restrict__ points, Affine* table, size_t n)
-{
-    constexpr int MSM_WINDOWS = MsmCfg<C>::windows, MSM_C = C;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine p = aff_load(points + i);
-    if (aff_is_inf(p)) {
-        for (int w = 0; w < MSM_WINDOWS; w++) aff_store(table + (size_t)w * n + i, aff_inf());
-        return;
-    }
-    p.x = fe_reduce_once(p.x);
-    p.y = fe_reduce_once(p.y);
-    aff_store(table + i, p);
-    // the 15 multiples live in per-thread scratch (one-off kernel: simplicity over registers)
-    Xyzz pts[MSM_WINDOWS - 1];
-    Fq prod[MSM_WINDOWS - 1];
-    Xyzz q = xyzz_dbl_affine(p);
-    for (int k = 1; k < MSM_C; k++) q = xyzz_dbl(q);
-    Fq acc = Fq::one();
-    for (int w = 1; w < MSM_WINDOWS; w++) {
-        pts[w - 1] = q;
-        prod[w - 1] = acc;
-        acc = fe_mul(acc, fe_mul(q.zz, q.zzz));
-        if (w < MSM_WINDOWS - 1)
-            for (int k = 0; k < MSM_C; k++) q = xyzz_dbl(q);
-    }
-    Fq inv = fq_invert(acc);
-    for (int w = MSM_WINDOWS - 1; w >= 1; w--) {
-        const Xyzz& t = pts[w - 1];
-        Fq iz = fe_mul(inv, prod[w - 1]); // 1 / (ZZ * ZZZ) of point w
-        inv = fe_mul(inv, fe_mul(t.zz, t.zzz));
-        Affine a;
-        a.x = fe_reduce_once(fe_mul(t.x, fe_mul(iz, t.zzz))); // X / ZZ
-        a.y = fe_reduce_once(fe_mul(t.y, fe_mul(iz, t.zz)));  // Y / ZZZ
-        aff_store(table + (size_t)w * n + i, a);
-    }
-}
-
+// ---------------------------------------------------------------------------------- synthetic SRS
 // P_i = (a + i*s) * G : thread t owns CH consecutive points; start by double-and-add, then madd steps, normalise
 // with one inversion per thread.
 constexpr int SYNTH_CH = 16;
@@ -183,563 +124,9 @@ __global__ void __launch_bounds__(128) k_srs_hashed(Affine* out, size_t n, uint6
     }
 }
 
-// ---------------------------------------------------------------------------------- scalar recoding
-// scalar (Montgomery, any rep < 2^256) -> canonical integer k -> digits d_w in [-2^15, 2^15], k = sum d_w 2^(16 w).
-// Replaces compute_wnaf_states + fixed_wnaf_with_counts (scalar_multiplication.cpp:188-252, wnaf.hpp:230-283):
-// same idea (signed windows halve the bucket count), but plain signed digits with carry instead of the
-// odd-digit + skew form, and zero digits produce no work.
-// from_montgomery = Montgomery product with the integer 1: (s + m*r) / 2^256 <= r for ANY 256-bit s, so one conditional
-// subtraction canonicalises (from_montgomery_form, field_impl.hpp:245-255).  Top window: k < 2^254, so the last digit
-// is < 2^14 + 1 and never produces a carry.
-template <int C>
-__device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, size_t i, uint32_t (&mag)[MSM_MAX_WINDOWS], uint32_t& signs)
-{
-    const Fr k = fe_from_mont(fe_load<FrP>(scalars + i)); // canonical integer < r < 2^254
-    uint32_t carry = 0;
-    signs = 0;
-#pragma unroll
-    for (int w = 0; w < MsmCfg<C>::windows; w++) {
-        constexpr uint32_t FULL = 1u << C, HALF = 1u << (C - 1);
-        const int bit = w * C, limb = bit >> 5, sh = bit & 31;
-        uint64_t two = k.v[limb];
-        if (limb + 1 < 8) two |= (uint64_t)k.v[limb + 1] << 32;
-        const uint32_t d = ((uint32_t)(two >> sh) & (FULL - 1)) + carry; // 0 .. 2^C
-        const uint32_t neg = d > HALF;
-        mag[w] = neg ? (FULL - d) : d; // |digit| in [0, 2^(C-1)]
-        carry = neg;
-        signs |= neg << w;
-    }
-}
-#ifdef BBG_ROCPRIM_SORT
-template <int C>
-__global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* keys, uint32_t* vals)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t mag[MSM_MAX_WINDOWS], signs;
-    recode_digits<C>(scalars, i, mag, signs);
-#pragma unroll
-    for (int w = 0; w < MsmCfg<C>::windows; w++) {
-        keys[(size_t)w * n + i] = mag[w];
-        vals[(size_t)w * n + i] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
-    }
-}
-
-#endif
-
-// ---------------------------------------------------------------------------------- fused recode + two-level partition sort
-// Replaces k_recode + the 2-pass library radix sort + k_offsets (0.42 ms at 2^20) with an MSD partition that exploits what
-// the accumulation needs: runs per bucket in ANY order.  Bucket id mag in [0, 2^15] splits into hi = mag >> 5 (1025
-// partitions) and lo = mag & 31.
-//   k_sortA_count   : digits of 1024 scalars per block, LDS histogram of hi, one global add per (block, partition)
-//   k_sortA_scan    : exclusive scan of the partition sizes
-//   k_sortA_scatter : digits again; each block reserves a contiguous range in every partition with ONE global atomic,
-//                     groups its entries by partition in LDS and writes them out coalesced; entry = (lo << 32) | value
-//   k_sortB         : one block per partition: LDS histogram of lo, writes the bucket offsets of its 32 buckets and
-//                     moves the 32-bit values to their final position (through LDS when the partition fits)
-// Digits are recomputed instead of stored (one Montgomery product per scalar is cheaper than 2 x 34 MiB of traffic).
-// Order inside a bucket is arbitrary (atomics), so the Jacobian REPRESENTATIVE of an MSM result may differ between runs;
-// the point it denotes does not (the reference's representative likewise depends on its thread count).
-constexpr int SORT_PAD = 2048;   // partition table size (power of two >= MsmCfg::parts = 1025)
-constexpr int SORT_BLOCK = 1024; // scalars per block in the A kernels
-
-// LDS counter bump that stays fast when a whole wave hits one counter (all-equal scalars): one atomic per wave then.
-// Inactive lanes are masked off (no traffic); returns the lane's rank within the counter.
-__device__ __forceinline__ uint32_t lds_take(uint32_t* ctr, uint32_t key, bool active)
-{
-    uint32_t r = 0;
-    if (active) {
-        const uint64_t act = __ballot(1);
-        const uint32_t k0 = __builtin_amdgcn_readfirstlane(key);
-        if (__ballot(key == k0) == act) {
-            const int lane = threadIdx.x & 63;
-            const uint32_t below = (uint32_t)__popcll(act & ((1ull << lane) - 1));
-            uint32_t b = 0;
-            if (below == 0) b = atomicAdd(&ctr[k0], (uint32_t)__popcll(act));
-            r = __builtin_amdgcn_readfirstlane(b) + below;
-        } else {
-            r = atomicAdd(&ctr[key], 1u);
-        }
-    }
-    return r;
-}
-
-// exclusive scan of tbl[0 .. SORT_PAD) by a 1024-thread block, two adjacent entries per thread; returns the pair's
-// exclusive prefixes.  wsum = 16 words of LDS scratch.
-__device__ __forceinline__ void block_scan_pairs(const uint32_t* tbl, uint32_t* wsum, uint32_t& excl0, uint32_t& c0, uint32_t& c1)
-{
-    const int tid = threadIdx.x;
-    c0 = tbl[2 * tid];
-    c1 = tbl[2 * tid + 1];
-    uint32_t incl = c0 + c1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d);
-        if ((tid & 63) >= d) incl += t;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
-    excl0 = before + incl - (c0 + c1);
-}
-
-template <int C> __global__ void __launch_bounds__(SORT_BLOCK) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
-{
-    constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
-    __shared__ uint32_t hist[SORT_PAD];
-    const int tid = threadIdx.x;
-    hist[tid] = 0;
-    hist[tid + 1024] = 0;
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
-    uint32_t mag[MSM_MAX_WINDOWS], signs;
-    if (i < n) recode_digits<C>(scalars, i, mag, signs);
-#pragma unroll
-    for (int w = 0; w < MSM_WINDOWS; w++) {
-        const bool on = i < n && mag[w] != 0; // zero digits contribute nothing: never sorted
-        lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
-    }
-    __syncthreads();
-    for (int h = tid; h < SORT_PARTS; h += SORT_BLOCK)
-        if (hist[h]) atomicAdd(&part_count[h], hist[h]);
-}
-// part_base[h] = sum_{h' < h} count[h'] ; cursor[h] = part_base[h] ; offsets[MSM_BUCKETS + 1] = total
-template <int C>
-__global__ void __launch_bounds__(1024) k_sortA_scan(const uint32_t* __restrict__ part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets)
-{
-    constexpr int SORT_PARTS = MsmCfg<C>::parts, MSM_BUCKETS = MsmCfg<C>::buckets;
-    __shared__ uint32_t wsum[16];
-    const int tid = threadIdx.x;
-    uint32_t excl, c0, c1;
-    block_scan_pairs(part_count, wsum, excl, c0, c1); // part_count[SORT_PARTS ..) is zero
-    const int h0 = 2 * tid, h1 = 2 * tid + 1;
-    if (h0 <= SORT_PARTS) part_base[h0] = excl; // part_base[SORT_PARTS] = total
-    if (h1 <= SORT_PARTS) part_base[h1] = excl + c0;
-    if (h0 < SORT_PARTS) cursor[h0] = excl;
-    if (h1 < SORT_PARTS) cursor[h1] = excl + c0;
-    if (h0 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl;
-    if (h1 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl + c0;
-}
-// The block's <= 16 Ki entries are first grouped by partition in LDS (values + bucket ids, 128 KiB) and then written
-// out with consecutive threads on consecutive addresses: every (block, partition) chunk is one contiguous burst instead
-// of independent 8-byte stores issued at random times.
-template <int C> __global__ void __launch_bounds__(SORT_BLOCK)
-k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* cursor, uint64_t* entries)
-{
-    constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
-    constexpr int CAP = SORT_BLOCK * MSM_WINDOWS;
-    __shared__ uint32_t hist[SORT_PAD];   // per-partition count, then rank counter
-    __shared__ uint32_t lstart[SORT_PAD]; // first LDS slot of each partition
-    __shared__ uint32_t gbase[SORT_PAD];  // this block's first global slot in each partition, minus lstart
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t st_val[CAP];
-    __shared__ uint32_t st_mag[CAP];
-    const int tid = threadIdx.x;
-    hist[tid] = 0;
-    hist[tid + 1024] = 0;
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
-    uint32_t mag[MSM_MAX_WINDOWS], signs = 0;
-    if (i < n) recode_digits<C>(scalars, i, mag, signs);
-#pragma unroll
-    for (int w = 0; w < MSM_WINDOWS; w++) {
-        const bool on = i < n && mag[w] != 0;
-        lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
-    }
-    __syncthreads();
-    uint32_t excl, c0, c1;
-    block_scan_pairs(hist, wsum, excl, c0, c1);
-    __syncthreads();
-    {
-        const int h0 = 2 * tid, h1 = 2 * tid + 1;
-        lstart[h0] = excl;
-        lstart[h1] = excl + c0;
-        gbase[h0] = (c0 ? atomicAdd(&cursor[h0], c0) : 0u) - excl; // one global reservation per (block, partition)
-        gbase[h1] = (c1 ? atomicAdd(&cursor[h1], c1) : 0u) - (excl + c0);
-        hist[h0] = 0;
-        hist[h1] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < MSM_WINDOWS; w++) {
-        const bool on = i < n && mag[w] != 0;
-        const uint32_t h = on ? mag[w] >> SORT_LO_BITS : 0u;
-        const uint32_t rank = lds_take(hist, h, on);
-        if (on) {
-            const uint32_t slot = lstart[h] + rank;
-            st_val[slot] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
-            st_mag[slot] = mag[w];
-        }
-    }
-    __syncthreads();
-    const uint32_t total = lstart[SORT_PARTS - 1] + hist[SORT_PARTS - 1];
-    for (uint32_t slot = tid; slot < total; slot += SORT_BLOCK) {
-        const uint32_t m = st_mag[slot];
-        entries[gbase[m >> SORT_LO_BITS] + slot] = ((uint64_t)(m & ((1u << SORT_LO_BITS) - 1)) << 32) | st_val[slot];
-    }
-}
-
-// One block per partition.  Fast path (partition <= SORTB_CAP entries, the normal case up to n = 2^20): entries are
-// read once into registers, ranked with LDS counters, staged in LDS in bucket order and written out coalesced.  Larger
-// partitions (bigger n, skewed digits) take two passes over global memory with scattered 4-byte stores.
-constexpr int SORTB_PER_THREAD = 18;
-constexpr int SORTB_CAP = SORTB_PER_THREAD * 1024; // 72 KiB of staging (+ up to 4 KiB of counters): two blocks per CU
-constexpr int SORTB_UNROLL = 8;
-template <int C> __global__ void __launch_bounds__(1024)
-k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_base, uint32_t* offsets, uint32_t* svals)
-{
-    constexpr int SORT_LO_BITS = MsmCfg<C>::lo_bits, MSM_BUCKETS = MsmCfg<C>::buckets, BINS = 1 << SORT_LO_BITS;
-    constexpr uint32_t SORT_LO_MASK = BINS - 1;
-    static_assert(BINS <= 1024, "one thread per bin");
-    __shared__ uint32_t hist[BINS];
-    __shared__ uint32_t off[BINS];
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t stage[SORTB_CAP];
-    const int tid = threadIdx.x;
-    const uint32_t h = blockIdx.x;
-    const uint32_t pb = part_base[h], pe = part_base[h + 1];
-    const uint32_t len = pe - pb;
-    const bool fast = len <= (uint32_t)SORTB_CAP;
-    if (tid < BINS) hist[tid] = 0;
-    __syncthreads();
-    uint64_t e[SORTB_PER_THREAD];
-    constexpr uint32_t CHUNK = 1024 * SORTB_UNROLL;
-    const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loops (lds_take is wave-cooperative)
-    if (fast) {
-#pragma unroll
-        for (int u = 0; u < SORTB_PER_THREAD; u++) {
-            const uint32_t q = u * 1024 + tid;
-            const uint64_t v = entries[pb + (q < len ? q : 0u)]; // unconditional: the loads batch up
-            e[u] = q < len ? v : ~0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < SORTB_PER_THREAD; u++) lds_take(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
-    } else {
-        for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
-            uint32_t key[SORTB_UNROLL];
-#pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
-                const uint32_t q = q0 + u * 1024 + tid;
-                const uint32_t k = (uint32_t)(entries[pb + (q < len ? q : 0u)] >> 32);
-                key[u] = q < len ? k : 0xffffffffu;
-            }
-#pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) lds_take(hist, key[u] & SORT_LO_MASK, key[u] != 0xffffffffu);
-        }
-    }
-    __syncthreads();
-    { // exclusive scan of the BINS counters (one per thread, wave scans + 16 wave totals)
-        const uint32_t c = tid < BINS ? hist[tid] : 0u;
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if ((tid & 63) >= d) incl += t;
-        }
-        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
-        if (tid < BINS) {
-            const uint32_t excl = before + incl - c;
-            off[tid] = excl;
-            const uint32_t bucket = (h << SORT_LO_BITS) + tid;
-            if (bucket <= (uint32_t)MSM_BUCKETS) offsets[bucket] = pb + excl;
-        }
-    }
-    __syncthreads();
-    if (fast) {
-#pragma unroll
-        for (int u = 0; u < SORTB_PER_THREAD; u++) {
-            const bool on = e[u] != ~0ull;
-            const uint32_t pos = lds_take(off, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, on);
-            if (on) stage[pos] = (uint32_t)e[u];
-        }
-        __syncthreads();
-        for (uint32_t q = tid; q < len; q += 1024) svals[pb + q] = stage[q];
-    } else {
-        // Large partition: chunks of 8192 entries are grouped by bucket in LDS and written out as runs (one run per bucket
-        // and chunk, on consecutive addresses) instead of 8192 independent 4-byte stores.  off[] = running global position
-        // of every bucket; cnt[] / cstart[] = this chunk's counts and their exclusive scan (reusing hist[] and wsum[]).
-        uint32_t* cnt = hist;
-        __shared__ uint32_t cstart[BINS];
-        uint32_t* stage_val = stage;
-        uint32_t* stage_bin = stage + CHUNK;
-        static_assert(2 * CHUNK <= (uint32_t)SORTB_CAP, "chunk staging must fit the fast path's stage buffer");
-        for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
-            uint64_t x[SORTB_UNROLL];
-            uint32_t rk[SORTB_UNROLL];
-            if (tid < BINS) cnt[tid] = 0;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
-                const uint32_t q = q0 + u * 1024 + tid;
-                const uint64_t v = entries[pb + (q < len ? q : 0u)];
-                x[u] = q < len ? v : ~0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) rk[u] = lds_take(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
-            __syncthreads();
-            { // exclusive scan of this chunk's counts
-                const uint32_t c = tid < BINS ? cnt[tid] : 0u;
-                uint32_t incl = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t t = __shfl_up(incl, d);
-                    if ((tid & 63) >= d) incl += t;
-                }
-                if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-                __syncthreads();
-                uint32_t before = 0;
-                for (int k = 0; k < (tid >> 6); k++) before += wsum[k];
-                if (tid < BINS) cstart[tid] = before + incl - c;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
-                if (x[u] != ~0ull) {
-                    const uint32_t b = (uint32_t)(x[u] >> 32) & SORT_LO_MASK;
-                    const uint32_t slot = cstart[b] + rk[u];
-                    stage_val[slot] = (uint32_t)x[u];
-                    stage_bin[slot] = b;
-                }
-            }
-            __syncthreads();
-            const uint32_t chunk_len = len - q0 < CHUNK ? len - q0 : CHUNK;
-            for (uint32_t slot = tid; slot < chunk_len; slot += 1024) {
-                const uint32_t b = stage_bin[slot];
-                svals[pb + off[b] + (slot - cstart[b])] = stage_val[slot];
-            }
-            __syncthreads();
-            if (tid < BINS) off[tid] += cnt[tid];
-            __syncthreads();
-        }
-    }
-}
-
-#ifdef BBG_ROCPRIM_SORT
-// offsets[b] = first sorted position with key >= b, for b = 0 .. MSM_BUCKETS + 1
-template <int C> __global__ void k_offsets(const uint32_t* __restrict__ keys, size_t total, uint32_t* offsets)
-{
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
-    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e > total) return;
-    if (e == total) {
-        uint32_t last = total ? keys[total - 1] : 0;
-        if (total == 0) offsets[0] = 0;
-        for (uint32_t b = last + 1; b <= MSM_BUCKETS + 1; b++) offsets[b] = (uint32_t)total;
-        return;
-    }
-    uint32_t k = keys[e];
-    if (e == 0) {
-        for (uint32_t b = 0; b <= k; b++) offsets[b] = 0;
-    } else {
-        uint32_t kp = keys[e - 1];
-        for (uint32_t b = kp + 1; b <= k; b++) offsets[b] = (uint32_t)e;
-    }
-}
-
-#endif
-
-// ---------------------------------------------------------------------------------- bucket accumulation
-// Load-balanced: the sorted entry array (without the key-0 prefix) is cut into segments of MSM_SEG entries, one lane
-// per segment, regardless of bucket boundaries -- every lane does the same number of mixed additions (a per-bucket
-// split leaves a wave waiting for its fullest bucket: ~77 % lane efficiency at Poisson(64)).  A lane walks its
-// segment; the bucket it is in comes from the offsets table (binary search once, then sequential).  Runs are emitted as
-//   head[lane]  : the run containing the segment's first entry (may continue from the previous lane)
-//   tail[lane]  : the run containing the segment's last entry, if different from the head run
-//   buckets[b]  : runs that start and end strictly inside the segment (complete buckets)
-// and k_combine adds head/tail pieces per bucket.  Values address the window tables: point = table[w*n_srs + idx],
-// negated when bit 31 is set.
-constexpr uint32_t MSM_SEG_MIN = 8, MSM_SEG_DEFAULT = 64; // segment length is chosen per call (msm_seg_len)
-constexpr int MSM_LONG_SPAN = 48; // buckets spanning more lanes than this are summed by a whole block
-
-__device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ table, size_t n_srs, uint32_t v)
-{
-    return aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
-}
-
-template <int C> __global__ void __launch_bounds__(256)
-k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-             size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets)
-{
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
-    const uint32_t total = offsets[MSM_BUCKETS + 1]; // the partition sort drops zero digits: the count lives on the device
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t base = offsets[1]; // entries with key 0 (zero digits) sort first and are skipped
-    const uint64_t s64 = (uint64_t)base + (uint64_t)lane * seg;
-    if (s64 >= total) return;
-    const uint32_t s = (uint32_t)s64;
-    const uint32_t e = (total - s > seg) ? s + seg : total;
-    // bucket containing position s: largest b in [1, 2^15] with offsets[b] <= s
-    uint32_t lo = 1, hi = MSM_BUCKETS;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (offsets[mid] <= s) lo = mid;
-        else hi = mid - 1;
-    }
-    uint32_t cur = lo;
-    uint32_t cur_end = offsets[cur + 1];
-    bool first_run = true;
-    Xyzz acc = xyzz_inf();
-    uint32_t v = vals[s];
-    Affine p = load_entry_point(table, n_srs, v);
-    for (uint32_t q = s; q < e; q++) {
-        if (q == cur_end) { // the run of bucket `cur` ended inside this segment
-            if (first_run) xyzz_store(head + lane, acc);
-            else xyzz_store(buckets + (cur - 1), acc);
-            first_run = false;
-            acc = xyzz_inf();
-            do {
-                cur++;
-                cur_end = offsets[cur + 1];
-            } while (cur_end <= q); // skip empty buckets
-        }
-        const uint32_t vc = v;
-        const Affine pc = p;
-        if (q + 1 < e) { // software prefetch of the next gather
-            v = vals[q + 1];
-            p = load_entry_point(table, n_srs, v);
-        }
-        acc = xyzz_madd(acc, aff_neg_if(pc, (vc >> 31) != 0));
-    }
-    if (first_run) xyzz_store(head + lane, acc);
-    else xyzz_store(tail + lane, acc);
-}
-
-// piece of bucket b held by lane l (see k_accumulate): head if the bucket starts at or before the lane's segment start
-__device__ __forceinline__ Xyzz bucket_piece(const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, uint32_t l, uint32_t l0,
-                                             bool starts_at_seg_start)
-{
-    if (l == l0 && !starts_at_seg_start) return xyzz_load(tail + l);
-    return xyzz_load(head + l);
-}
-
-// buckets[b-1] = sum of the pieces of bucket b; complete ("middle") runs were already written by k_accumulate.
-// Buckets spanning more than MSM_LONG_SPAN lanes (skewed scalar distributions) are queued for k_combine_long.
-template <int C> __global__ void __launch_bounds__(256, 1)
-k_combine(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-          Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
-{
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
-    const uint32_t total = offsets[MSM_BUCKETS + 1];
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (b > MSM_BUCKETS) return;
-    const uint32_t base = offsets[1];
-    const uint32_t sb = offsets[b], eb = offsets[b + 1];
-    if (sb == eb) {
-        xyzz_store(buckets + (b - 1), xyzz_inf());
-        return;
-    }
-    const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
-    const bool at_start = (sb == base + l0 * seg);
-    if (l0 == l1) {
-        uint32_t seg_end = base + (l0 + 1) * seg;
-        if (seg_end > total || seg_end < base) seg_end = total;
-        if (at_start) xyzz_store(buckets + (b - 1), xyzz_load(head + l0));
-        else if (eb == seg_end) xyzz_store(buckets + (b - 1), xyzz_load(tail + l0));
-        return; // else: complete run, already stored
-    }
-    if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
-        const uint32_t slot = atomicAdd(long_count, 1u);
-        long_list[slot] = b;
-        return;
-    }
-    Xyzz acc = bucket_piece(head, tail, l0, l0, at_start);
-    for (uint32_t l = l0 + 1; l <= l1; l++) acc = xyzz_add(acc, xyzz_load(head + l));
-    xyzz_store(buckets + (b - 1), acc);
-}
-
-__device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads);
-
-__device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
-{
-    Xyzz r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        r.x.v[i] = __shfl_xor(v.x.v[i], mask);
-        r.y.v[i] = __shfl_xor(v.y.v[i], mask);
-        r.zz.v[i] = __shfl_xor(v.zz.v[i], mask);
-        r.zzz.v[i] = __shfl_xor(v.zzz.v[i], mask);
-    }
-    return r;
-}
-
-// Latency-oriented variant of k_combine: MSM_COMBINE_LANES adjacent lanes share a bucket, each sums every 4th piece, then
-// a butterfly over the lane group (a bucket of ~512 entries has ~9 pieces: the serial chain drops from 8 additions to
-// 5).  4 lanes, not 8: the butterfly runs in lock-step on every lane, and with 8 the reduce phase (which shares the chip
-// with the next MSM's accumulation) cost 40 lane-additions per bucket instead of 17 -- 5 % of the pipelined step time.
-constexpr int MSM_COMBINE_LANES = 4;
-template <int C> __global__ void __launch_bounds__(256, 1)
-k_combine_lanes(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
-{
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
-    const uint32_t total = offsets[MSM_BUCKETS + 1];
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = gid / MSM_COMBINE_LANES + 1;
-    const uint32_t r = gid % MSM_COMBINE_LANES;
-    if (b > MSM_BUCKETS) return; // whole lane groups drop out together (grid is a multiple of 8)
-    const uint32_t base = offsets[1];
-    const uint32_t sb = offsets[b], eb = offsets[b + 1];
-    bool store = true, reduce = false;
-    Xyzz acc = xyzz_inf();
-    if (sb != eb) {
-        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
-        const bool at_start = (sb == base + l0 * seg);
-        if (l0 == l1) {
-            uint32_t seg_end = base + (l0 + 1) * seg;
-            if (seg_end > total || seg_end < base) seg_end = total;
-            if (at_start) acc = xyzz_load(head + l0);
-            else if (eb == seg_end) acc = xyzz_load(tail + l0);
-            else store = false; // complete run, already written by k_accumulate
-        } else if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
-            if (r == 0) {
-                const uint32_t slot = atomicAdd(long_count, 1u);
-                long_list[slot] = b;
-            }
-            store = false;
-        } else {
-            reduce = true;
-            for (uint32_t l = l0 + r; l <= l1; l += MSM_COMBINE_LANES) acc = xyzz_add(acc, bucket_piece(head, tail, l, l0, at_start));
-        }
-    }
-    // the butterfly is executed by all lanes of the wave (shuffles need every lane); groups that do not reduce carry infinities
-    if (!reduce && !(sb != eb && store)) acc = xyzz_inf();
-    const unsigned long long any = __ballot(reduce);
-    if (any) {
-        Xyzz part = reduce ? acc : xyzz_inf();
-        for (int m = MSM_COMBINE_LANES >> 1; m >= 1; m >>= 1) part = xyzz_add(part, xyzz_shfl_xor(part, m));
-        if (reduce) acc = part;
-    }
-    if (store && r == 0) xyzz_store(buckets + (b - 1), acc);
-}
-
-
-// one block per queued long bucket (grid-stride over the queue)
-template <int C> __global__ void __launch_bounds__(256, 1)
-k_combine_long(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
-               const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list)
-{
-    __shared__ Xyzz sm[128];
-    const uint32_t cnt = *long_count;
-    const uint32_t base = offsets[1];
-    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-        const uint32_t b = long_list[i];
-        const uint32_t sb = offsets[b], eb = offsets[b + 1];
-        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
-        const bool at_start = (sb == base + l0 * seg);
-        Xyzz acc = xyzz_inf();
-        for (uint32_t l = l0 + threadIdx.x; l <= l1; l += 256) acc = xyzz_add(acc, bucket_piece(head, tail, l, l0, at_start));
-        acc = block_reduce(acc, sm, 256);
-        if (threadIdx.x == 0) xyzz_store(buckets + (b - 1), acc);
-        __syncthreads();
-    }
-}
-
+// ---------------------------------------------------------------------------------- last reduce stage, g1 helpers
 // LDS tree reduction of one point per thread; result valid in thread 0.
-__device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads)
+static __device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads)
 {
     const int tid = threadIdx.x;
     for (int stride = nthreads >> 1; stride >= 1; stride >>= 1) {
@@ -750,71 +137,7 @@ __device__ Xyzz block_reduce(Xyzz v, Xyzz* sm, int nthreads)
     }
     return v;
 }
-
-// weight of bucket index idx (0-based) is idx + 1 = hi*COLS + lo + 1  (COLS = 2^log_cols, ROWS = 2^log_rows).
-// blocks 0..ROWS-1: Row_hi = sum_lo B[hi][lo] ; blocks ROWS..ROWS+COLS-1: Col_lo = sum_hi B[hi][lo].
-template <int C> __global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
-{
-    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
-    __shared__ Xyzz sm[128];
-    const int tid = threadIdx.x;
-    if (blockIdx.x < ROWS) {
-        const int hi = blockIdx.x;
-        Xyzz v = xyzz_load(buckets + (size_t)hi * COLS + tid);
-        for (int lo = tid + 256; lo < COLS; lo += 256) v = xyzz_add(v, xyzz_load(buckets + (size_t)hi * COLS + lo));
-        v = block_reduce(v, sm, 256);
-        if (tid == 0) xyzz_store(rows + hi, v);
-    } else {
-        const int lo = blockIdx.x - ROWS;
-        Xyzz v = xyzz_inf();
-        for (int hi = tid; hi < ROWS; hi += 256) v = xyzz_add(v, xyzz_load(buckets + (size_t)hi * COLS + lo));
-        v = block_reduce(v, sm, 256);
-        if (tid == 0) xyzz_store(cols + lo, v);
-    }
-}
-
-// sum_b b*B_b = COLS * sum_hi hi*Row_hi + sum_lo (lo+1)*Col_lo = sum_t 2^t H_t with the bit planes
-//   H_t = sum_{lo : bit t of (lo+1)} Col_lo  +  sum_{hi : bit (t - log_cols) of hi} Row_hi        (t = 0 .. C-2).
-// One block per bit plane: tree-sum the selected rows/columns, then t doublings by one lane -- the planes run side by
-// side, so the serial depth is ~9 additions + t doublings instead of a double-and-add on top of a tree plus log_cols more
-// doublings.  k_final_sum adds the planes and converts to the reference's Jacobian layout.
-template <int C> __global__ void __launch_bounds__(256, 1) k_final_planes(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Xyzz* planes)
-{
-    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols, LOGC = MsmCfg<C>::log_cols;
-    __shared__ Xyzz sm[128];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    Xyzz v = xyzz_inf();
-    if (t <= LOGC)
-        for (int lo = tid; lo < COLS; lo += 256)
-            if (((lo + 1) >> t) & 1) v = xyzz_add(v, xyzz_load(cols + lo));
-    if (t >= LOGC)
-        for (int hi = tid; hi < ROWS; hi += 256)
-            if ((hi >> (t - LOGC)) & 1) v = xyzz_add(v, xyzz_load(rows + hi));
-    v = block_reduce(v, sm, 256);
-    if (tid == 0) {
-        for (int k = 0; k < t; k++) v = xyzz_dbl(v);
-        xyzz_store(planes + t, v);
-    }
-}
-constexpr int MSM_MAX_PLANES = 32;
-__global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ planes, int nplanes, Jacobian* out)
-{
-    __shared__ Xyzz sm[16];
-    Xyzz v = (int)threadIdx.x < nplanes ? xyzz_load(planes + threadIdx.x) : xyzz_inf();
-    v = block_reduce(v, sm, MSM_MAX_PLANES);
-    if (threadIdx.x == 0) {
-        Jacobian j = xyzz_to_jacobian(v);
-        fe_store<FqP>(&out->x, j.x);
-        fe_store<FqP>(&out->y, j.y);
-        fe_store<FqP>(&out->z, j.z);
-    }
-}
-
-// ------------------------------------------------------------------------------------ quad-cooperative reduce phase
-// The same reduce phase with every EC operation shared by FOUR adjacent lanes (curve_quad.hip.h): a logical lane lt = thread / 4,
-// q = thread % 4.  Identical structure and results; the dependency chain is ~3x shorter in time.  Blocks carry 4x the threads for the
-// same number of logical lanes (512 threads = 128 logical lanes, so that a thread may keep up to 256 VGPRs).
-__device__ __forceinline__ Xyzz block_reduce_q4(Xyzz v, Xyzz* sm, int nlogical)
+static __device__ __forceinline__ Xyzz block_reduce_q4(Xyzz v, Xyzz* sm, int nlogical)
 {
     const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
     for (int stride = nlogical >> 1; stride >= 1; stride >>= 1) {
@@ -825,152 +148,16 @@ __device__ __forceinline__ Xyzz block_reduce_q4(Xyzz v, Xyzz* sm, int nlogical)
     }
     return v;
 }
-constexpr int Q_LOGICAL = 128, Q_THREADS = 4 * Q_LOGICAL;
-
-template <int C> __global__ void __launch_bounds__(Q_THREADS)
-k_combine_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+__global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ planes, int nplanes, Jacobian* out)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
-    const uint32_t total = offsets[MSM_BUCKETS + 1];
-    const uint32_t gl = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const int q = threadIdx.x & 3;
-    const uint32_t b = gl + 1;
-    if (b > MSM_BUCKETS) return;
-    const uint32_t base = offsets[1];
-    const uint32_t sb = offsets[b], eb = offsets[b + 1];
-    if (sb == eb) {
-        if (q == 0) xyzz_store(buckets + (b - 1), xyzz_inf());
-        return;
-    }
-    const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
-    const bool at_start = (sb == base + l0 * seg);
-    if (l0 == l1) {
-        uint32_t seg_end = base + (l0 + 1) * seg;
-        if (seg_end > total || seg_end < base) seg_end = total;
-        if (at_start) { if (q == 0) xyzz_store(buckets + (b - 1), xyzz_load(head + l0)); }
-        else if (eb == seg_end) { if (q == 0) xyzz_store(buckets + (b - 1), xyzz_load(tail + l0)); }
-        return; // else: complete run, already stored
-    }
-    if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
-        if (q == 0) {
-            const uint32_t slot = atomicAdd(long_count, 1u);
-            long_list[slot] = b;
-        }
-        return;
-    }
-    Xyzz acc = bucket_piece(head, tail, l0, l0, at_start);
-    for (uint32_t l = l0 + 1; l <= l1; l++) acc = xyzz_add_q4(acc, xyzz_load(head + l), q);
-    if (q == 0) xyzz_store(buckets + (b - 1), acc);
-}
-
-// MSM_COMBINE_LANES logical lanes (16 threads) per bucket, butterfly across the logical lanes (shuffle distances 8 and 4)
-template <int C> __global__ void __launch_bounds__(Q_THREADS)
-k_combine_lanes_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-                  Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
-{
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
-    const uint32_t total = offsets[MSM_BUCKETS + 1];
-    const uint32_t gl = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const int q = threadIdx.x & 3;
-    const uint32_t b = gl / MSM_COMBINE_LANES + 1;
-    const uint32_t r = gl % MSM_COMBINE_LANES;
-    if (b > MSM_BUCKETS) return; // whole waves drop out together (64 threads = 4 buckets)
-    const uint32_t base = offsets[1];
-    const uint32_t sb = offsets[b], eb = offsets[b + 1];
-    bool store = true, reduce = false;
-    Xyzz acc = xyzz_inf();
-    if (sb != eb) {
-        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
-        const bool at_start = (sb == base + l0 * seg);
-        if (l0 == l1) {
-            uint32_t seg_end = base + (l0 + 1) * seg;
-            if (seg_end > total || seg_end < base) seg_end = total;
-            if (at_start) acc = xyzz_load(head + l0);
-            else if (eb == seg_end) acc = xyzz_load(tail + l0);
-            else store = false; // complete run, already written by k_accumulate
-        } else if (l1 - l0 > (uint32_t)MSM_LONG_SPAN) {
-            if (r == 0 && q == 0) {
-                const uint32_t slot = atomicAdd(long_count, 1u);
-                long_list[slot] = b;
-            }
-            store = false;
-        } else {
-            reduce = true;
-            for (uint32_t l = l0 + r; l <= l1; l += MSM_COMBINE_LANES) acc = xyzz_add_q4(acc, bucket_piece(head, tail, l, l0, at_start), q);
-        }
-    }
-    if (!reduce && !(sb != eb && store)) acc = xyzz_inf();
-    const unsigned long long any = __ballot(reduce);
-    if (any) {
-        Xyzz part = reduce ? acc : xyzz_inf();
-        for (int m = MSM_COMBINE_LANES >> 1; m >= 1; m >>= 1) part = xyzz_add_q4(part, xyzz_shfl_xor(part, 4 * m), q);
-        if (reduce) acc = part;
-    }
-    if (store && r == 0 && q == 0) xyzz_store(buckets + (b - 1), acc);
-}
-
-template <int C> __global__ void __launch_bounds__(Q_THREADS)
-k_combine_long_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail, Xyzz* buckets,
-                 const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list)
-{
-    __shared__ Xyzz sm[Q_LOGICAL / 2];
-    const int lt = threadIdx.x >> 2, q = threadIdx.x & 3;
-    const uint32_t cnt = *long_count;
-    const uint32_t base = offsets[1];
-    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-        const uint32_t b = long_list[i];
-        const uint32_t sb = offsets[b], eb = offsets[b + 1];
-        const uint32_t l0 = (sb - base) / seg, l1 = (eb - 1 - base) / seg;
-        const bool at_start = (sb == base + l0 * seg);
-        Xyzz acc = xyzz_inf();
-        for (uint32_t l = l0 + lt; l <= l1; l += Q_LOGICAL) acc = xyzz_add_q4(acc, bucket_piece(head, tail, l, l0, at_start), q);
-        acc = block_reduce_q4(acc, sm, Q_LOGICAL);
-        if (threadIdx.x == 0) xyzz_store(buckets + (b - 1), acc);
-        __syncthreads();
-    }
-}
-
-// QL logical lanes (4 QL threads) per row / column: each lane first sums its share serially, then a tree of log2 QL levels.  Fewer lanes =
-// more serial additions but fewer idle tree slots and fewer waves per SIMD (a tree level costs ~2.7 us with one wave per SIMD, ~7 with three).
-template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
-{
-    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
-    __shared__ Xyzz sm[QL / 2];
-    const int q = threadIdx.x & 3;
-    // serial phase: every THREAD sums its own share with one-lane additions (a quad-cooperative addition costs 1.55x the instructions of a
-    // one-lane one -- it buys latency, and there is none to buy while all four lanes have items of their own); then the four partial sums of
-    // a quad are added with four-lane operations, then the tree over the QL quads
-    Xyzz s = xyzz_inf();
-    if (blockIdx.x < ROWS) {
-        const int hi = blockIdx.x;
-        for (int lo = threadIdx.x; lo < COLS; lo += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
-        Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
-        if (threadIdx.x == 0) xyzz_store(rows + hi, v);
-    } else {
-        const int lo = blockIdx.x - ROWS;
-        for (int hi = threadIdx.x; hi < ROWS; hi += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
-        Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
-        if (threadIdx.x == 0) xyzz_store(cols + lo, v);
-    }
-}
-
-template <int C> __global__ void __launch_bounds__(Q_THREADS) k_final_planes_q(const Xyzz* __restrict__ rows, const Xyzz* __restrict__ cols, Xyzz* planes)
-{
-    constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols, LOGC = MsmCfg<C>::log_cols;
-    __shared__ Xyzz sm[Q_LOGICAL / 2];
-    const int t = blockIdx.x, lt = threadIdx.x >> 2, q = threadIdx.x & 3;
-    Xyzz v = xyzz_inf();
-    if (t <= LOGC)
-        for (int lo = lt; lo < COLS; lo += Q_LOGICAL)
-            if (((lo + 1) >> t) & 1) v = xyzz_add_q4(v, xyzz_load(cols + lo), q);
-    if (t >= LOGC)
-        for (int hi = lt; hi < ROWS; hi += Q_LOGICAL)
-            if ((hi >> (t - LOGC)) & 1) v = xyzz_add_q4(v, xyzz_load(rows + hi), q);
-    v = block_reduce_q4(v, sm, Q_LOGICAL);
-    if (lt == 0) {
-        for (int k = 0; k < t; k++) v = xyzz_dbl_q4(v, q);
-        if (q == 0) xyzz_store(planes + t, v);
+    __shared__ Xyzz sm[16];
+    Xyzz v = (int)threadIdx.x < nplanes ? xyzz_load(planes + threadIdx.x) : xyzz_inf();
+    v = block_reduce(v, sm, MSM_MAX_PLANES);
+    if (threadIdx.x == 0) {
+        Jacobian j = xyzz_to_jacobian(v);
+        fe_store<FqP>(&out->x, j.x);
+        fe_store<FqP>(&out->y, j.y);
+        fe_store<FqP>(&out->z, j.z);
     }
 }
 __global__ void __launch_bounds__(4 * MSM_MAX_PLANES) k_final_sum_q(const Xyzz* __restrict__ planes, int nplanes, Jacobian* out)
@@ -987,6 +174,13 @@ __global__ void __launch_bounds__(4 * MSM_MAX_PLANES) k_final_sum_q(const Xyzz* 
         fe_store<FqP>(&out->y, j.y);
         fe_store<FqP>(&out->z, j.z);
     }
+}
+int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st)
+{
+    if (quad) hipLaunchKernelGGL(k_final_sum_q, dim3(1), dim3(4 * MSM_MAX_PLANES), 0, st, (const Xyzz*)d_planes, nplanes, (Jacobian*)d_out_jac);
+    else hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, st, (const Xyzz*)d_planes, nplanes, (Jacobian*)d_out_jac);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
 }
 
 // sum of n Jacobian points (g1_sum, reference c_bind.cpp:39-46): one block, serial per thread then tree.
@@ -1032,106 +226,55 @@ __global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ 
     aff_store(out + i, xyzz_to_affine(xyzz_from_jacobian(j)));
 }
 
-// ---------------------------------------------------------------------------------- host side
-struct MsmLayout {
-    size_t entries, lanes;
-    size_t off_keys0, off_keys1, off_vals0, off_vals1, off_sort, off_parts;
-    uint32_t seg;
-    // reduce-phase working set, double buffered so that the reduce of MSM i (aux stream) overlaps MSM i+1
-    size_t off_offsets[bbg_ctx::MSM_SLOTS], off_head[bbg_ctx::MSM_SLOTS], off_tail[bbg_ctx::MSM_SLOTS], off_buckets[bbg_ctx::MSM_SLOTS], off_rows[bbg_ctx::MSM_SLOTS],
-        off_cols[bbg_ctx::MSM_SLOTS], off_long[bbg_ctx::MSM_SLOTS];
-    size_t sort_bytes;
-    size_t total;
+// ---------------------------------------------------------------------------------- host side: width dispatch
+static const int MSM_WIDTHS[] = {
+#define X(c) c,
+    BBG_MSM_WIDTHS(X)
+#undef X
 };
-static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr int MSM_NUM_WIDTHS = (int)(sizeof(MSM_WIDTHS) / sizeof(MSM_WIDTHS[0]));
+static_assert(MSM_NUM_WIDTHS == Srs::MAX_WIDTHS, "Srs::tables has one slot per compiled window width");
 
-// Segment length (entries per accumulation lane).  Around 64 at the headline size; shorter for small MSMs, whose run time
-// is the latency of one lane's serial chain of mixed additions (64 additions = 0.43 ms regardless of n), and longer for
-// very large ones so that a bucket spans <= ~32 lanes and the lane-group combine (not the block-per-bucket fallback) sums
-// its pieces.  When one round of waves covers the whole job the lane count is made a multiple of the chip's 65536 SIMD
-// lanes: with 3.25 waves per SIMD the kernel takes as long as with 4, because the busiest SIMD sets the time.
-static uint32_t msm_seg_len(size_t entries, size_t buckets)
+int msm_width_slot(int c)
 {
-    constexpr size_t CHIP_LANES = 65536; // 256 CUs x 4 SIMDs x 64
-    constexpr size_t MAX_WAVES = 6;      // resident waves per SIMD of k_accumulate (84 VGPRs)
-    if (entries <= MSM_SEG_MIN * 4 * CHIP_LANES) return MSM_SEG_MIN; // small: at most 4 waves per SIMD of 8 entries
-    size_t seg;
-    if (entries <= MSM_SEG_DEFAULT * MAX_WAVES * CHIP_LANES) { // one round of k = 4..6 full waves per SIMD, <= 64 entries each
-        size_t k = (entries + MSM_SEG_DEFAULT * CHIP_LANES - 1) / (MSM_SEG_DEFAULT * CHIP_LANES);
-        if (k < 4) k = 4;
-        seg = (entries + k * CHIP_LANES - 1) / (k * CHIP_LANES);
-    } else { // whole rounds of MAX_WAVES waves per SIMD, ~64 entries each
-        const size_t per_round = MSM_SEG_DEFAULT * MAX_WAVES * CHIP_LANES;
-        size_t rounds = (entries + per_round / 2) / per_round;
-        if (rounds < 1) rounds = 1;
-        seg = (entries + rounds * MAX_WAVES * CHIP_LANES - 1) / (rounds * MAX_WAVES * CHIP_LANES);
-    }
-    while (entries / seg > buckets * 32 && entries / seg > (size_t)1048576) seg *= 2; // <= 32 pieces per average bucket
-    return (uint32_t)seg;
+    for (int k = 0; k < MSM_NUM_WIDTHS; k++)
+        if (MSM_WIDTHS[k] == c) return k;
+    return -1;
 }
-
-template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L)
+int msm_windows_for(int c)
 {
-    using K = MsmCfg<C>;
-    L.entries = n * K::windows;
-    L.seg = msm_seg_len(L.entries, K::buckets);
-    L.lanes = (L.entries + L.seg - 1) / L.seg;
-    size_t tmp = 0;
-#ifdef BBG_ROCPRIM_SORT
-    if (library_sort) { // only the A/B path (msm_sort = 0) needs rocPRIM's temporary storage: the default path neither queries nor reserves it
-        rocprim::double_buffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, dk, dv, L.entries, 0u, (unsigned)C);
-        if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs(size query)", __FILE__, __LINE__);
+    switch (c) {
+#define X(c) case c: return MsmCfg<c>::windows;
+        BBG_MSM_WIDTHS(X)
+#undef X
     }
-#else
-    (void)library_sort;
-#endif
-    L.sort_bytes = tmp;
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    L.off_keys0 = take(L.entries * 4);
-    L.off_keys1 = take(L.entries * 4);
-    L.off_vals0 = take(L.entries * 4);
-    L.off_vals1 = take(L.entries * 4);
-    L.off_sort = take(L.sort_bytes);
-    L.off_parts = take(3 * SORT_PAD * 4);
-    for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
-        L.off_offsets[k] = take(((size_t)K::buckets + 2) * 4);
-        L.off_head[k] = take(L.lanes * sizeof(Xyzz));
-        L.off_tail[k] = take(L.lanes * sizeof(Xyzz));
-        L.off_buckets[k] = take((size_t)K::buckets * sizeof(Xyzz));
-        L.off_rows[k] = take(((size_t)(1 << K::log_rows) + MSM_MAX_PLANES) * sizeof(Xyzz)); // row sums + bit planes
-        L.off_cols[k] = take((size_t)(1 << K::log_cols) * sizeof(Xyzz));
-        L.off_long[k] = take(((size_t)K::buckets + 1) * 4);
-    }
-    L.total = o;
-    return BBG_OK;
+    return 0;
 }
-
-int msm_windows_for(int c) { return c == 20 ? MsmCfg<20>::windows : MsmCfg<16>::windows; }
-
-// Window width for an n-term MSM (0 = automatic).  2^19 buckets cost ~0.25 ms of extra reduction and sort work against
-// 19 % fewer mixed additions.  Measured (interleaved A/B, pipelined, profiles/r01_msm_size_sweep.txt): n = 2^20 1.70 vs
-// 1.75 ms MSM-only but 1.85 vs 1.80 ms for the MSM + NTT bench step (the longer reduce phase competes with the NTT);
-// n = 2^21 3.03 vs 3.22 ms; n = 2^22 6.0 vs 6.5 ms.  Hence 20 bits from 2^21 terms in round 1.
-// Round 2 (reduce trees with four lanes per EC operation, combine with one; profiles/r02_reduce_ab.txt, r02_window_sweep.txt): n = 2^20
-// 1.573 vs 1.608 ms pipelined, 1.727 vs 1.741 stand-alone, and the MSM + NTT bench step 1.71 vs 1.78 ms (613 vs 588 Mscalar-mul/s); n = 2^19
-// 1.04 vs 0.90 ms.  Hence 20 bits from 2^20 terms.
-int msm_pick_window(const bbg_ctx* ctx, size_t n)
-{
-    if (ctx->msm_window == 16 || ctx->msm_window == 20) return ctx->msm_window;
-    return n >= ((size_t)1 << 20) ? 20 : 16; // r2 (one-lane combine + four-lane trees): the crossover moved from 2^21 down to 2^20
-}
-
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st)
 {
-    if (n == 0) return BBG_OK;
-    if (c == 20)
-        hipLaunchKernelGGL(k_precompute_tables<20>, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Affine*)d_points, (Affine*)d_table, n);
-    else
-        hipLaunchKernelGGL(k_precompute_tables<16>, dim3(grid_for(n, 128)), dim3(128), 0, st, (const Affine*)d_points, (Affine*)d_table, n);
-    BBG_HIP(hipGetLastError());
-    return BBG_OK;
+    switch (c) {
+#define X(c) case c: return srs_build_tables_c<c>(d_points, n, d_table, st);
+        BBG_MSM_WIDTHS(X)
+#undef X
+    }
+    set_error("srs_build_tables: window width not compiled");
+    return BBG_E_INVALID;
+}
+
+// Window width for an n-term MSM.  The trade: windows x n mixed additions against a bucket reduction (combine, row / column sums: two
+// full additions per bucket) that grows with 2^(C-1) and runs beside the NEXT call's sort -- the reference widens its buckets with n
+// for the same reason (get_optimal_bucket_width, runtime_states.hpp:9-63).  The thresholds are measured (profiles/r03_window_sweep.txt,
+// tests/tools/msm_window_sweep.py: pipelined MSMs, every compiled width, interleaved); msm_window = 0 selects them, a compiled width forces one.
+int msm_auto_window(size_t n)
+{
+    if (n >= ((size_t)1 << 23)) return 22; // 2^23: 10.9 vs 11.3 ms, 2^24: 20.2 vs 21.3 ms (22 vs 20 bits, pipelined); 2^22: 5.67 vs 5.39
+    if (n >= ((size_t)1 << 20)) return 20; // 2^20: MSM + NTT step 1.61 (20) / 1.63 (19) / 1.67 (17) / 1.73 (16); 2^21: 2.80 vs 2.93 (19)
+    return 16;                             // 2^19: 0.95 (16) / 0.93 (19, but 0.97 in the step); 2^18: 0.56 vs 0.58 (17)
+}
+int msm_pick_window(const bbg_ctx* ctx, size_t n)
+{
+    if (ctx->msm_window && msm_width_slot(ctx->msm_window) >= 0) return ctx->msm_window;
+    return msm_auto_window(n);
 }
 
 int srs_synth_linear(bbg_ctx*, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t st)
@@ -1152,179 +295,6 @@ int srs_synth_hashed(bbg_ctx*, uint64_t seed, size_t n, void* d_points, hipStrea
     return BBG_OK;
 }
 
-template <int C>
-static int msm_run_c(bbg_ctx* ctx, const Srs& srs, const Affine* table, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
-                     hipStream_t st, const void* h_scalars)
-{
-    using K = MsmCfg<C>;
-    MsmLayout L;
-    int rc = msm_layout<C>(n, ctx->msm_sort == 0, L);
-    if (rc) return rc;
-    rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
-    if (rc) return rc;
-    if (!ctx->aux_stream) {
-        // the reduce phase is latency work that only has to finish before its result is consumed: a LOW-priority stream, so that what
-        // the caller queues next on the main stream (the following MSM's sort / accumulation, an NTT) is dispatched first
-        int least = 0, greatest = 0;
-        BBG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
-            BBG_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[k], hipStreamNonBlocking, ctx->msm_reduce_low_priority ? least : (least + greatest) / 2));
-            BBG_HIP(hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming));
-            BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
-        }
-        ctx->aux_stream = ctx->aux_streams[0];
-    }
-    if (ctx->msm_layout_n != n || ctx->msm_layout_c != C || ctx->msm_layout_sort != ctx->msm_sort) {
-        // a different (n, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
-        // regions this call is about to overwrite, so the main stream first waits for both slots (no host sync)
-        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++)
-            if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
-        ctx->msm_layout_n = n;
-        ctx->msm_layout_c = C;
-        ctx->msm_layout_sort = ctx->msm_sort;
-    }
-    const int slot = (int)(ctx->msm_seq++ % bbg_ctx::MSM_SLOTS);
-    char* base = (char*)ctx->msm.buf;
-    uint32_t* keys0 = (uint32_t*)(base + L.off_keys0);
-    uint32_t* keys1 = (uint32_t*)(base + L.off_keys1);
-    uint32_t* vals0 = (uint32_t*)(base + L.off_vals0);
-    uint32_t* vals1 = (uint32_t*)(base + L.off_vals1);
-    uint32_t* offsets = (uint32_t*)(base + L.off_offsets[slot]);
-    Xyzz* head = (Xyzz*)(base + L.off_head[slot]);
-    Xyzz* tail = (Xyzz*)(base + L.off_tail[slot]);
-    Xyzz* buckets = (Xyzz*)(base + L.off_buckets[slot]);
-    Xyzz* rows = (Xyzz*)(base + L.off_rows[slot]);
-    Xyzz* cols = (Xyzz*)(base + L.off_cols[slot]);
-    Xyzz* planes = rows + (1 << K::log_rows);
-    uint32_t* long_count = (uint32_t*)(base + L.off_long[slot]);
-    uint32_t* long_list = long_count + 1;
-    const bool overlap = ctx->msm_async_reduce;
-    hipStream_t rst = overlap ? ctx->aux_streams[slot] : st; // stream of the reduce phase
-
-    // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM MSM_SLOTS calls ago
-    if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[slot], 0));
-    const uint32_t* svals;
-    const int pieces = (h_scalars && ctx->msm_sort == 1 && n >= ((size_t)1 << 16)) ? ctx->msm_upload_pieces : 1;
-    if (h_scalars && pieces <= 1) // small n / library sort / option: one copy in front of everything
-        BBG_HIP(hipMemcpyAsync((void*)d_scalars, h_scalars, n * 32, hipMemcpyHostToDevice, st));
-    if (ctx->msm_sort == 1) {
-        // fused recode + MSD partition sort (keys0 area = 64-bit entries, vals0 = final values, keys1 head = partition tables)
-        uint64_t* entries = (uint64_t*)keys0; // keys0 and keys1 are adjacent: 2 x 4 x 16n bytes = 8 x 16n
-        uint32_t* part_count = (uint32_t*)(base + L.off_parts);
-        uint32_t* part_base = part_count + SORT_PAD;
-        uint32_t* cursor = part_count + 2 * SORT_PAD;
-        const int nblk = grid_for(n, SORT_BLOCK);
-        {
-            ProfScope ps(ctx, "msm_recode", st);
-            BBG_HIP(hipMemsetAsync(part_count, 0, SORT_PAD * 4, st));
-            if (pieces > 1) {
-                // The counting pass is a histogram (global atomics): it does not care in which order, or in how many launches, it
-                // sees the scalars.  So the 32n bytes travel in pieces on their own stream and each piece is counted as soon as it has
-                // landed -- the only part of the MSM that can start before ALL scalars are there (the scatter needs the totals).
-                if (!ctx->upload_stream) {
-                    BBG_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
-                    BBG_HIP(hipEventCreateWithFlags(&ctx->ev_upload_go, hipEventDisableTiming));
-                    for (int k = 0; k < bbg_ctx::UPLOAD_PIECES; k++) BBG_HIP(hipEventCreateWithFlags(&ctx->ev_upload[k], hipEventDisableTiming));
-                }
-                BBG_HIP(hipEventRecord(ctx->ev_upload_go, st)); // whatever `st` still does with the staging area comes first
-                BBG_HIP(hipStreamWaitEvent(ctx->upload_stream, ctx->ev_upload_go, 0));
-                const size_t blocks_per_piece = ((size_t)nblk + pieces - 1) / pieces;
-                for (int k = 0; k < pieces; k++) {
-                    const size_t lo = (size_t)k * blocks_per_piece * SORT_BLOCK;
-                    if (lo >= n) break;
-                    const size_t len = n - lo < blocks_per_piece * SORT_BLOCK ? n - lo : blocks_per_piece * SORT_BLOCK;
-                    BBG_HIP(hipMemcpyAsync((char*)d_scalars + lo * 32, (const char*)h_scalars + lo * 32, len * 32, hipMemcpyHostToDevice,
-                                           ctx->upload_stream));
-                    BBG_HIP(hipEventRecord(ctx->ev_upload[k], ctx->upload_stream));
-                    BBG_HIP(hipStreamWaitEvent(st, ctx->ev_upload[k], 0));
-                    hipLaunchKernelGGL(k_sortA_count<C>, dim3(grid_for(len, SORT_BLOCK)), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars + lo, len,
-                                       part_count);
-                }
-            } else {
-                hipLaunchKernelGGL(k_sortA_count<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, part_count);
-            }
-            hipLaunchKernelGGL(k_sortA_scan<C>, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets);
-        }
-        {
-            ProfScope ps(ctx, "msm_sort", st);
-            hipLaunchKernelGGL(k_sortA_scatter<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, from, cursor, entries);
-            hipLaunchKernelGGL(k_sortB<C>, dim3(K::parts), dim3(1024), 0, st, entries, part_base, offsets, vals0);
-        }
-        svals = vals0;
-    } else {
-#ifdef BBG_ROCPRIM_SORT
-        {
-            ProfScope ps(ctx, "msm_recode", st);
-            hipLaunchKernelGGL(k_recode<C>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
-        }
-        rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
-        {
-            ProfScope ps(ctx, "msm_sort", st);
-            size_t tmp = L.sort_bytes;
-            hipError_t e = rocprim::radix_sort_pairs(base + L.off_sort, tmp, dk, dv, L.entries, 0u, (unsigned)C, st);
-            if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
-        }
-        const uint32_t* skeys = dk.current();
-        svals = dv.current();
-        {
-            ProfScope ps(ctx, "msm_offsets", st);
-            hipLaunchKernelGGL(k_offsets<C>, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
-        }
-#else
-        set_error("msm_sort = 0 needs a library built with ROCPRIM_SORT=1");
-        return BBG_E_INVALID;
-#endif
-    }
-    {
-        ProfScope ps(ctx, "msm_accumulate", st);
-        BBG_HIP(hipMemsetAsync(long_count, 0, 4, st));
-        hipLaunchKernelGGL(k_accumulate<C>, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, table,
-                           srs.n, L.seg, head, tail, buckets);
-    }
-    if (overlap) {
-        BBG_HIP(hipEventRecord(ctx->ev_acc[slot], st));
-        BBG_HIP(hipStreamWaitEvent(rst, ctx->ev_acc[slot], 0));
-    }
-    {
-        ProfScope ps(ctx, "msm_reduce", rst);
-        // msm_reduce_quad: bit 0 combine, bit 1 row/column sums, bit 2 bit planes, bit 3 plane sum -- each stage either with four lanes per EC
-        // operation (curve_quad.hip.h: the same chain, ~3x shorter in time) or with one (the round-1 kernels, kept for A/B)
-        const int quad = ctx->msm_reduce_quad;
-        if (quad & 1) {
-            if (L.lanes > (size_t)2 * K::buckets)
-                hipLaunchKernelGGL(k_combine_lanes_q<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst,
-                                   offsets, L.seg, head, tail, buckets, long_count, long_list);
-            else
-                hipLaunchKernelGGL(k_combine_q<C>, dim3(grid_for((size_t)K::buckets * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail,
-                                   buckets, long_count, long_list);
-            hipLaunchKernelGGL(k_combine_long_q<C>, dim3(256), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
-        } else {
-            if (L.lanes > (size_t)2 * K::buckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
-                hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
-                                   L.seg, head, tail, buckets, long_count, long_list);
-            else
-                hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
-                                   buckets, long_count, long_list);
-            hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
-        }
-        // 64 logical lanes per row / column (measured against 128 / 32 / 16: reduce phase 0.458 / 0.49 / 0.53 / 0.55 ms at 2^20 stand-alone,
-        // 0.154 / 0.165 / 0.164 / 0.184 at 2^10; bench step equal for 64 and 128, worse below)
-        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, 64>), dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
-        else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
-        if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
-        else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
-        if (quad & 8) hipLaunchKernelGGL(k_final_sum_q, dim3(1), dim3(4 * MSM_MAX_PLANES), 0, rst, planes, (int)K::planes, (Jacobian*)d_out_jac);
-        else hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, rst, planes, (int)K::planes, (Jacobian*)d_out_jac);
-    }
-    if (overlap) {
-        BBG_HIP(hipEventRecord(ctx->ev_done[slot], rst));
-        ctx->ev_done_valid[slot] = true;
-    }
-    BBG_HIP(hipGetLastError());
-    return BBG_OK;
-}
-
-
 int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st, const void* h_scalars)
 {
     if (from > srs.n || n > srs.n - from) {
@@ -1342,8 +312,16 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
         BBG_HIP(hipStreamSynchronize(st));
         return BBG_OK;
     }
-    const int c = msm_pick_window(ctx, n);
-    void*& table = c == 20 ? srs.table20 : srs.table16;
+    int c = msm_pick_window(ctx, n);
+    if (!ctx->msm_window && !srs.tables[msm_width_slot(c)] && n * 4 <= srs.n) {
+        // a short MSM over a long SRS (automatic width only): the width chosen for n has no table yet and building one costs
+        // windows x srs.n x 64 bytes for a call that touches a fraction of it -- use the resident table whose width is nearest instead
+        int best = -1;
+        for (int k = 0; k < MSM_NUM_WIDTHS; k++)
+            if (srs.tables[k] && (best < 0 || abs(MSM_WIDTHS[k] - c) < abs(MSM_WIDTHS[best] - c))) best = k;
+        if (best >= 0) c = MSM_WIDTHS[best];
+    }
+    void*& table = srs.tables[msm_width_slot(c)];
     if (!table) { // first MSM of this width on this SRS: build its window tables from the plain points (one-off)
         hipError_t e = hipMalloc(&table, srs.n * (size_t)msm_windows_for(c) * sizeof(Affine));
         if (e != hipSuccess) {
@@ -1357,8 +335,13 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
             return rc;
         }
     }
-    if (c == 20) return msm_run_c<20>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st, h_scalars);
-    return msm_run_c<16>(ctx, srs, (const Affine*)table, d_scalars, from, n, d_out_jac, st, h_scalars);
+    switch (c) {
+#define X(c) case c: return msm_run_c<c>(ctx, srs, table, d_scalars, from, n, d_out_jac, st, h_scalars);
+        BBG_MSM_WIDTHS(X)
+#undef X
+    }
+    set_error("bbg_msm: window width not compiled");
+    return BBG_E_INVALID;
 }
 
 // makes the context stream wait for every reduce phase queued on the auxiliary stream (no host sync)

@@ -1,0 +1,49 @@
+// Compile-time configuration of the bucket MSM (msm_kernels.hip.h) and the entry points every window width instantiates.
+#pragma once
+#include "bbg_internal.h"
+
+namespace bbg {
+
+// A configuration is named by its widest window C (the bucket count is 2^(C-1)) and is a per-call choice among the compiled ones
+// (msm_pick_window, BBG_MSM_WIDTHS below): C = 16 (16 windows, 2^15 buckets) ... C = 22 (12 windows, 2^21 buckets).  Wider windows trade mixed
+// additions (windows x n of them) for a bucket reduction that grows with 2^(C-1); the automatic rule follows n the way the reference's
+// bucket width does (runtime_states.hpp:9-63).
+//
+// BALANCED windows: the scalar has 254 bits and the signed recoding needs one more for its carry, so W = ceil(255 / C) windows must cover
+// exactly 255 bits: the first `nwide` windows are C bits wide, the others C - 1 (C = 20: 8 x 20 + 5 x 19; C = 22: 3 x 22 + 9 x 21; C = 17:
+// 15 x 17).  Cutting W windows of C bits from the bottom instead leaves a top window with a handful of bits (C = 19: 7, C = 22: 12) whose n
+// digits all land in the first few buckets -- one partition of the sort then holds n entries and its single block runs for a millisecond
+// (measured, profiles/r03_window_sweep_a.txt).  Widths whose W equals a narrower width's (18 -> 17, 21 -> 20) are pointless and not compiled.
+// Each configuration has its own window tables T[w][i] = 2^(offset(w)) P_i, built the first time it is used on an SRS, and its own
+// translation unit (msm_wNN.hip) so that the configurations compile side by side.
+template <int C> struct MsmCfg {
+    static constexpr int c = C;
+    static constexpr int windows = (254 + C) / C;           // C * windows >= 255
+    static constexpr int nwide = 255 - windows * (C - 1);   // windows [0, nwide) have C bits, the rest C - 1
+    static_assert(nwide >= 1 && nwide <= windows, "use the narrower configuration with the same number of windows");
+    static constexpr int width(int w) { return w < nwide ? C : C - 1; }
+    static constexpr int offset(int w) { return w * (C - 1) + (w < nwide ? w : nwide); } // first scalar bit of window w; offset(windows) = 255
+    static constexpr int buckets = 1 << (C - 1);       // |digit| in [1, 2^(C-1)]
+    static constexpr int lo_bits = C - 11;             // sort partitions = buckets >> lo_bits (+1) = 1025; bins per partition = 2^lo_bits
+    static constexpr int parts = (buckets >> lo_bits) + 1;
+    static constexpr int log_cols = C / 2;             // bucket index (0-based) = hi * cols + lo
+    static constexpr int log_rows = C - 1 - log_cols;
+    static constexpr int planes = C - 1;               // bit planes of the weight idx + 1 <= 2^(C-1)
+};
+constexpr int MSM_MAX_WINDOWS = 16;
+constexpr int MSM_IDX_BITS = 26;     // point index bits in an entry value (n <= 2^26 per call)
+constexpr int MSM_MAX_PLANES = 32;
+
+// every width with a translation unit msm_wNN.hip (X-macro: dispatch tables in msm.hip, option parsing, table slots in Srs)
+#define BBG_MSM_WIDTHS(X) X(16) X(17) X(19) X(20) X(22)
+
+// one n-term MSM with C-bit windows over `table` (window tables of this width); defined in msm_kernels.hip.h, instantiated in msm_wNN.hip
+template <int C>
+int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st,
+              const void* h_scalars);
+// table[w * n + i] = 2^(MsmCfg<C>::offset(w)) P_i
+template <int C> int srs_build_tables_c(const void* d_points, size_t n, void* d_table, hipStream_t st);
+// the last reduce stage (sum of the bit planes -> Jacobian), shared by all widths (msm.hip)
+int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st);
+
+} // namespace bbg

@@ -116,7 +116,8 @@ def main():
     ap.add_argument("--config5-log2n", type=int, default=24)
     ap.add_argument("--no-sweeps", action="store_true", help="skip extra.host_path / extra.ntt_sweep / extra.msm_sweep (SURVEY 8d tables)")
     ap.add_argument("--reduce-priority", type=int, default=-1, help="A/B: 1 = low-priority auxiliary stream for the MSM reduce phase (library default), 0 = normal")
-    ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, 16 or 20 (A/B runs)")
+    ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, or a compiled width (A/B runs)")
+    ap.add_argument("--reduce-blocks", type=int, default=-1, help="A/B: blocks per kernel of the overlapped reduce phase's throughput stages (0 = one block per unit of work)")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +154,8 @@ def main():
         bbg.set_option("msm_window", args.msm_window)
     if args.reduce_priority >= 0:
         bbg.set_option("msm_reduce_priority", args.reduce_priority)
+    if args.reduce_blocks >= 0:
+        bbg.set_option("msm_reduce_blocks", args.reduce_blocks)
 
     # ---- setup (untimed): SRS shard resident in HBM, scalars / coefficients resident, twiddles built
     start = rank * n  # weak scaling: every rank owns n points of a world*n-point SRS
@@ -227,8 +230,8 @@ def main():
                 "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
-    msm_windows = (20 if (args.msm_window == 20 or (args.msm_window == 0 and n >= (1 << 20))) else 16)
-    msm_windows = 13.0 if msm_windows == 20 else 16.0
+    width = args.msm_window or (22 if n >= (1 << 23) else 20 if n >= (1 << 20) else 16)  # csrc/msm.hip msm_auto_window
+    msm_windows = float((254 + width) // width)
     pass_ms = avg("ntt_pass")
     ntt_alg = 64.0 * n
     ntt_passes = prof["ntt_pass"][1] / max(1, args.steps)

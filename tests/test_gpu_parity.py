@@ -14,7 +14,7 @@ import callback_engines  # tests/tools: Python stand-ins for work-queue callback
 pytestmark = pytest.mark.gpu
 
 FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
-MSM_WINDOWS = (16, 20)  # every window width libbbg.so compiles (option msm_window)
+MSM_WINDOWS = (16, 17, 19, 20, 22)  # every window width libbbg.so compiles (csrc/msm_cfg.h BBG_MSM_WIDTHS; option msm_window)
 
 
 # ---------------------------------------------------------------------------------------------- fields
@@ -446,10 +446,11 @@ def test_msm_option_matrix_is_bit_identical(pkg, oracle, bbg, srs16):
         bbg.set_option("msm_async_reduce", 0)
 
 
-def test_msm_window20_vs_oracle(pkg, oracle, bbg, golden, srs16):
-    """The 20-bit-window configuration (automatic from n = 2^20) forced at small sizes: oracle parity, `from` offsets,
+@pytest.mark.parametrize("window", [17, 19, 20, 22])
+def test_msm_wide_windows_vs_oracle(pkg, oracle, bbg, golden, srs16, window):
+    """Every wider window configuration (chosen automatically only for large n) forced at small sizes: oracle parity, `from` offsets,
     the reference's golden results and the mixed-width scalar distribution."""
-    bbg.set_option("msm_window", 20)
+    bbg.set_option("msm_window", window)
     try:
         pts = srs16.read(0, 5000)
         sc = pkg.synthetic_scalars(0xBB254 + 3, 5000)
@@ -476,7 +477,7 @@ def test_msm_async_reduce_with_changing_shapes(pkg, oracle, bbg, srs16):
     first: every result of an interleaved sequence must equal the synchronous one."""
     import torch
     sizes = [1 << 16, 1000, 1 << 15, 17, 40001, 1 << 16, 3]
-    windows = [16, 20, 16, 16, 20, 20, 16]
+    windows = [16, 20, 17, 16, 22, 19, 16]
     scal = [pkg.synthetic_scalars(900 + i, n) for i, n in enumerate(sizes)]
     want = []
     for sc, w in zip(scal, windows):
@@ -545,7 +546,7 @@ def test_msm_2_22_properties_wide_windows(pkg, oracle, bbg, golden):
     sc20 = pkg.synthetic_scalars(rec["scalar_seed"], 1 << 20)
     want = unhex(rec["result"], 8)[0]
     try:
-        for window in (16, 20):
+        for window in MSM_WINDOWS:
             bbg.set_option("msm_window", window)
             assert np.array_equal(oracle.jac_to_affine(bbg.msm(srs, sc20)), want), window
     finally:
