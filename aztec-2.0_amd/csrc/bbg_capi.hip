@@ -228,6 +228,10 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_reduce_quad = (int)value & 15;
         return BBG_OK;
     }
+    if (!strcmp(key, "quotient_fuse")) {
+        ctx->quotient_fuse = value != 0;
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_reduce_blocks")) {
         if (value < 0 || value > 65535) { set_error("msm_reduce_blocks must be 0 (one block per unit of work) .. 65535"); return BBG_E_INVALID; }
         ctx->msm_reduce_blocks = (int)value;

@@ -338,6 +338,79 @@ __global__ void __launch_bounds__(256) k_quotient_turbo_logic(QuotientArgs a)
     fe_store<FrP>(a.quotient + i, fe_add(q, fe_mul(id, QLOAD(QP_QLOGIC, i))));
 }
 
+// ---- arithmetic + range + logic in ONE pass over the wires (TurboPLONK round 4): the three cheapest transition widgets are memory-bound
+// on their own (each reads the four wire columns -- range and logic the shifted rows as well -- and read-modify-writes the quotient:
+// 0.57 + 0.66 + 0.64 ms at 4n = 2^22, profiles/r02_prover_kernel_stats_v3.txt); fused, the wires, their shifted rows, q_c and the
+// quotient are touched once.  Same identities, same alpha powers: each part takes its own set-up block (the alpha_base chain of
+// execute_fourth_round, prover.cpp:304-319, runs over the set-up kernels only), and field addition does not care about the order.
+__global__ void __launch_bounds__(256) k_quotient_turbo_arith_range_logic(QuotientArgs a, const QuotientSetup* s_range, const QuotientSetup* s_logic)
+{
+    const QuotientSetup& s = *a.s; // arithmetic widget's block; alpha and the small constants are the same in all three
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > a.mask) return;
+    const uint32_t ish = (i + 4) & a.mask;
+    const Fr w1 = QLOAD(QP_W1, i), w2 = QLOAD(QP_W2, i), w3 = QLOAD(QP_W3, i), w4 = QLOAD(QP_W4, i);
+    const Fr w4n = QLOAD(QP_W4, ish);
+    const Fr qc = QLOAD(QP_QC, i);
+    Fr total;
+    { // arithmetic (k_quotient_turbo_arith)
+        const Fr qa = QLOAD(QP_QARITH, i);
+        Fr gate = fe_mul(fe_mul(w1, w2), QLOAD(QP_QM, i));
+        gate = fe_add(gate, fe_mul(w1, QLOAD(QP_Q1, i)));
+        gate = fe_add(gate, fe_mul(w2, QLOAD(QP_Q2, i)));
+        gate = fe_add(gate, fe_mul(w3, QLOAD(QP_Q3, i)));
+        gate = fe_add(gate, fe_mul(w4, QLOAD(QP_Q4, i)));
+        gate = fe_add(gate, qc);
+        Fr t = fe_mul(fe_sub(fe_sqr(w4), w4), fe_sub(w4, s.c2));
+        t = fe_mul(fe_mul(t, s.alpha), QLOAD(QP_Q5, i));
+        gate = fe_mul(fe_add(gate, t), qa);
+        const Fr d = fe_sub(w3, x4(w4));
+        const Fr d2 = fe_sqr(d);
+        Fr h = fe_add(x4(d), x4(d));
+        h = fe_sub(fe_add(h, d), fe_add(d2, d2));
+        h = fe_mul(fe_sub(h, s.c7), d);
+        h = fe_mul(h, fe_sub(fe_sqr(qa), qa));
+        total = fe_mul(fe_add(gate, h), s.ap[0]);
+    }
+    { // range (k_quotient_turbo_range)
+        const QuotientSetup& r = *s_range;
+        Fr sum = fe_mul(quad_check(fe_sub(w3, x4(w4)), s), r.ap[0]);
+        sum = fe_add(sum, fe_mul(quad_check(fe_sub(w2, x4(w3)), s), r.ap[1]));
+        sum = fe_add(sum, fe_mul(quad_check(fe_sub(w1, x4(w2)), s), r.ap[2]));
+        sum = fe_add(sum, fe_mul(quad_check(fe_sub(w4n, x4(w1)), s), r.ap[3]));
+        total = fe_add(total, fe_mul(sum, QLOAD(QP_QRANGE, i)));
+    }
+    { // logic (k_quotient_turbo_logic)
+        const QuotientSetup& l = *s_logic;
+        const Fr qa = fe_sub(QLOAD(QP_W1, ish), x4(w1));
+        const Fr qb = fe_sub(QLOAD(QP_W2, ish), x4(w2));
+        const Fr qcq = fe_sub(w4n, x4(w4));
+        const Fr sum = fe_add(qa, qb);
+        Fr id = fe_sub(fe_mul(qa, qb), w3);
+        id = fe_mul(fe_add(id, id), s.alpha);
+        id = fe_mul(fe_add(id, quad_check(qa, s)), s.alpha);
+        id = fe_mul(fe_add(id, quad_check(qb, s)), s.alpha);
+        const Fr sum3 = fe_add(fe_add(sum, sum), sum), sum9 = fe_add(fe_add(sum3, sum3), sum3);
+        const Fr sum18 = fe_add(sum9, sum9);
+        Fr sum81 = x4(sum18);
+        sum81 = fe_add(sum81, sum9);
+        const Fr sq = fe_add(fe_sqr(qa), fe_sqr(qb));
+        const Fr sq3 = fe_add(fe_add(sq, sq), sq), sq9 = fe_add(fe_add(sq3, sq3), sq3);
+        const Fr sq18 = fe_add(sq9, sq9);
+        Fr e = fe_add(fe_sub(x4(w3), sum18), s.c81);
+        e = fe_mul(e, w3);
+        e = fe_add(e, fe_add(fe_sub(sq18, sum81), s.c83));
+        e = fe_mul(e, w3);
+        const Fr c3 = fe_add(fe_add(qcq, qcq), qcq), c9 = fe_add(fe_add(c3, c3), c3);
+        Fr tail = fe_sub(fe_add(c3, sum3), fe_add(e, e));
+        tail = fe_add(tail, fe_mul(fe_sub(c9, sum3), qc));
+        id = fe_mul(fe_add(id, tail), l.ap[0]);
+        total = fe_add(total, fe_mul(id, QLOAD(QP_QLOGIC, i)));
+    }
+    const Fr q = fe_load<FrP>(a.quotient + i);
+    fe_store<FrP>(a.quotient + i, fe_add(q, total));
+}
+
 // ---------------------------------------------------------------------------------------------- permutation grand product
 // z of ProverPermutationWidget<W,false>::compute_round_commitments (permutation_widget_impl.hpp:48-268, steps 1-3; the blinding of
 // the last rows and the ifft stay with the caller):
@@ -669,12 +742,29 @@ int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const vo
     a.mask = (uint32_t)(((size_t)1 << log2_large) - 1);
     a.dc = (const DomainConsts*)dc;
     const size_t m = (size_t)1 << log2_large;
+    // the alpha_base chain runs over the set-up kernels alone (block w reads the alpha_out of block w - 1), so the widget kernels behind
+    // them may run in any order and share passes: arithmetic + range + logic of a TurboPLONK chain go through the data once
+    int pos_arith = -1, pos_range = -1, pos_logic = -1;
     for (int w = 0; w < count; w++) {
         const Fr* prev = w ? &setups[w - 1].alpha_out[widgets[w - 1]] : nullptr;
         hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setups + w, ch, prev);
+        if (widgets[w] == 1 && pos_arith < 0) pos_arith = w;
+        if (widgets[w] == 3 && pos_range < 0) pos_range = w;
+        if (widgets[w] == 4 && pos_logic < 0) pos_logic = w;
+    }
+    // a widget that ASSIGNS the quotient (the permutation widgets) must come first; the prover's chains start with it
+    const bool fuse = ctx->quotient_fuse && pos_arith > 0 && pos_range > 0 && pos_logic > 0 && (widgets[0] == 0 || widgets[0] == 5);
+    for (int w = 0; w < count; w++) {
+        if (fuse && (w == pos_arith || w == pos_range || w == pos_logic)) continue;
         a.s = setups + w;
         rc = launch_widget(ctx, widgets[w], a, m, st);
         if (rc) return rc;
+    }
+    if (fuse) {
+        ProfScope ps(ctx, "quotient_widget", st);
+        a.s = setups + pos_arith;
+        hipLaunchKernelGGL(k_quotient_turbo_arith_range_logic, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, setups + pos_range, setups + pos_logic);
+        BBG_HIP(hipGetLastError());
     }
     if (alpha_out) {
         BBG_HIP(hipMemcpyAsync(alpha_out, &setups[count - 1].alpha_out[widgets[count - 1]], sizeof(Fr), hipMemcpyDeviceToHost, st));

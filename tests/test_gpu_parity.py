@@ -1287,6 +1287,30 @@ def test_prover_key_polynomial_replaced_on_live_handle(pkg, bbg):
     srs.free()
 
 
+def test_quotient_fused_widgets_equal_separate(pkg, bbg):
+    """Round 4's fused pass (arithmetic + range + logic widgets in one kernel, option quotient_fuse = 1, default) against one kernel per
+    widget: the same quotient commitments T_1..T_4 (the byte-identical-proof tests then pin the fused path against the reference prover)."""
+    lib = bbg.lib
+    lg, n = 11, 1 << 11
+    srs = bbg.srs_synth_hashed(5, n)
+    gens = np.stack([bbg.field_op(0, 5, np.array([[k, 0, 0, 0]], dtype=np.uint64))[0] for k in (5, 5, 6, 7)])
+    h = ctypes.c_void_p()
+    assert lib.bbg_prover_create(bbg.ctx, srs.handle, lg, 4, gens.ctypes.data, ctypes.byref(h)) == 0
+    for pid in range(5, 20):
+        assert lib.bbg_prover_set_key_poly(h, pid, 0, pkg.synthetic_scalars(500 + pid, n).ctypes.data) == 0
+    assert lib.bbg_prover_finalize_key(h) == 0
+    try:
+        bbg.set_option("quotient_fuse", 0)
+        separate = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
+        bbg.set_option("quotient_fuse", 1)
+        fused = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
+    finally:
+        bbg.set_option("quotient_fuse", 1)
+    assert np.array_equal(separate, fused)
+    lib.bbg_prover_destroy(h)
+    srs.free()
+
+
 def test_prover_keeps_its_srs_alive(pkg, bbg):
     """a bbg_prover shares ownership of its SRS (bbg_srs_retain): the creator freeing its handle -- what the shim's table cache
     does when a larger table is registered at the same address -- must not pull the window tables from under the live prover."""
