@@ -123,6 +123,7 @@ def load_library():
         "bbg_multi_srs_synth_hashed": (cint, [vp, ctypes.c_uint64, sz]),
         "bbg_multi_srs_num_points": (sz, [vp]),
         "bbg_multi_msm": (cint, [vp, vp, sz, sz, vp]),
+        "bbg_multi_set_option": (cint, [vp, ctypes.c_char_p, ctypes.c_long]),
         "bbg_multi_ntt_device": (cint, [vp, vp, ctypes.c_uint, cint]),
         "bbg_multi_ntt": (cint, [vp, vp, ctypes.c_uint, cint]),
     }
@@ -146,7 +147,7 @@ EXPORTED_SYMBOLS = [
     "bbg_prover_create", "bbg_prover_create_flavour", "bbg_prover_destroy", "bbg_prover_set_key_poly", "bbg_prover_finalize_key", "bbg_prover_round1", "bbg_prover_round3",
     "bbg_prover_round4", "bbg_prover_evaluate", "bbg_prover_linearise", "bbg_prover_round6", "bbg_prover_read_poly",
     "bbg_multi_create", "bbg_multi_destroy", "bbg_multi_count", "bbg_multi_ctx", "bbg_multi_sync", "bbg_multi_srs_register",
-    "bbg_multi_srs_synth_hashed", "bbg_multi_srs_num_points", "bbg_multi_msm", "bbg_multi_ntt_device", "bbg_multi_ntt",
+    "bbg_multi_srs_synth_hashed", "bbg_multi_srs_num_points", "bbg_multi_msm", "bbg_multi_ntt_device", "bbg_multi_ntt", "bbg_multi_set_option",
 ]
 
 

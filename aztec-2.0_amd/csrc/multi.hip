@@ -10,10 +10,18 @@
 //         context g transforms a_{g + G j} (size m = n / G), multiplies by w_n^(g q); chunk r of every context goes to context r
 //         (peer copies over xGMI: (G-1)/G^2 of the data leaves each GPU); context r finishes with size-G DFTs across the chunks.
 //
+// Two exchange back ends, selected with bbg_multi_set_option("exchange", ...):
+//   0  peer copies (hipMemcpyPeerAsync ordered with events, never with host synchronisation between the phases) -- the default
+//   1  RCCL from C++ (north_star: "RCCL reduce/all-gather over xGMI"): one communicator per context (ncclCommInitAll over the group's
+//      devices), ncclAllGather of the 96-byte partials + the group sum on every context's own GPU, and the all-to-all as grouped
+//      ncclSend / ncclRecv; everything is enqueued on the contexts' streams, so stream order alone sequences compute and exchange.
+//      librccl.so is loaded on first use (dlopen): a single-GPU user of libbbg.so neither links nor initialises RCCL.
 // The process-per-GPU form of the same split (torch.distributed / RCCL, what bench.py --gpus N runs) is aztec-2.0_amd/parallel.py;
-// both call the same kernels.  Peer copies (hipMemcpyPeerAsync) are the natural primitive for 96-byte partials and for an
-// all-to-all inside one process; they are ordered with events, never with host synchronisation between the phases.
+// all three call the same kernels.
 #include "bbg_internal.h"
+
+#include <rccl/rccl.h> // types and prototypes only: the entry points are resolved with dlsym
+#include <dlfcn.h>
 
 #include <cstring>
 #include <thread>
@@ -37,8 +45,65 @@ struct bbg_multi {
     std::vector<hipEvent_t> ev_sent, ev_done;
     std::vector<bool> ev_done_valid;
     char* h_parts = nullptr;     // pinned: G x 96 bytes
+    // exchange back end 1: RCCL
+    bool use_rccl = false;
+    std::vector<ncclComm_t> comm;   // one per context (rank g = context g)
+    std::vector<void*> d_gather;    // MSM: G x 96 bytes on every context
+    void* d_sum = nullptr;          // MSM: the group sum on context 0
     std::mutex mu;
 };
+
+namespace {
+// librccl.so, resolved once per process
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return BBG_OK;
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { set_error(std::string("bbg_multi: cannot load librccl.so: ") + dlerror()); return BBG_E_INVALID; }
+    RcclApi a;
+    a.lib = lib;
+#define BBG_RCCL_SYM(field, name)                                                                              \
+    a.field = (decltype(a.field))dlsym(lib, name);                                                             \
+    if (!a.field) { set_error("bbg_multi: librccl.so lacks " name); dlclose(lib); return BBG_E_INVALID; }
+    BBG_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    BBG_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    BBG_RCCL_SYM(AllGather, "ncclAllGather")
+    BBG_RCCL_SYM(Send, "ncclSend")
+    BBG_RCCL_SYM(Recv, "ncclRecv")
+    BBG_RCCL_SYM(GroupStart, "ncclGroupStart")
+    BBG_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    BBG_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef BBG_RCCL_SYM
+    g_rccl = a;
+    return BBG_OK;
+}
+int rccl_fail(ncclResult_t r, const char* what)
+{
+    set_error(std::string("bbg_multi (RCCL): ") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    return BBG_E_HIP;
+}
+#define BBG_RCCL(expr)                                                                                          \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess) return rccl_fail(_r, #expr);                                                    \
+    } while (0)
+} // namespace
 
 namespace {
 
@@ -119,7 +184,7 @@ int multi_ntt_core(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
     const bool inverse = (op == BBG_IFFT || op == BBG_COSET_IFFT), coset = (op == BBG_COSET_FFT || op == BBG_COSET_IFFT);
     const unsigned log2m = log2n - (unsigned)log2G;
     const size_t mm = (size_t)1 << log2m, len = mm >> log2G;
-    if (G == 1) { // one context: the plain transform
+    if (G == 1 && !m->use_rccl) { // one context: the plain transform (with RCCL selected even a group of one goes through the exchange)
         int rc = set_dev(m->ctx[0]);
         if (rc) return rc;
         std::lock_guard<std::mutex> lk(m->ctx[0]->mu);
@@ -136,17 +201,33 @@ int multi_ntt_core(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
         hipStream_t st = c->stream;
         void* x = d_shards[g];
         // the receive buffers of the previous transform must have been consumed before anything is sent again
-        for (int r = 0; r < G; r++)
+        for (int r = 0; r < G && !m->use_rccl; r++)
             if (m->ev_done_valid[(size_t)r]) BBG_HIP(hipStreamWaitEvent(st, m->ev_done[(size_t)r], 0));
         if (coset && !inverse) rc = ntt_scale_geometric(c, x, mm, log2n, 0 /* g */, (uint64_t)G, (uint64_t)g, -1, st); // a_{g+Gj} *= gen^(g+Gj)
         if (!rc) rc = ntt_run(c, x, log2m, inverse ? BBG_IFFT : BBG_FFT, 0, nullptr, st);
         // x[q] *= w_n^(+-g q); the inverse also owes the factor 1/G (the local ifft divided by m only)
         if (!rc && (g != 0 || inverse)) rc = ntt_scale_geometric(c, x, mm, log2n, inverse ? 3 : 2, (uint64_t)g, 0, inverse ? log2G : -1, st);
         if (rc) return rc;
-        for (int r = 0; r < G; r++) // chunk r -> context r, slot g
-            BBG_HIP(hipMemcpyPeerAsync((char*)m->d_recv[(size_t)r] + (size_t)g * len * 32, m->ctx[(size_t)r]->device, (const char*)x + (size_t)r * len * 32,
-                                       c->device, len * 32, st));
-        BBG_HIP(hipEventRecord(m->ev_sent[(size_t)g], st));
+        if (!m->use_rccl) {
+            for (int r = 0; r < G; r++) // chunk r -> context r, slot g
+                BBG_HIP(hipMemcpyPeerAsync((char*)m->d_recv[(size_t)r] + (size_t)g * len * 32, m->ctx[(size_t)r]->device, (const char*)x + (size_t)r * len * 32,
+                                           c->device, len * 32, st));
+            BBG_HIP(hipEventRecord(m->ev_sent[(size_t)g], st));
+        }
+    }
+    if (m->use_rccl) {
+        // the all-to-all as ONE group of point-to-point operations (xGMI is point-to-point: every pair has its own links): rank g sends
+        // chunk r of its shard to rank r and receives rank r's chunk g into slot r.  Enqueued on the contexts' streams: behind the
+        // local transform, ahead of the cross DFT -- and behind the previous transform's cross DFT, which read the same receive buffer.
+        BBG_RCCL(g_rccl.GroupStart());
+        for (int g = 0; g < G; g++) {
+            hipStream_t st = m->ctx[(size_t)g]->stream;
+            for (int r = 0; r < G; r++) {
+                BBG_RCCL(g_rccl.Send((const char*)d_shards[g] + (size_t)r * len * 32, len * 32, ncclUint8, r, m->comm[(size_t)g], st));
+                BBG_RCCL(g_rccl.Recv((char*)m->d_recv[(size_t)g] + (size_t)r * len * 32, len * 32, ncclUint8, r, m->comm[(size_t)g], st));
+            }
+        }
+        BBG_RCCL(g_rccl.GroupEnd());
     }
     // phase 2: size-G DFT across the received chunks, the coset_ifft post-scaling, result back into the shard
     for (int r = 0; r < G; r++) {
@@ -155,7 +236,8 @@ int multi_ntt_core(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
         if (rc) return rc;
         std::lock_guard<std::mutex> lk(c->mu);
         hipStream_t st = c->stream;
-        for (int g = 0; g < G; g++) BBG_HIP(hipStreamWaitEvent(st, m->ev_sent[(size_t)g], 0));
+        if (!m->use_rccl)
+            for (int g = 0; g < G; g++) BBG_HIP(hipStreamWaitEvent(st, m->ev_sent[(size_t)g], 0));
         rc = ntt_cross_dft(c, m->d_recv[(size_t)r], m->d_out[(size_t)r], (unsigned)log2G, len, log2n, inverse ? 1 : 0, st);
         if (rc) return rc;
         BBG_HIP(hipEventRecord(m->ev_done[(size_t)r], st));
@@ -169,9 +251,87 @@ int multi_ntt_core(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
     return BBG_OK;
 }
 
+void multi_release_rccl(bbg_multi* m)
+{
+    for (size_t g = 0; g < m->comm.size(); g++)
+        if (m->comm[g] && g_rccl.CommDestroy) {
+            if (m->ctx[g]) {
+                (void)hipSetDevice(m->ctx[g]->device);
+                (void)hipDeviceSynchronize();
+            }
+            (void)g_rccl.CommDestroy(m->comm[g]);
+        }
+    m->comm.clear();
+    for (size_t g = 0; g < m->d_gather.size(); g++)
+        if (m->d_gather[g] && m->ctx[g]) {
+            (void)hipSetDevice(m->ctx[g]->device);
+            (void)hipFree(m->d_gather[g]);
+        }
+    m->d_gather.clear();
+    if (m->d_sum && m->ctx[0]) {
+        (void)hipSetDevice(m->ctx[0]->device);
+        (void)hipFree(m->d_sum);
+    }
+    m->d_sum = nullptr;
+    m->use_rccl = false;
+}
+// communicators over the group's devices (rank g = context g) and the all-gather buffers
+int multi_init_rccl(bbg_multi* m)
+{
+    if (!m->comm.empty()) return BBG_OK;
+    int rc = rccl_load();
+    if (rc) return rc;
+    std::vector<int> devices((size_t)m->G);
+    for (int g = 0; g < m->G; g++) devices[(size_t)g] = m->ctx[(size_t)g]->device;
+    for (int a = 0; a < m->G; a++)
+        for (int b = a + 1; b < m->G; b++)
+            if (devices[(size_t)a] == devices[(size_t)b]) {
+                set_error("bbg_multi_set_option(exchange = 1): RCCL needs one DISTINCT device per context (a device appears twice in this group)");
+                return BBG_E_INVALID;
+            }
+    m->comm.assign((size_t)m->G, nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), m->G, devices.data());
+    if (r != ncclSuccess) {
+        m->comm.clear();
+        return rccl_fail(r, "ncclCommInitAll");
+    }
+    m->d_gather.assign((size_t)m->G, nullptr);
+    for (int g = 0; g < m->G; g++) {
+        rc = set_dev(m->ctx[(size_t)g]);
+        if (rc) return rc;
+        BBG_HIP(hipMalloc(&m->d_gather[(size_t)g], (size_t)m->G * 96));
+    }
+    rc = set_dev(m->ctx[0]);
+    if (rc) return rc;
+    BBG_HIP(hipMalloc(&m->d_sum, 96));
+    return BBG_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int bbg_multi_set_option(bbg_multi* m, const char* key, long value)
+{
+    if (!m || !key) { set_error("bbg_multi_set_option: null argument"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!strcmp(key, "exchange")) {
+        if (value != 0 && value != 1) { set_error("bbg_multi_set_option: exchange must be 0 (peer copies) or 1 (RCCL)"); return BBG_E_INVALID; }
+        int rc = bbg_multi_sync(m); // pending work of the other back end first
+        if (rc) return rc;
+        if (value == 1) {
+            rc = multi_init_rccl(m);
+            if (rc) {
+                multi_release_rccl(m);
+                return rc;
+            }
+        }
+        m->use_rccl = value == 1;
+        return BBG_OK;
+    }
+    set_error("bbg_multi_set_option: unknown key");
+    return BBG_E_INVALID;
+}
 
 int bbg_multi_create(const int* devices, int count, bbg_multi** out)
 {
@@ -228,6 +388,7 @@ void bbg_multi_destroy(bbg_multi* m)
 {
     if (!m) return;
     free_srs(m);
+    multi_release_rccl(m);
     for (int g = 0; g < m->G; g++) {
         bbg_ctx* c = m->ctx[(size_t)g];
         if (!c) continue;
@@ -312,11 +473,32 @@ int bbg_multi_msm(bbg_multi* m, const uint64_t* scalars, size_t from, size_t n, 
         r = msm_run(c, m->srs[(size_t)g]->s, m->d_scal[(size_t)g], cnt ? lo - sf : 0, cnt, m->d_part[(size_t)g], st); // cnt == 0 -> infinity
         if (!r) r = msm_join(c, st);
         if (r) return r;
+        if (m->use_rccl) return (int)BBG_OK; // the partial stays on the device: the all-gather below is ordered behind it on this stream
         BBG_HIP(hipMemcpyAsync(m->h_parts + (size_t)g * 96, m->d_part[(size_t)g], 96, hipMemcpyDeviceToHost, st));
         BBG_HIP(hipStreamSynchronize(st));
         return (int)BBG_OK;
     });
     if (rc) return rc;
+    if (m->use_rccl) {
+        // "reduce" = all-gather + local group sum (RCCL has no elliptic-curve reduction operator): every context receives the G partials
+        BBG_RCCL(g_rccl.GroupStart());
+        for (int g = 0; g < m->G; g++)
+            BBG_RCCL(g_rccl.AllGather(m->d_part[(size_t)g], m->d_gather[(size_t)g], 96, ncclUint8, m->comm[(size_t)g], m->ctx[(size_t)g]->stream));
+        BBG_RCCL(g_rccl.GroupEnd());
+        bbg_ctx* c0 = m->ctx[0];
+        rc = set_dev(c0);
+        if (rc) return rc;
+        {
+            std::lock_guard<std::mutex> lkc(c0->mu);
+            rc = g1_sum_device(c0, m->d_gather[0], (size_t)m->G, m->d_sum, c0->stream); // g1_sum of the partials (c_bind.cpp:39-46)
+            if (rc) return rc;
+            BBG_HIP(hipMemcpyAsync(m->h_parts, m->d_sum, 96, hipMemcpyDeviceToHost, c0->stream));
+        }
+        rc = bbg_multi_sync(m); // every context's all-gather has completed: the partial buffers may be reused
+        if (rc) return rc;
+        memcpy(out_jacobian, m->h_parts, 96);
+        return BBG_OK;
+    }
     return bbg_g1_sum(m->ctx[0], (const uint64_t*)m->h_parts, (size_t)m->G, out_jacobian); // g1_sum of the partials (c_bind.cpp:39-46)
 }
 

@@ -300,6 +300,10 @@ void bbg_multi_destroy(bbg_multi* m);
 int bbg_multi_count(const bbg_multi* m);
 bbg_ctx* bbg_multi_ctx(bbg_multi* m, int k); /* context k of the group (for the *_device entry points on its GPU) */
 int bbg_multi_sync(bbg_multi* m);
+/* key "exchange": 0 = peer copies ordered with events (default), 1 = RCCL from C++ -- one communicator per context (ncclCommInitAll over
+ * the group's devices, which must be distinct), ncclAllGather of the 96-byte MSM partials + the group sum, the NTT's all-to-all as grouped
+ * ncclSend / ncclRecv on the contexts' streams.  librccl.so is loaded on first use.  Both back ends give identical results. */
+int bbg_multi_set_option(bbg_multi* m, const char* key, long value);
 /* Shards the SRS by point range: context g keeps points [g*ceil(n/G), (g+1)*ceil(n/G)) with their window tables resident.
  * points / stride_bytes as bbg_srs_register.  Replaces a previously registered SRS. */
 int bbg_multi_srs_register(bbg_multi* m, const uint64_t* points, size_t n, size_t stride_bytes);

@@ -134,6 +134,9 @@ bbg_multi* device_group()
     }
     if (const char* mn = std::getenv("BBG_SHIM_MULTI_MIN_POINTS")) s.multi_min = (size_t)std::strtoull(mn, nullptr, 10);
     if (devices.size() > 1 && bbg_multi_create(devices.data(), (int)devices.size(), &s.multi) != BBG_OK) fail("bbg_multi_create");
+    // BBG_SHIM_EXCHANGE=rccl: the group's exchanges (all-gather of the MSM partials) go through RCCL instead of peer copies
+    if (const char* ex = std::getenv("BBG_SHIM_EXCHANGE"))
+        if (s.multi && std::string(ex) == "rccl" && bbg_multi_set_option(s.multi, "exchange", 1) != BBG_OK) fail("bbg_multi_set_option(exchange = rccl)");
     return s.multi;
 }
 bbg_srs* upload(const g1::affine_element* points, size_t num_points)

@@ -1482,6 +1482,54 @@ def test_multi_ntt_2_24_vs_reference(pkg, oracle, bbg, G):
         M.close()
 
 
+def test_multi_rccl_exchange_backend(pkg, oracle, bbg):
+    """bbg_multi_set_option("exchange", 1): the C++ RCCL back end (ncclCommInitAll, ncclAllGather of the 96-byte partials + group sum,
+    grouped ncclSend / ncclRecv for the all-to-all).  One GPU here, so the group has ONE context: with RCCL selected even that group goes
+    through the exchange (all-gather of one partial; every chunk sent to and received from rank 0 = itself), which exercises every RCCL
+    call the multi-GPU path makes.  Results against the oracle, and equal to the peer-copy back end.  Duplicate devices are refused."""
+    import torch
+    M = _Multi(pkg, [0])
+    try:
+        n = 1 << 14
+        M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, 0xBB254, n))
+        sc = pkg.synthetic_scalars(4711, n)
+        pts = oracle.srs_hashed(0xBB254, n)
+        out = np.zeros(12, dtype=np.uint64)
+        M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
+        peer = oracle.jac_to_affine(out)
+        M.ck(M.lib.bbg_multi_set_option(M.h, b"exchange", 1))
+        M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
+        assert np.array_equal(oracle.jac_to_affine(out), peer)
+        assert np.array_equal(peer, oracle.pippenger(sc, pts))
+        M.ck(M.lib.bbg_multi_msm(M.h, sc[:1000].ctypes.data, 300, 1000, out.ctypes.data))
+        assert np.array_equal(oracle.jac_to_affine(out), oracle.pippenger(sc[:1000], pts[300:1300]))
+        lg = 12
+        a = pkg.synthetic_scalars(3100, 1 << lg)
+        for op in (FFT, IFFT, COSET_FFT, COSET_IFFT):
+            buf = a.copy()
+            M.ck(M.lib.bbg_multi_ntt(M.h, buf.ctypes.data, lg, op))
+            assert np.array_equal(oracle.canon(0, buf), oracle.ntt(a, op)), op
+            shard = torch.from_numpy(a.view(np.int64).reshape(-1).copy()).cuda()
+            torch.cuda.synchronize()
+            ptrs = (ctypes.c_void_p * 1)(shard.data_ptr())
+            M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, op))
+            M.ck(M.lib.bbg_multi_sync(M.h))
+            assert np.array_equal(oracle.canon(0, shard.cpu().numpy().view(np.uint64).reshape(-1, 4)), oracle.ntt(a, op)), op
+        M.ck(M.lib.bbg_multi_set_option(M.h, b"exchange", 0))
+        M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
+        assert np.array_equal(oracle.jac_to_affine(out), peer)
+        with pytest.raises(pkg.BbgError):
+            M.ck(M.lib.bbg_multi_set_option(M.h, b"exchange", 2))
+    finally:
+        M.close()
+    M2 = _Multi(pkg, [0, 0])
+    try:
+        with pytest.raises(pkg.BbgError, match="DISTINCT"):
+            M2.ck(M2.lib.bbg_multi_set_option(M2.h, b"exchange", 1))
+    finally:
+        M2.close()
+
+
 def test_multi_rejects_bad_groups(pkg, bbg):
     M = _Multi(pkg, [0, 0, 0])
     a = pkg.synthetic_scalars(1, 64)
