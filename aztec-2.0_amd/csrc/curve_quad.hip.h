@@ -110,6 +110,40 @@ __device__ __forceinline__ Xyzz xyzz_add_q4(const Xyzz& a, const Xyzz& b, int q)
     return r;
 }
 
+// a + p, p affine (madd-2008-s), complete like xyzz_madd; same contract as xyzz_add_q4 (all four lanes pass the same operands).  Depth 4:
+//     {U2 = x2 ZZ1, S2 = y2 ZZZ1}  ->  {P^2, R^2}  ->  {P PP, X1 PP, ZZ1 PP}  ->  {R (Q - X3), Y1 PPP, ZZZ1 PPP}
+// (two or three of the four lanes carry a product per step; the others repeat a neighbour's so that no lane diverges).  Used by the
+// accumulation of SMALL MSMs, whose run time is the latency of one lane's chain of mixed additions (msm_kernels.hip.h).
+__device__ __forceinline__ Xyzz xyzz_madd_q4(const Xyzz& a, const Affine& p, int q)
+{
+    if (aff_is_inf(p)) return a; // operands are identical in the four lanes: every branch is uniform across the quad
+    if (xyzz_is_inf(a)) return xyzz_from_affine(p);
+    const QuadRole w = quad_role(q);
+    // step 1: U2 | S2 | U2 | S2
+    Fq m = fe_mul(quad_pick2(w.odd, p.x, p.y), quad_pick2(w.odd, a.zz, a.zzz));
+    const Fq U2 = quad_bcast<0>(m), S2 = quad_bcast<1>(m);
+    const Fq P = fe_sub(U2, a.x), R = fe_sub(S2, a.y);
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) return xyzz_dbl_q4(xyzz_from_affine(p), q);
+        return xyzz_inf();
+    }
+    // step 2: P^2 | R^2 | P^2 | R^2
+    const Fq pr = quad_pick2(w.odd, P, R);
+    m = fe_mul(pr, pr);
+    const Fq PP = quad_bcast<0>(m), RR = quad_bcast<1>(m);
+    // step 3: PPP = P PP | Q = X1 PP | ZZ3 = ZZ1 PP | (Q again)
+    m = fe_mul(quad_pick(w, P, a.x, a.zz, a.x), PP);
+    const Fq PPP = quad_bcast<0>(m), Q = quad_bcast<1>(m), ZZ3 = quad_bcast<2>(m);
+    Xyzz r;
+    r.x = fe_sub(fe_sub(RR, PPP), fe_dbl(Q));
+    // step 4: R (Q - X3) | Y1 PPP | ZZZ3 = ZZZ1 PPP | (Y1 PPP again)
+    m = fe_mul(quad_pick(w, R, a.y, a.zzz, a.y), quad_pick(w, fe_sub(Q, r.x), PPP, PPP, PPP));
+    r.y = fe_sub(quad_bcast<0>(m), quad_bcast<1>(m));
+    r.zz = ZZ3;
+    r.zzz = quad_bcast<2>(m);
+    return r;
+}
+
 // (p0 + p1) + (p2 + p3) for the four DIFFERENT points p held by the lanes of a quad; every lane receives the sum
 __device__ __forceinline__ Xyzz quad_sum4(const Xyzz& p, int q)
 {

@@ -50,6 +50,29 @@ __global__ void k_check(int* bad)
     c = xyzz_dbl_q4(xyzz_dbl_q4(c, q), q);
     cs = xyzz_dbl(xyzz_dbl(cs));
     if (!same_point(c, cs)) fails |= 32;
+    { // mixed additions (xyzz_madd_q4, the small-MSM accumulation): general case, acc = inf, P = acc (doubling), P = -acc, P = inf, a chain
+        Affine pb;
+        {
+            const Fq izz = fq_invert(fe_mul(b.zz, b.zzz));
+            pb.x = fe_reduce_once(fe_mul(b.x, fe_mul(izz, b.zzz)));
+            pb.y = fe_reduce_once(fe_mul(b.y, fe_mul(izz, b.zz)));
+        }
+        if (!same_point(xyzz_madd_q4(a, pb, q), xyzz_madd(a, pb))) fails |= 0x1000;
+        if (!same_point(xyzz_madd_q4(xyzz_inf(), pb, q), xyzz_from_affine(pb))) fails |= 0x2000;
+        if (!same_point(xyzz_madd_q4(b, pb, q), xyzz_dbl(b))) fails |= 0x4000;
+        Affine nb = pb;
+        nb.y = fe_neg(pb.y);
+        if (!xyzz_is_inf(xyzz_madd_q4(b, nb, q))) fails |= 0x8000;
+        if (!same_point(xyzz_madd_q4(a, aff_inf(), q), a)) fails |= 0x10000;
+        Xyzz c2 = xyzz_inf(), c2s = xyzz_inf();
+        for (int k = 0; k < 5; k++) {
+            c2 = xyzz_madd_q4(c2, k & 1 ? nb : pb, q);
+            c2s = xyzz_madd(c2s, k & 1 ? nb : pb);
+            c2 = xyzz_madd_q4(xyzz_add_q4(c2, a, q), pb, q);
+            c2s = xyzz_madd(xyzz_add(c2s, a), pb);
+        }
+        if (!same_point(c2, c2s)) fails |= 0x20000;
+    }
     if (fails) atomicOr(bad, fails);
 }
 // the shapes msm.hip's reduce kernels use: quads of one wave taking different branches, a runtime-length doubling chain run by quad 0 only
@@ -113,6 +136,8 @@ int main()
     hipMalloc(&d_bad, 4);
     hipMemcpy(d_bad, &bad, 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_check, dim3(8), dim3(256), 0, 0, d_bad);
+    hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost); // (the per-t passes below reuse the flag word)
+    printf("k_check (add / dbl / madd, all lanes) mask 0x%x\n", bad);
     Xyzz* d_out;
     hipMalloc(&d_out, sizeof(Xyzz));
     for (int t = 0; t < 15; t++) {
