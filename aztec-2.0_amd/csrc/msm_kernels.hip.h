@@ -273,9 +273,9 @@ constexpr int SORTB_CAP = SORTB_PER_THREAD * 1024; // 72 KiB of staging (+ the c
 constexpr int SORTB_UNROLL = 8;
 
 // exclusive scan of cnt[0 .. BINS) into excl[0 .. BINS) by a 1024-thread block (thread t owns bins t*BPT .. t*BPT + BPT - 1); wsum = 16 words
-template <int BINS> __device__ __forceinline__ void block_scan_bins(const uint32_t* cnt, uint32_t* excl, uint32_t* wsum)
+template <int BINS, int TPB> __device__ __forceinline__ void block_scan_bins(const uint32_t* cnt, uint32_t* excl, uint32_t* wsum)
 {
-    constexpr int BPT = BINS > 1024 ? BINS / 1024 : 1;
+    constexpr int BPT = BINS > TPB ? BINS / TPB : 1;
     const int tid = threadIdx.x;
     uint32_t c[BPT], tot = 0;
 #pragma unroll
@@ -302,30 +302,33 @@ template <int BINS> __device__ __forceinline__ void block_scan_bins(const uint32
     }
 }
 
-template <int C> __global__ void __launch_bounds__(1024)
+// TPB threads per block: 1024, or 256 for small MSMs (partitions of a few hundred entries: a 1024-thread block per partition spends its time
+// in barriers and scans -- 25 us of a 2^12-term MSM's 270).
+template <int C, int TPB> __global__ void __launch_bounds__(TPB)
 k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_base, uint32_t* offsets, uint32_t* svals)
 {
     constexpr int SORT_LO_BITS = MsmCfg<C>::lo_bits, MSM_BUCKETS = MsmCfg<C>::buckets, BINS = 1 << SORT_LO_BITS;
     constexpr uint32_t SORT_LO_MASK = BINS - 1;
-    static_assert(BINS <= 2048, "LDS: three counter arrays of BINS words beside the 72 KiB stage");
+    constexpr int CAP = SORTB_PER_THREAD * TPB; // fast-path capacity and LDS stage
+    static_assert(BINS <= 2048 && BINS <= 8 * TPB, "LDS: three counter arrays of BINS words beside the stage; at most 8 bins per thread");
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t off[BINS];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t stage[SORTB_CAP];
+    __shared__ uint32_t stage[CAP];
     const int tid = threadIdx.x;
     const uint32_t h = blockIdx.x;
     const uint32_t pb = part_base[h], pe = part_base[h + 1];
     const uint32_t len = pe - pb;
-    const bool fast = len <= (uint32_t)SORTB_CAP;
-    for (int b = tid; b < BINS; b += 1024) hist[b] = 0;
+    const bool fast = len <= (uint32_t)CAP;
+    for (int b = tid; b < BINS; b += TPB) hist[b] = 0;
     __syncthreads();
     uint64_t e[SORTB_PER_THREAD];
-    constexpr uint32_t CHUNK = 1024 * SORTB_UNROLL;
+    constexpr uint32_t CHUNK = TPB * SORTB_UNROLL;
     const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loops (lds_take is wave-cooperative)
     if (fast) {
 #pragma unroll
         for (int u = 0; u < SORTB_PER_THREAD; u++) {
-            const uint32_t q = u * 1024 + tid;
+            const uint32_t q = u * TPB + tid;
             const uint64_t v = entries[pb + (q < len ? q : 0u)]; // unconditional: the loads batch up
             e[u] = q < len ? v : ~0ull;
         }
@@ -336,7 +339,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
             uint32_t key[SORTB_UNROLL];
 #pragma unroll
             for (int u = 0; u < SORTB_UNROLL; u++) {
-                const uint32_t q = q0 + u * 1024 + tid;
+                const uint32_t q = q0 + u * TPB + tid;
                 const uint32_t k = (uint32_t)(entries[pb + (q < len ? q : 0u)] >> 32);
                 key[u] = q < len ? k : 0xffffffffu;
             }
@@ -345,9 +348,9 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
         }
     }
     __syncthreads();
-    block_scan_bins<BINS>(hist, off, wsum); // off[b] = entries of this partition in bins below b
+    block_scan_bins<BINS, TPB>(hist, off, wsum); // off[b] = entries of this partition in bins below b
     __syncthreads();
-    for (int b = tid; b < BINS; b += 1024) {
+    for (int b = tid; b < BINS; b += TPB) {
         const uint32_t bucket = (h << SORT_LO_BITS) + (uint32_t)b;
         if (bucket <= (uint32_t)MSM_BUCKETS) offsets[bucket] = pb + off[b];
     }
@@ -360,7 +363,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
             if (on) stage[pos] = (uint32_t)e[u];
         }
         __syncthreads();
-        for (uint32_t q = tid; q < len; q += 1024) svals[pb + q] = stage[q];
+        for (uint32_t q = tid; q < len; q += TPB) svals[pb + q] = stage[q];
     } else {
         // Large partition: chunks of 8192 entries are grouped by bucket in LDS and written out as runs (one run per bucket
         // and chunk, on consecutive addresses) instead of 8192 independent 4-byte stores.  off[] = running global position
@@ -369,22 +372,22 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
         __shared__ uint32_t cstart[BINS];
         uint32_t* stage_val = stage;
         uint32_t* stage_bin = stage + CHUNK;
-        static_assert(2 * CHUNK <= (uint32_t)SORTB_CAP, "chunk staging must fit the fast path's stage buffer");
+        static_assert(2 * CHUNK <= (uint32_t)CAP, "chunk staging must fit the fast path's stage buffer");
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
             uint64_t x[SORTB_UNROLL];
             uint32_t rk[SORTB_UNROLL];
-            for (int b = tid; b < BINS; b += 1024) cnt[b] = 0;
+            for (int b = tid; b < BINS; b += TPB) cnt[b] = 0;
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < SORTB_UNROLL; u++) {
-                const uint32_t q = q0 + u * 1024 + tid;
+                const uint32_t q = q0 + u * TPB + tid;
                 const uint64_t v = entries[pb + (q < len ? q : 0u)];
                 x[u] = q < len ? v : ~0ull;
             }
 #pragma unroll
             for (int u = 0; u < SORTB_UNROLL; u++) rk[u] = lds_take(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
             __syncthreads();
-            block_scan_bins<BINS>(cnt, cstart, wsum); // exclusive scan of this chunk's counts
+            block_scan_bins<BINS, TPB>(cnt, cstart, wsum); // exclusive scan of this chunk's counts
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < SORTB_UNROLL; u++) {
@@ -397,12 +400,12 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
             }
             __syncthreads();
             const uint32_t chunk_len = len - q0 < CHUNK ? len - q0 : CHUNK;
-            for (uint32_t slot = tid; slot < chunk_len; slot += 1024) {
+            for (uint32_t slot = tid; slot < chunk_len; slot += TPB) {
                 const uint32_t b = stage_bin[slot];
                 svals[pb + off[b] + (slot - cstart[b])] = stage_val[slot];
             }
             __syncthreads();
-            for (int b = tid; b < BINS; b += 1024) off[b] += cnt[b];
+            for (int b = tid; b < BINS; b += TPB) off[b] += cnt[b];
             __syncthreads();
         }
     }
@@ -1089,7 +1092,11 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
         {
             ProfScope ps(ctx, "msm_sort", st);
             hipLaunchKernelGGL(k_sortA_scatter<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, from, cursor, entries);
-            hipLaunchKernelGGL(k_sortB<C>, dim3(K::parts), dim3(1024), 0, st, entries, part_base, offsets, vals0);
+            // partitions of a few hundred entries (n <= 2^17 at 16 windows): 256-thread blocks; skewed input is still handled (chunked path)
+            if (L.entries / 1024 <= (size_t)SORTB_PER_THREAD * 256 / 2)
+                hipLaunchKernelGGL((k_sortB<C, 256>), dim3(K::parts), dim3(256), 0, st, entries, part_base, offsets, vals0);
+            else
+                hipLaunchKernelGGL((k_sortB<C, 1024>), dim3(K::parts), dim3(1024), 0, st, entries, part_base, offsets, vals0);
         }
         svals = vals0;
     } else {
@@ -1162,6 +1169,9 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
         else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
         if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
         else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
+        // (the plane sum stays a launch of its own: folded into the planes kernel as "the last block to finish adds the planes", its
+        // device-scope fences write back and invalidate the L2 of every XCD a block runs on -- the accumulation running beside it lost
+        // 2 % (1.120 vs 1.098 ms, bench step 1.672 vs 1.647), and a small MSM gained nothing: 87-98 us against 64 + 20)
         rc = msm_launch_final_sum((quad & 8) != 0, planes, (int)K::planes, d_out_jac, rst);
         if (rc) return rc;
     }
