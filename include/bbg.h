@@ -324,12 +324,16 @@ int bbg_multi_ntt(bbg_multi* m, uint64_t* coeffs, unsigned log2n, int op);
 
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
- * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (bucket window width: 0 = automatic [20 bits from n = 2^20 terms,
- * else 16], 16 or 20; a width's window tables are built the first time it is used on an SRS), "msm_sort" (1 = fused recode + two-level partition sort, default;
- * 0 = recode + rocPRIM radix sort + offsets kernels; both feed the same accumulation and give identical results),
+ * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [16 bits below 2^20 terms, 20 from 2^20, 22 from 2^23],
+ * or a compiled width 16 / 17 / 19 / 20 / 22; windows are BALANCED -- 255 bits split as evenly as the window count allows --; a width's window tables
+ * are built the first time it is used on an SRS), "msm_sort" (1 = fused recode + two-level partition sort, default; 0 = recode + rocPRIM radix sort, only
+ * in builds made with `make ROCPRIM_SORT=1`),
  * "msm_reduce_quad" (bit mask 0..15, default 14: reduce-phase stages with four lanes per EC operation -- bit 0 combine, 1 row/column sums, 2 bit
- * planes, 3 plane sum; 0 = the one-lane kernels), "msm_reduce_priority" (1 = low-priority reduce streams, default), "msm_upload_pieces" (1..4,
- * default 1: pieces the host scalars of bbg_msm travel in), "ntt_kernel" (2 = register-resident radix-8 passes, default; 1 = radix-2 in LDS),
+ * planes, 3 plane sum; 0 = the one-lane kernels), "msm_accumulate_quad" (1 = small MSMs accumulate with four threads per lane segment, default),
+ * "msm_reduce_blocks" (0 = one block per unit of work, default; N > 0 = thin grid-stride launches of the overlapped reduce phase: measured slower),
+ * "msm_reduce_priority" (1 = low-priority reduce streams, default), "msm_upload_pieces" (1..4, default 1: pieces the host scalars of bbg_msm travel in),
+ * "quotient_fuse" (1 = arithmetic + range + logic widgets of a chain in one pass, default),
+ * "ntt_kernel" (2 = register-resident radix-8 passes, default; 1 = radix-2 in LDS),
  * "ntt_max_logr8" (6..11, max log-radix per radix-8 pass, default 10), "ntt_big_tile" (0 / 1 / 2: 4096-element tiles for 2^21 [default] / also 2^22).
  * Every value of every option gives bit-identical results; they exist for A/B measurements. */
 int bbg_set_option(bbg_ctx* ctx, const char* key, long value);
