@@ -14,7 +14,7 @@ namespace bbg {
 // 15 x 17).  Cutting W windows of C bits from the bottom instead leaves a top window with a handful of bits (C = 19: 7, C = 22: 12) whose n
 // digits all land in the first few buckets -- one partition of the sort then holds n entries and its single block runs for a millisecond
 // (measured, profiles/r03_window_sweep_a.txt).  Widths whose W equals a narrower width's (18 -> 17, 21 -> 20) are pointless and not compiled.
-// Each configuration has its own window tables T[w][i] = 2^(offset(w)) P_i, built the first time it is used on an SRS, and its own
+// Each configuration has its own window tables T[w][i] = 2^(table_offset(w)) P_i, built the first time it is used on an SRS, and its own
 // translation unit (msm_wNN.hip) so that the configurations compile side by side.
 template <int C> struct MsmCfg {
     static constexpr int c = C;
@@ -23,6 +23,11 @@ template <int C> struct MsmCfg {
     static_assert(nwide >= 1 && nwide <= windows, "use the narrower configuration with the same number of windows");
     static constexpr int width(int w) { return w < nwide ? C : C - 1; }
     static constexpr int offset(int w) { return w * (C - 1) + (w < nwide ? w : nwide); } // first scalar bit of window w; offset(windows) = 255
+    // A narrow window's digits d fill only the lower half of the bucket range; filed under bucket d they would double the load of the lower
+    // half of the sort's partitions (at n = 2^20, C = 20 exactly up to the second level's single-pass capacity).  They are filed under bucket
+    // 2d against the table point of HALF the weight instead -- d 2^offset P = (2d) 2^(offset - 1) P --: every partition sees every window.
+    static constexpr int scale(int w) { return w < nwide ? 0 : 1; }                 // bucket = |digit| << scale(w)
+    static constexpr int table_offset(int w) { return offset(w) - scale(w); }       // table[w][i] = 2^table_offset(w) P_i
     static constexpr int buckets = 1 << (C - 1);       // |digit| in [1, 2^(C-1)]
     static constexpr int lo_bits = C - 11;             // sort partitions = buckets >> lo_bits (+1) = 1025; bins per partition = 2^lo_bits
     static constexpr int parts = (buckets >> lo_bits) + 1;
@@ -41,7 +46,7 @@ constexpr int MSM_MAX_PLANES = 32;
 template <int C>
 int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st,
               const void* h_scalars);
-// table[w * n + i] = 2^(MsmCfg<C>::offset(w)) P_i
+// table[w * n + i] = 2^(MsmCfg<C>::table_offset(w)) P_i
 template <int C> int srs_build_tables_c(const void* d_points, size_t n, void* d_table, hipStream_t st);
 // the last reduce stage (sum of the bit planes -> Jacobian), shared by all widths (msm.hip)
 int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st);

@@ -5,6 +5,7 @@
 #include "curve.hip.h"
 #include "curve_quad.hip.h"
 
+#include <algorithm>
 #include <cstring>
 #ifdef BBG_ROCPRIM_SORT // A/B build only (make ROCPRIM_SORT=1): k_recode + rocPRIM radix sort + k_offsets instead of the partition sort
 #include <rocprim/device/device_radix_sort.hpp>
@@ -15,7 +16,7 @@ namespace bbg {
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
 // ---------------------------------------------------------------------------------- SRS precomputation
-// table[w * n + i] = 2^(offset(w)) * P_i (affine, canonical).  One thread per point: width(w - 1) doublings in XYZZ from one window to
+// table[w * n + i] = 2^(table_offset(w)) * P_i (affine, canonical).  One thread per point: doublings in XYZZ from one window to
 // the next, then one shared inversion (Montgomery's trick over the Z-products) to normalise.
 template <int C> __global__ void __launch_bounds__(128) k_precompute_tables(const Affine* __restrict__ points, Affine* table, size_t n)
 {
@@ -34,15 +35,14 @@ template <int C> __global__ void __launch_bounds__(128) k_precompute_tables(cons
     // the multiples live in per-thread scratch (one-off kernel: simplicity over registers)
     Xyzz pts[MSM_WINDOWS - 1];
     Fq prod[MSM_WINDOWS - 1];
-    Xyzz q = xyzz_dbl_affine(p);
-    for (int k = 1; k < K::width(0); k++) q = xyzz_dbl(q);
+    Xyzz q = xyzz_dbl_affine(p); // 2^1 P
+    int at = 1;
     Fq acc = Fq::one();
     for (int w = 1; w < MSM_WINDOWS; w++) {
+        for (; at < K::table_offset(w); at++) q = xyzz_dbl(q);
         pts[w - 1] = q;
         prod[w - 1] = acc;
         acc = fe_mul(acc, fe_mul(q.zz, q.zzz));
-        if (w < MSM_WINDOWS - 1)
-            for (int k = 0; k < K::width(w); k++) q = xyzz_dbl(q);
     }
     Fq inv = fq_invert(acc);
     for (int w = MSM_WINDOWS - 1; w >= 1; w--) {
@@ -79,7 +79,7 @@ __device__ __forceinline__ void recode_digits(const Fr* __restrict__ scalars, si
         if (limb + 1 < 8) two |= (uint64_t)k.v[limb + 1] << 32;
         const uint32_t d = ((uint32_t)(two >> sh) & (FULL - 1)) + carry; // 0 .. 2^width
         const uint32_t neg = d > HALF;
-        mag[w] = neg ? (FULL - d) : d; // |digit| in [0, 2^(width-1)]
+        mag[w] = (neg ? (FULL - d) : d) << K::scale(w); // bucket: |digit| in [0, 2^(width-1)], doubled for the narrow windows (msm_cfg.h)
         carry = neg;
         signs |= neg << w;
     }
@@ -162,22 +162,35 @@ __device__ __forceinline__ void block_scan_pairs(const uint32_t* tbl, uint32_t* 
 // hold three waves per SIMD, and a 1024-thread block needs four free wave slots on EVERY SIMD of a CU at once -- it waited for them
 // (134-160 us per launch in the step's timeline against 29 us alone, profiles/r03_timeline_a.txt); one 49-VGPR wave per SIMD fits beside them.
 constexpr int COUNT_THREADS = 256;
-template <int C> __global__ void __launch_bounds__(COUNT_THREADS) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
+constexpr int COUNT_MAX_BLOCKS = 2048; // 8 blocks per CU
+// STRIDE = false (n <= 2^21: one group per block) keeps the kernel at 56 VGPRs -- a wave of it then fits beside the three 152-VGPR waves per SIMD of
+// the previous MSM's row / column sums (3 x 152 + 56 = 512); the loop costs four more registers, which is 0.1 ms of waiting per bench step.
+template <int C, bool STRIDE> __global__ void __launch_bounds__(COUNT_THREADS) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
 {
     constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
     __shared__ uint32_t hist[SORT_PAD];
     const int tid = threadIdx.x;
     for (int h = tid; h < SORT_PAD; h += COUNT_THREADS) hist[h] = 0;
     __syncthreads();
-    for (int r = 0; r < SORT_BLOCK / COUNT_THREADS; r++) {
-        const size_t i = (size_t)blockIdx.x * SORT_BLOCK + (size_t)r * COUNT_THREADS + tid;
-        uint32_t mag[MSM_MAX_WINDOWS], signs;
-        if (i < n) recode_digits<C>(scalars, i, mag, signs);
+    // grid-stride over groups of SORT_BLOCK scalars: a large MSM is counted by COUNT_MAX_BLOCKS blocks, each flushing its histogram ONCE
+    // (one block per group meant 16 384 x 1 025 global atomics onto the same 1 025 words at n = 2^24: 0.37 ms)
+    auto count_group = [&](size_t g) {
+        for (int r = 0; r < SORT_BLOCK / COUNT_THREADS; r++) {
+            const size_t i = g * SORT_BLOCK + (size_t)r * COUNT_THREADS + tid;
+            uint32_t mag[MSM_MAX_WINDOWS], signs;
+            if (i < n) recode_digits<C>(scalars, i, mag, signs);
 #pragma unroll
-        for (int w = 0; w < MSM_WINDOWS; w++) {
-            const bool on = i < n && mag[w] != 0; // zero digits contribute nothing: never sorted
-            lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
+            for (int w = 0; w < MSM_WINDOWS; w++) {
+                const bool on = i < n && mag[w] != 0; // zero digits contribute nothing: never sorted
+                lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
+            }
         }
+    };
+    if constexpr (STRIDE) {
+        const size_t groups = (n + SORT_BLOCK - 1) / SORT_BLOCK;
+        for (size_t g = blockIdx.x; g < groups; g += gridDim.x) count_group(g);
+    } else {
+        count_group(blockIdx.x);
     }
     __syncthreads();
     for (int h = tid; h < SORT_PARTS; h += COUNT_THREADS)
@@ -309,7 +322,12 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
 {
     constexpr int SORT_LO_BITS = MsmCfg<C>::lo_bits, MSM_BUCKETS = MsmCfg<C>::buckets, BINS = 1 << SORT_LO_BITS;
     constexpr uint32_t SORT_LO_MASK = BINS - 1;
-    constexpr int CAP = SORTB_PER_THREAD * TPB; // fast-path capacity and LDS stage
+    // LDS budget: TWO blocks per CU (<= 80 KB each) whatever the bin count -- in the chunked path a block alternates between global loads and
+    // LDS work, and a second block on the CU is what covers either.  Stage = PER entries per thread: 18 up to 1024 bins (72 KB + 8 KB of counters),
+    // 15 for 2048 bins (60 KB + 16 KB); the chunked path's per-chunk bin starts live in the stage's tail instead of an array of their own.
+    constexpr int PER = BINS > 1024 ? 15 : SORTB_PER_THREAD;
+    constexpr int CAP = PER * TPB; // fast-path capacity and LDS stage
+    constexpr int UNROLL = (CAP - BINS) / (2 * TPB) < SORTB_UNROLL ? (CAP - BINS) / (2 * TPB) : SORTB_UNROLL; // entries per thread and chunk
     static_assert(BINS <= 2048 && BINS <= 8 * TPB, "LDS: three counter arrays of BINS words beside the stage; at most 8 bins per thread");
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t off[BINS];
@@ -322,29 +340,29 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     const bool fast = len <= (uint32_t)CAP;
     for (int b = tid; b < BINS; b += TPB) hist[b] = 0;
     __syncthreads();
-    uint64_t e[SORTB_PER_THREAD];
-    constexpr uint32_t CHUNK = TPB * SORTB_UNROLL;
+    uint64_t e[PER];
+    constexpr uint32_t CHUNK = TPB * UNROLL;
     const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loops (lds_take is wave-cooperative)
     if (fast) {
 #pragma unroll
-        for (int u = 0; u < SORTB_PER_THREAD; u++) {
+        for (int u = 0; u < PER; u++) {
             const uint32_t q = u * TPB + tid;
             const uint64_t v = entries[pb + (q < len ? q : 0u)]; // unconditional: the loads batch up
             e[u] = q < len ? v : ~0ull;
         }
 #pragma unroll
-        for (int u = 0; u < SORTB_PER_THREAD; u++) lds_take(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
+        for (int u = 0; u < PER; u++) lds_take(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
     } else {
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
-            uint32_t key[SORTB_UNROLL];
+            uint32_t key[UNROLL];
 #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
+            for (int u = 0; u < UNROLL; u++) {
                 const uint32_t q = q0 + u * TPB + tid;
                 const uint32_t k = (uint32_t)(entries[pb + (q < len ? q : 0u)] >> 32);
                 key[u] = q < len ? k : 0xffffffffu;
             }
 #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) lds_take(hist, key[u] & SORT_LO_MASK, key[u] != 0xffffffffu);
+            for (int u = 0; u < UNROLL; u++) lds_take(hist, key[u] & SORT_LO_MASK, key[u] != 0xffffffffu);
         }
     }
     __syncthreads();
@@ -357,7 +375,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     __syncthreads();
     if (fast) {
 #pragma unroll
-        for (int u = 0; u < SORTB_PER_THREAD; u++) {
+        for (int u = 0; u < PER; u++) {
             const bool on = e[u] != ~0ull;
             const uint32_t pos = lds_take(off, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, on);
             if (on) stage[pos] = (uint32_t)e[u];
@@ -369,28 +387,28 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
         // and chunk, on consecutive addresses) instead of 8192 independent 4-byte stores.  off[] = running global position
         // of every bucket; cnt[] / cstart[] = this chunk's counts and their exclusive scan (reusing hist[] and wsum[]).
         uint32_t* cnt = hist;
-        __shared__ uint32_t cstart[BINS];
+        uint32_t* cstart = stage + 2 * CHUNK; // the stage's tail
+        static_assert(2 * CHUNK + BINS <= (uint32_t)CAP, "chunk staging + per-chunk bin starts must fit the stage");
         uint32_t* stage_val = stage;
         uint32_t* stage_bin = stage + CHUNK;
-        static_assert(2 * CHUNK <= (uint32_t)CAP, "chunk staging must fit the fast path's stage buffer");
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
-            uint64_t x[SORTB_UNROLL];
-            uint32_t rk[SORTB_UNROLL];
+            uint64_t x[UNROLL];
+            uint32_t rk[UNROLL];
             for (int b = tid; b < BINS; b += TPB) cnt[b] = 0;
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
+            for (int u = 0; u < UNROLL; u++) {
                 const uint32_t q = q0 + u * TPB + tid;
                 const uint64_t v = entries[pb + (q < len ? q : 0u)];
                 x[u] = q < len ? v : ~0ull;
             }
 #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) rk[u] = lds_take(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
+            for (int u = 0; u < UNROLL; u++) rk[u] = lds_take(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
             __syncthreads();
             block_scan_bins<BINS, TPB>(cnt, cstart, wsum); // exclusive scan of this chunk's counts
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) {
+            for (int u = 0; u < UNROLL; u++) {
                 if (x[u] != ~0ull) {
                     const uint32_t b = (uint32_t)(x[u] >> 32) & SORT_LO_MASK;
                     const uint32_t slot = cstart[b] + rk[u];
@@ -576,7 +594,10 @@ k_combine(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __rest
     const uint32_t base = offsets[1];
     // grid-stride: the launch decides how much of the chip this stage occupies (msm_reduce_blocks: a thin launch leaves the wave slots to
     // the main stream's kernels and trickles along beside them)
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x + 1; b <= MSM_BUCKETS; b += gridDim.x * blockDim.x) {
+    // Even buckets first, then odd ones: with narrow windows filed under doubled bucket numbers (msm_cfg.h) even buckets hold several times the
+    // entries of odd ones and span more lane segments; a wave that mixes both runs the long loop for everybody (2^24, C = 22: 0.83 vs 0.61 ms).
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < MSM_BUCKETS; t += gridDim.x * blockDim.x) {
+        const uint32_t b = t < MSM_BUCKETS / 2 ? 2 * (t + 1) : 2 * (t - MSM_BUCKETS / 2) + 1;
         const uint32_t sb = offsets[b], eb = offsets[b + 1];
         if (sb == eb) {
             xyzz_store(buckets + (b - 1), xyzz_inf());
@@ -1081,11 +1102,14 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
                                            ctx->upload_stream));
                     BBG_HIP(hipEventRecord(ctx->ev_upload[k], ctx->upload_stream));
                     BBG_HIP(hipStreamWaitEvent(st, ctx->ev_upload[k], 0));
-                    hipLaunchKernelGGL(k_sortA_count<C>, dim3(grid_for(len, SORT_BLOCK)), dim3(COUNT_THREADS), 0, st, (const Fr*)d_scalars + lo, len,
-                                       part_count);
+                    hipLaunchKernelGGL((k_sortA_count<C, true>), dim3(std::min(grid_for(len, SORT_BLOCK), COUNT_MAX_BLOCKS)), dim3(COUNT_THREADS), 0, st,
+                                       (const Fr*)d_scalars + lo, len, part_count);
                 }
             } else {
-                hipLaunchKernelGGL(k_sortA_count<C>, dim3(nblk), dim3(COUNT_THREADS), 0, st, (const Fr*)d_scalars, n, part_count);
+                if (nblk > COUNT_MAX_BLOCKS)
+                    hipLaunchKernelGGL((k_sortA_count<C, true>), dim3(COUNT_MAX_BLOCKS), dim3(COUNT_THREADS), 0, st, (const Fr*)d_scalars, n, part_count);
+                else
+                    hipLaunchKernelGGL((k_sortA_count<C, false>), dim3(nblk), dim3(COUNT_THREADS), 0, st, (const Fr*)d_scalars, n, part_count);
             }
             hipLaunchKernelGGL(k_sortA_scan<C>, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets, long_count);
         }
