@@ -236,11 +236,6 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->quotient_fuse = value != 0;
         return BBG_OK;
     }
-    if (!strcmp(key, "msm_reduce_blocks")) {
-        if (value < 0 || value > 65535) { set_error("msm_reduce_blocks must be 0 (one block per unit of work) .. 65535"); return BBG_E_INVALID; }
-        ctx->msm_reduce_blocks = (int)value;
-        return BBG_OK;
-    }
     if (!strcmp(key, "msm_window")) {
         if (value != 0 && msm_width_slot((int)value) < 0) { set_error("msm_window must be 0 (automatic) or a compiled width: 16, 17, 19, 20, 22"); return BBG_E_INVALID; }
         ctx->msm_window = (int)value;

@@ -592,11 +592,9 @@ k_combine(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __rest
     constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t base = offsets[1];
-    // grid-stride: the launch decides how much of the chip this stage occupies (msm_reduce_blocks: a thin launch leaves the wave slots to
-    // the main stream's kernels and trickles along beside them)
     // Even buckets first, then odd ones: with narrow windows filed under doubled bucket numbers (msm_cfg.h) even buckets hold several times the
     // entries of odd ones and span more lane segments; a wave that mixes both runs the long loop for everybody (2^24, C = 22: 0.83 vs 0.61 ms).
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < MSM_BUCKETS; t += gridDim.x * blockDim.x) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < MSM_BUCKETS; t = MSM_BUCKETS) { // (one pass; `continue` = done)
         const uint32_t b = t < MSM_BUCKETS / 2 ? 2 * (t + 1) : 2 * (t - MSM_BUCKETS / 2) + 1;
         const uint32_t sb = offsets[b], eb = offsets[b + 1];
         if (sb == eb) {
@@ -899,20 +897,18 @@ template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(co
     const int q = threadIdx.x & 3;
     // serial phase: every THREAD sums its own share with one-lane additions (a quad-cooperative addition costs 1.55x the instructions of a
     // one-lane one -- it buys latency, and there is none to buy while all four lanes have items of their own); then the four partial sums of
-    // a quad are added with four-lane operations, then the tree over the QL quads.  Grid-stride over the ROWS + COLS jobs (see k_combine).
-    for (int job = blockIdx.x; job < ROWS + COLS; job += gridDim.x) {
-        Xyzz s = xyzz_inf();
-        if (job < ROWS) {
-            const int hi = job;
-            for (int lo = threadIdx.x; lo < COLS; lo += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
-            Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
-            if (threadIdx.x == 0) xyzz_store(rows + hi, v);
-        } else {
-            const int lo = job - ROWS;
-            for (int hi = threadIdx.x; hi < ROWS; hi += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
-            Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
-            if (threadIdx.x == 0) xyzz_store(cols + lo, v);
-        }
+    // a quad are added with four-lane operations, then the tree over the QL quads
+    Xyzz s = xyzz_inf();
+    if (blockIdx.x < ROWS) {
+        const int hi = blockIdx.x;
+        for (int lo = threadIdx.x; lo < COLS; lo += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
+        Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
+        if (threadIdx.x == 0) xyzz_store(rows + hi, v);
+    } else {
+        const int lo = blockIdx.x - ROWS;
+        for (int hi = threadIdx.x; hi < ROWS; hi += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
+        Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
+        if (threadIdx.x == 0) xyzz_store(cols + lo, v);
     }
 }
 
@@ -1166,10 +1162,6 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
         // msm_reduce_quad: bit 0 combine, bit 1 row/column sums, bit 2 bit planes, bit 3 plane sum -- each stage either with four lanes per EC
         // operation (curve_quad.hip.h: the same chain, ~3x shorter in time) or with one (the round-1 kernels, kept for A/B)
         const int quad = ctx->msm_reduce_quad;
-        // msm_reduce_blocks > 0: the throughput stages of an OVERLAPPED reduce phase (combine, row / column sums) are launched with at most
-        // that many blocks (grid-stride inside) instead of one block per unit of work
-        const int thin = (overlap && ctx->msm_reduce_blocks > 0) ? ctx->msm_reduce_blocks : 0;
-        auto thin_grid = [thin](int full) { return thin && thin < full ? thin : full; };
         if (quad & 1) {
             if (L.lanes > (size_t)2 * K::buckets)
                 hipLaunchKernelGGL(k_combine_lanes_q<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst,
@@ -1183,13 +1175,13 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
                 hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
                                    L.seg, head, tail, buckets, long_count, long_list);
             else
-                hipLaunchKernelGGL(k_combine<C>, dim3(thin_grid(grid_for((size_t)K::buckets, 256))), dim3(256), 0, rst, offsets, L.seg, head, tail,
+                hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
                                    buckets, long_count, long_list);
             hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
         }
         // 64 logical lanes per row / column (measured against 128 / 32 / 16: reduce phase 0.458 / 0.49 / 0.53 / 0.55 ms at 2^20 stand-alone,
         // 0.154 / 0.165 / 0.164 / 0.184 at 2^10; bench step equal for 64 and 128, worse below)
-        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, 64>), dim3(thin_grid((1 << K::log_rows) + (1 << K::log_cols))), dim3(256), 0, rst, buckets, rows, cols);
+        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, 64>), dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
         else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
         if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
         else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);

@@ -118,7 +118,6 @@ def main():
     ap.add_argument("--reduce-priority", type=int, default=-1, help="A/B: 1 = low-priority auxiliary stream for the MSM reduce phase (library default), 0 = normal")
     ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, or a compiled width (A/B runs)")
     ap.add_argument("--reduce-quad", type=int, default=-1, help="A/B: msm_reduce_quad stage mask (library default 14)")
-    ap.add_argument("--reduce-blocks", type=int, default=-1, help="A/B: blocks per kernel of the overlapped reduce phase's throughput stages (0 = one block per unit of work)")
     args = ap.parse_args()
 
     import torch
@@ -155,8 +154,6 @@ def main():
         bbg.set_option("msm_window", args.msm_window)
     if args.reduce_priority >= 0:
         bbg.set_option("msm_reduce_priority", args.reduce_priority)
-    if args.reduce_blocks >= 0:
-        bbg.set_option("msm_reduce_blocks", args.reduce_blocks)
     if args.reduce_quad >= 0:
         bbg.set_option("msm_reduce_quad", args.reduce_quad)
 
