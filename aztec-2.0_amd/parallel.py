@@ -216,3 +216,27 @@ def ntt_sharded(ops, dist, x_local, log2n, inverse=False, coset_shift=None, new_
     out = new_like(x_local) if new_like is not None else x_local.clone()
     ops.cross_dft(recv, out, log2g, lenq, log2n, inverse)
     return out
+
+
+def gather_natural_order(dist, out_local, log2n):
+    """Collects the outputs of ntt_sharded on rank 0 and puts them into natural order: rank g holds out[t*(m/G) + q] = A[(g*m/G + q) + m*t]
+    (m = n/G).  Returns the (n, 4) uint64 array on rank 0, None elsewhere.  Used by bench.py's self-checking config 5 and by the gloo test."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    n = 1 << log2n
+    m = n // world
+    lenq = m // world
+    if world > 1:
+        parts = [torch.empty_like(out_local) for _ in range(world)] if rank == 0 else None
+        dist.gather(out_local, parts, dst=0)
+    else:
+        parts = [out_local]
+    if rank != 0:
+        return None
+    nat = np.empty((n, 4), dtype=np.uint64)
+    for g, part in enumerate(parts):
+        o = part.cpu().numpy().view(np.uint64).reshape(world, lenq, 4)
+        for t in range(world):
+            nat[t * m + g * lenq: t * m + (g + 1) * lenq] = o[t]
+    return nat

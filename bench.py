@@ -546,20 +546,8 @@ def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
         if rank == 0:
             check["msm"] = bool(np.array_equal(bbg.g1_normalize(jac).reshape(-1), want_msm))
     if want_ntt is not None:
-        mine = last["ntt"]
-        if world > 1:
-            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-            dist.gather(mine, parts, dst=0)
-        else:
-            parts = [mine]
+        nat = par.gather_natural_order(dist, last["ntt"], lg)  # rank g holds out[t*(m/G) + q] = A[(g*m/G + q) + m*t]  (parallel.ntt_sharded)
         if rank == 0:
-            # rank g holds out[t*(m/G) + q] = A[(g*m/G + q) + m*t]  (parallel.ntt_sharded)
-            lenq = m // world
-            nat = np.empty((n, 4), dtype=np.uint64)
-            for g, part in enumerate(parts):
-                o = part.cpu().numpy().view(np.uint64).reshape(world, lenq, 4)
-                for t in range(world):
-                    nat[t * m + g * lenq: t * m + (g + 1) * lenq] = o[t]
             check["ntt"] = hashlib.sha256(pkg.fr_reduce_once(nat).tobytes()).hexdigest() == want_ntt
     srs.free()
     return {"workload": "ONE 2^%d-point MSM + ONE 2^%d coset NTT over %d GPU(s), strong scaling (north_star's split: point-range MSM shards + "

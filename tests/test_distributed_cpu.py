@@ -110,6 +110,17 @@ for inverse, shift, op in ((False, None, 0), (True, None, 1), (False, five, 2)):
     for t_ in range(world):
         for q_ in range(lenq):
             assert np.array_equal(got[t_, q_], whole[(rank * lenq + q_) + mm * t_]), ("sharded ntt", op, t_, q_)
+# what bench.py's self-checking config 5 does with the shards: the strided input generator, gather on rank 0, natural order, canonical form
+import hashlib
+xl = torch.from_numpy(pkg.synthetic_scalars_strided(900 + lg, nn // world, rank, world).view(np.int64).reshape(-1).copy())
+assert np.array_equal(xl.numpy().view(np.uint64).reshape(-1, 4), pkg.synthetic_scalars(900 + lg, nn)[rank::world])
+res = par.ntt_sharded(CpuNttOps(), dist, xl, lg, coset_shift=five)
+nat = par.gather_natural_order(dist, res, lg)
+if rank == 0:
+    want = O.ntt(pkg.synthetic_scalars(900 + lg, nn), 2)
+    assert hashlib.sha256(pkg.fr_reduce_once(nat).tobytes()).hexdigest() == hashlib.sha256(np.ascontiguousarray(want).tobytes()).hexdigest(), "config-5 style gather"
+else:
+    assert nat is None
 # the prover's 4n coset FFT with n non-zero coefficients: ext independent size-n coset FFTs, no arithmetic exchange (8e row 3)
 for lg6, ext in ((6, 4), (5, 8), (6, 2)):
     c6 = O.canon(0, pkg.synthetic_scalars(778 + ext, 1 << lg6))

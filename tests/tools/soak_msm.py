@@ -33,7 +33,9 @@ for c in range(cases):
         sc = base[rng.integers(0, 3, n)]
     else:  # raw 256-bit limbs (un-reduced representatives)
         sc = rng.integers(0, 1 << 63, (n, 4), dtype=np.int64).astype(np.uint64) * 2 + 1
-    B.set_option("msm_window", int(rng.choice([0, 16, 20])))
+    B.set_option("msm_window", int(rng.choice([0, 16, 17, 19, 20, 22])))
+    B.set_option("msm_accumulate_quad", int(rng.integers(0, 2)))
+    B.set_option("msm_async_reduce", int(rng.integers(0, 2)))
     got = O.jac_to_affine(B.msm(srs, sc, start=start))
     want = O.pippenger(sc, pts[start:start + n])
     if not np.array_equal(got, want):
