@@ -228,6 +228,12 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_reduce_quad = (int)value & 15;
         return BBG_OK;
     }
+    if (!strcmp(key, "msm_acc_waves")) {
+        BBG_HIP(hipDeviceSynchronize());
+        ctx->msm_acc_waves = (int)value;
+        ctx->msm_layout_n = 0;
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_accumulate_quad")) {
         ctx->msm_accumulate_quad = value != 0;
         return BBG_OK;

@@ -962,15 +962,16 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // very large ones so that a bucket spans <= ~32 lanes and the lane-group combine (not the block-per-bucket fallback) sums
 // its pieces.  When one round of waves covers the whole job the lane count is made a multiple of the chip's 65536 SIMD
 // lanes: with 3.25 waves per SIMD the kernel takes as long as with 4, because the busiest SIMD sets the time.
-static uint32_t msm_seg_len(size_t entries, size_t buckets)
+static uint32_t msm_seg_len(size_t entries, size_t buckets, int waves_override)
 {
     constexpr size_t CHIP_LANES = 65536; // 256 CUs x 4 SIMDs x 64
-    constexpr size_t MAX_WAVES = 6;      // resident waves per SIMD of k_accumulate (84 VGPRs)
+    const size_t MAX_WAVES = waves_override > 0 ? (size_t)waves_override : 6; // lane segments per SIMD lane and round
     if (entries <= MSM_SEG_MIN * 4 * CHIP_LANES) return MSM_SEG_MIN; // small: at most 4 waves per SIMD of 8 entries
     size_t seg;
     if (entries <= MSM_SEG_DEFAULT * MAX_WAVES * CHIP_LANES) { // one round of k = 4..6 full waves per SIMD, <= 64 entries each
         size_t k = (entries + MSM_SEG_DEFAULT * CHIP_LANES - 1) / (MSM_SEG_DEFAULT * CHIP_LANES);
         if (k < 4) k = 4;
+        if (waves_override > 0) k = (size_t)waves_override;
         seg = (entries + k * CHIP_LANES - 1) / (k * CHIP_LANES);
     } else { // whole rounds of MAX_WAVES waves per SIMD, ~64 entries each
         const size_t per_round = MSM_SEG_DEFAULT * MAX_WAVES * CHIP_LANES;
@@ -982,11 +983,11 @@ static uint32_t msm_seg_len(size_t entries, size_t buckets)
     return (uint32_t)seg;
 }
 
-template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L)
+template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L, int acc_waves = 0)
 {
     using K = MsmCfg<C>;
     L.entries = n * K::windows;
-    L.seg = msm_seg_len(L.entries, K::buckets);
+    L.seg = msm_seg_len(L.entries, K::buckets, acc_waves);
     L.lanes = (L.entries + L.seg - 1) / L.seg;
     size_t tmp = 0;
 #ifdef BBG_ROCPRIM_SORT
@@ -1029,7 +1030,7 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
     const Affine* table = (const Affine*)table_v;
     using K = MsmCfg<C>;
     MsmLayout L;
-    int rc = msm_layout<C>(n, ctx->msm_sort == 0, L);
+    int rc = msm_layout<C>(n, ctx->msm_sort == 0, L, ctx->msm_acc_waves);
     if (rc) return rc;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
