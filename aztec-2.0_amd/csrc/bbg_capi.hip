@@ -234,6 +234,10 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_layout_n = 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "msm_limbs29")) {
+        ctx->msm_limbs29 = value != 0;
+        return BBG_OK;
+    }
     if (!strcmp(key, "msm_accumulate_quad")) {
         ctx->msm_accumulate_quad = value != 0;
         return BBG_OK;

@@ -104,6 +104,7 @@ struct bbg_ctx {
     bool msm_async_reduce = false;
     int msm_reduce_quad = 14;   // reduce stages with four lanes per EC operation (curve_quad.hip.h): bit 0 combine (a THROUGHPUT kernel over all buckets: one lane per operation is cheaper, measured), 1 row/col, 2 planes, 3 sum
     int msm_acc_waves = 0;           // option "msm_acc_waves": lane segments per SIMD lane of the accumulation (0 = automatic), A/B
+    bool msm_limbs29 = true;         // option "msm_limbs29": the accumulation's field arithmetic on 9 x 29-bit limbs (0 = 8 x 32, A/B)
     bool msm_accumulate_quad = true; // option "msm_accumulate_quad": small MSMs accumulate with four threads per lane segment (0 = one, A/B)
     bool msm_reduce_low_priority = true; // auxiliary stream created with the lowest priority (option "msm_reduce_priority" = 0 undoes it)
     std::map<uint32_t, void*> dpv_consts; // poly.hip: Z*_H division constants per (src, target, roots cut)

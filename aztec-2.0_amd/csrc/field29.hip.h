@@ -1,0 +1,310 @@
+// BN254 field arithmetic on 9 x 29-bit limbs (gfx950): the multiplier of the MSM bucket accumulation.
+//
+// Why a second limb format.  v_mad_u64_u32 computes a 32 x 32 product plus a 64-bit addend in one VALU instruction, but with full 32-bit
+// limbs the running column sum of a product-scanning Montgomery multiplication overflows 64 bits after two products, so field.hip.h's
+// fe_mul pays one v_addc_co_u32 per limb product (136 mads + 136 addc + 8 mul_lo).  With 29-bit limbs a column holds at most 9 a*b and
+// 9 m*p products of < 2^58 each: 18 * 2^58 < 2^63, the accumulator never overflows and a limb product is ONE instruction --
+// 81 + 81 mads, 9 (mul_lo + and) for the m digits and 17 column shifts.  Same algorithm as the reference's montgomery_mul
+// (ecc/fields/field_impl_generic.hpp:392-442), radix 2^29 instead of 2^64, Montgomery radix R' = 2^261.
+//
+// Ranges.  A value is 9 limbs v[0..8], value = sum v[i] 2^(29 i) < 2^261 + slack; limbs may exceed 29 bits ("lazy"): additions are
+// limbwise without carries, f29_carry() is one parallel carry pass (limbs < 2^29 + 8 afterwards).  f29_mul needs
+// 9 * maxlimb(a) * maxlimb(b) + 9 * 2^58 < 2^64, i.e. bitlen(a limbs) + bitlen(b limbs) <= 60, and returns
+// (a * b + m * p) / R' < a * b / R' + p with limbs < 2^29 (the top one unmasked).  p / R' = 2^-7.4: operands of 32p and 2p give < 1.4p.
+//
+// Conversion.  Device buffers hold the reference's residues x * 2^256 (8 x u32).  (x * 2^256) << 5 = x * 2^261 as an integer < 2^261
+// when x * 2^256 mod p is stored below 2^256, so R-form -> R'-form is the limb split at a 5-bit offset (f29_from_fe<P, 5>), free.  Back
+// is a division by 32 mod p: one 5-bit Montgomery step against a table of the multiples of p (f29_div32_to_fe).
+#pragma once
+#include "field.hip.h"
+
+namespace bbg {
+
+constexpr uint32_t M29 = 0x1fffffffu;
+
+template <class P> struct F29 {
+    uint32_t v[9];
+};
+
+// bits [29 j, 29 j + 29) of the 256-bit constant w (limb j of w in radix 2^29)
+constexpr uint32_t k29_limb(const uint32_t* w, int j)
+{
+    const int b = 29 * j, i = b >> 5, o = b & 31;
+    const uint64_t lo = i < 8 ? w[i] : 0, hi = i + 1 < 8 ? w[i + 1] : 0;
+    return (uint32_t)(((lo | (hi << 32)) >> o) & M29);
+}
+// limb j of M * p (M < 2^7: M p < 2^261)
+constexpr uint32_t k29_limb_times(const uint32_t* w, int j, uint32_t mult)
+{
+    uint32_t t[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint64_t carry = 0;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t x = (uint64_t)w[i] * mult + carry;
+        t[i] = (uint32_t)x;
+        carry = x >> 32;
+    }
+    t[8] = (uint32_t)carry;
+    const int b = 29 * j, i = b >> 5, o = b & 31;
+    const uint64_t lo = t[i], hi = t[i + 1];
+    return (uint32_t)(((lo | (hi << 32)) >> o) & M29);
+}
+template <class P, int J> struct P29 {
+    static constexpr uint32_t value = k29_limb(P::MOD, J);
+};
+// M p written with every limb below the top raised by 2^E (borrowed from the limb above): limbwise a + spread - b never goes negative
+// for b limbs <= 2^E - 2 and a top limb of b <= that of M p minus 2^(E - 29); the value added is exactly M p.
+template <class P, int J, int M, int E> struct Spread29 {
+    static constexpr uint32_t q = k29_limb_times(P::MOD, J, M);
+    static constexpr uint32_t up = 1u << E, down = 1u << (E - 29);
+    static constexpr uint32_t value = J == 0 ? q + up : (J < 8 ? q + up - down : q - down);
+};
+
+// limb J of (x << S) for a 256-bit x in 8 x u32
+template <int S, int J> __device__ __forceinline__ uint32_t f29_split_limb(const uint32_t* x)
+{
+    constexpr int b = 29 * J - S;
+    if constexpr (b < 0) return (x[0] << (-b)) & M29;
+    else {
+        constexpr int i = b >> 5, o = b & 31;
+        if constexpr (i >= 8) return 0;
+        else if constexpr (o == 0) return x[i] & M29;
+        else if constexpr (o <= 3) return (x[i] >> o) & M29;
+        else if constexpr (i == 7) return x[i] >> o;
+        else return __builtin_amdgcn_alignbit(x[i + 1], x[i], o) & M29;
+    }
+}
+template <class P, int S> __device__ __forceinline__ F29<P> f29_from_fe(const Fe<P>& x)
+{
+    F29<P> r;
+    r.v[0] = f29_split_limb<S, 0>(x.v);
+    r.v[1] = f29_split_limb<S, 1>(x.v);
+    r.v[2] = f29_split_limb<S, 2>(x.v);
+    r.v[3] = f29_split_limb<S, 3>(x.v);
+    r.v[4] = f29_split_limb<S, 4>(x.v);
+    r.v[5] = f29_split_limb<S, 5>(x.v);
+    r.v[6] = f29_split_limb<S, 6>(x.v);
+    r.v[7] = f29_split_limb<S, 7>(x.v);
+    r.v[8] = f29_split_limb<S, 8>(x.v);
+    return r;
+}
+
+// one parallel carry pass: limbs < 2^32 in, limbs < 2^29 + 8 out (top limb: whatever the value needs)
+template <class P> __device__ __forceinline__ F29<P> f29_carry(const F29<P>& a)
+{
+    F29<P> r;
+    r.v[0] = a.v[0] & M29;
+#pragma unroll
+    for (int i = 1; i < 8; i++) r.v[i] = (a.v[i] & M29) + (a.v[i - 1] >> 29);
+    r.v[8] = a.v[8] + (a.v[7] >> 29);
+    return r;
+}
+// exact limbs (< 2^29 each below the top): sequential carries
+template <class P> __device__ __forceinline__ F29<P> f29_norm(const F29<P>& a)
+{
+    F29<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t t = a.v[i] + c;
+        r.v[i] = t & M29;
+        c = t >> 29;
+    }
+    r.v[8] = a.v[8] + c;
+    return r;
+}
+// 8 x u32 words of an exactly normalised value < 2^256
+template <int I> __device__ __forceinline__ uint32_t f29_join_word(const uint32_t* a)
+{
+    constexpr int j = (32 * I) / 29, o = 32 * I - 29 * j;
+    uint32_t w = a[j] >> o;
+    if constexpr (j + 1 < 9) w |= a[j + 1] << (29 - o);
+    if constexpr (j + 2 < 9 && 58 - o < 32) w |= a[j + 2] << (58 - o);
+    return w;
+}
+template <class P> __device__ __forceinline__ Fe<P> f29_to_fe(const F29<P>& a0)
+{
+    const F29<P> a = f29_norm(a0);
+    Fe<P> r;
+    r.v[0] = f29_join_word<0>(a.v);
+    r.v[1] = f29_join_word<1>(a.v);
+    r.v[2] = f29_join_word<2>(a.v);
+    r.v[3] = f29_join_word<3>(a.v);
+    r.v[4] = f29_join_word<4>(a.v);
+    r.v[5] = f29_join_word<5>(a.v);
+    r.v[6] = f29_join_word<6>(a.v);
+    r.v[7] = f29_join_word<7>(a.v);
+    return r;
+}
+
+// ---- R'-form -> R-form without a multiplication: x R' / 32 = x R.  Division by 32 mod p = one Montgomery step with a 5-bit digit:
+// m = -x p^-1 mod 32 makes x + m p divisible by 32.  The 32 multiples m p come from a table (LDS, filled by f29_fill_div32_table: rows of 12 words,
+// 9 used); the shift by 5 bits is folded into the word join.  Input < 2^261 - 31p (any lazily reduced value), output < (x + 31p) / 32.
+constexpr int DIV32_ROW = 12;
+template <class P> __device__ __forceinline__ void f29_fill_div32_table(uint32_t* tbl, int m)
+{
+    // row m = m * p in radix 2^29 (exact limbs, the top one < 2^27)
+    uint64_t carry = 0;
+    uint32_t w[9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t x = (uint64_t)P::MOD[i] * (uint32_t)m + carry;
+        w[i] = (uint32_t)x;
+        carry = x >> 32;
+    }
+    w[8] = (uint32_t)carry;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int b = 29 * j, i = b >> 5, o = b & 31;
+        const uint64_t lo = w[i], hi = i + 1 < 9 ? w[i + 1] : 0;
+        tbl[m * DIV32_ROW + j] = (uint32_t)(((lo | (hi << 32)) >> o) & M29);
+    }
+}
+template <int I> __device__ __forceinline__ uint32_t f29_join_word_div32(const uint32_t* a)
+{
+    constexpr int b = 32 * I + 5, j = b / 29, o = b - 29 * j;
+    uint32_t w = a[j] >> o;
+    if constexpr (j + 1 < 9) w |= a[j + 1] << (29 - o);
+    if constexpr (j + 2 < 9 && 58 - o < 32) w |= a[j + 2] << (58 - o);
+    return w;
+}
+template <class P> __device__ __forceinline__ Fe<P> f29_div32_to_fe(const F29<P>& x, const uint32_t* tbl)
+{
+    constexpr uint32_t NINV5 = (32u - ((P::MOD[0] * P::MOD[0] * P::MOD[0] * P::MOD[0] * P::MOD[0] * P::MOD[0] * P::MOD[0]) & 31u)) & 31u; // -p^-1 mod 32 (p^8 = 1 mod 32)
+    const uint32_t m = (x.v[0] * NINV5) & 31u;
+    const uint4* row = reinterpret_cast<const uint4*>(tbl + m * DIV32_ROW);
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2];
+    F29<P> t;
+    t.v[0] = x.v[0] + r0.x; t.v[1] = x.v[1] + r0.y; t.v[2] = x.v[2] + r0.z; t.v[3] = x.v[3] + r0.w;
+    t.v[4] = x.v[4] + r1.x; t.v[5] = x.v[5] + r1.y; t.v[6] = x.v[6] + r1.z; t.v[7] = x.v[7] + r1.w;
+    t.v[8] = x.v[8] + r2.x;
+    const F29<P> a = f29_norm(t);
+    Fe<P> r;
+    r.v[0] = f29_join_word_div32<0>(a.v);
+    r.v[1] = f29_join_word_div32<1>(a.v);
+    r.v[2] = f29_join_word_div32<2>(a.v);
+    r.v[3] = f29_join_word_div32<3>(a.v);
+    r.v[4] = f29_join_word_div32<4>(a.v);
+    r.v[5] = f29_join_word_div32<5>(a.v);
+    r.v[6] = f29_join_word_div32<6>(a.v);
+    r.v[7] = f29_join_word_div32<7>(a.v);
+    return r;
+}
+
+template <class P> __device__ __forceinline__ F29<P> f29_add(const F29<P>& a, const F29<P>& b)
+{
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+// a - b + M p, limbwise (b limbs <= 2^E - 2, b < M p with the top-limb margin above); result limbs < a limb + 2^E + 2^29
+template <class P, int J, int K, int E> __device__ __forceinline__ uint32_t f29_sub_limb(uint32_t a, uint32_t b)
+{
+    return a + (Spread29<P, J, K, E>::value - b);
+}
+template <int K, int E = 30, class P> __device__ __forceinline__ F29<P> f29_sub(const F29<P>& a, const F29<P>& b)
+{
+    F29<P> r;
+    r.v[0] = f29_sub_limb<P, 0, K, E>(a.v[0], b.v[0]);
+    r.v[1] = f29_sub_limb<P, 1, K, E>(a.v[1], b.v[1]);
+    r.v[2] = f29_sub_limb<P, 2, K, E>(a.v[2], b.v[2]);
+    r.v[3] = f29_sub_limb<P, 3, K, E>(a.v[3], b.v[3]);
+    r.v[4] = f29_sub_limb<P, 4, K, E>(a.v[4], b.v[4]);
+    r.v[5] = f29_sub_limb<P, 5, K, E>(a.v[5], b.v[5]);
+    r.v[6] = f29_sub_limb<P, 6, K, E>(a.v[6], b.v[6]);
+    r.v[7] = f29_sub_limb<P, 7, K, E>(a.v[7], b.v[7]);
+    r.v[8] = f29_sub_limb<P, 8, K, E>(a.v[8], b.v[8]);
+    return r;
+}
+
+// ---- Montgomery product, product scanning over 29-bit limbs
+template <class P, int K> __device__ __forceinline__ void f29_mp_terms(uint64_t& acc, const uint32_t* m)
+{
+    // sum over i of m[i] * p[K - i], i in [max(0, K - 8), min(K, 8)] except the i = K term of the low columns (added after m[K] exists)
+    constexpr int lo = K > 8 ? K - 8 : 0, hi = K > 8 ? 8 : K - 1;
+    if constexpr (lo <= hi) {
+        if constexpr (lo <= 0 && 0 <= hi) acc += (uint64_t)m[0] * P29<P, (K - 0 >= 0 && K - 0 <= 8) ? K - 0 : 0>::value;
+        if constexpr (lo <= 1 && 1 <= hi) acc += (uint64_t)m[1] * P29<P, (K - 1 >= 0 && K - 1 <= 8) ? K - 1 : 0>::value;
+        if constexpr (lo <= 2 && 2 <= hi) acc += (uint64_t)m[2] * P29<P, (K - 2 >= 0 && K - 2 <= 8) ? K - 2 : 0>::value;
+        if constexpr (lo <= 3 && 3 <= hi) acc += (uint64_t)m[3] * P29<P, (K - 3 >= 0 && K - 3 <= 8) ? K - 3 : 0>::value;
+        if constexpr (lo <= 4 && 4 <= hi) acc += (uint64_t)m[4] * P29<P, (K - 4 >= 0 && K - 4 <= 8) ? K - 4 : 0>::value;
+        if constexpr (lo <= 5 && 5 <= hi) acc += (uint64_t)m[5] * P29<P, (K - 5 >= 0 && K - 5 <= 8) ? K - 5 : 0>::value;
+        if constexpr (lo <= 6 && 6 <= hi) acc += (uint64_t)m[6] * P29<P, (K - 6 >= 0 && K - 6 <= 8) ? K - 6 : 0>::value;
+        if constexpr (lo <= 7 && 7 <= hi) acc += (uint64_t)m[7] * P29<P, (K - 7 >= 0 && K - 7 <= 8) ? K - 7 : 0>::value;
+        if constexpr (lo <= 8 && 8 <= hi) acc += (uint64_t)m[8] * P29<P, (K - 8 >= 0 && K - 8 <= 8) ? K - 8 : 0>::value;
+    }
+}
+template <int K> __device__ __forceinline__ void f29_ab_terms(uint64_t& acc, const uint32_t* a, const uint32_t* b)
+{
+    constexpr int lo = K > 8 ? K - 8 : 0, hi = K > 8 ? 8 : K;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) acc += (uint64_t)a[i] * b[K - i];
+}
+// the reduction half shared by every product shape: closes column K after its a*b terms were added
+template <class P, int K> __device__ __forceinline__ void f29_close_column(uint64_t& acc, uint32_t* m, uint32_t* r)
+{
+    f29_mp_terms<P, K>(acc, m);
+    if constexpr (K <= 8) {
+        m[K] = ((uint32_t)acc * (P::INV & M29)) & M29;
+        acc += (uint64_t)m[K] * P29<P, 0>::value;
+    } else {
+        r[K - 9] = (uint32_t)acc & M29;
+    }
+    acc >>= 29;
+}
+#define BBG_F29_COLUMNS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
+template <class P> __device__ __forceinline__ F29<P> f29_mul(const F29<P>& a, const F29<P>& b)
+{
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29<P> r;
+#define BBG_X(K) f29_ab_terms<K>(acc, a.v, b.v); f29_close_column<P, K>(acc, m, r.v);
+    BBG_F29_COLUMNS(BBG_X)
+#undef BBG_X
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+// a^2: cross terms once against the doubled operand (limbs < 2^30: still inside the column bound)
+template <int K> __device__ __forceinline__ void f29_sq_terms(uint64_t& acc, const uint32_t* a, const uint32_t* d)
+{
+    constexpr int lo = K > 8 ? K - 8 : 0;
+#pragma unroll
+    for (int i = lo; 2 * i < K; i++) acc += (uint64_t)d[i] * a[K - i];
+    if constexpr (K % 2 == 0) acc += (uint64_t)a[K / 2] * a[K / 2];
+}
+template <class P> __device__ __forceinline__ F29<P> f29_sqr(const F29<P>& a)
+{
+    uint64_t acc = 0;
+    uint32_t m[9], d[9];
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+#define BBG_X(K) f29_sq_terms<K>(acc, a.v, d); f29_close_column<P, K>(acc, m, r.v);
+    BBG_F29_COLUMNS(BBG_X)
+#undef BBG_X
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+// (a * b - c * d) / R' + multiple of p with ONE reduction (the Y3 shape of the XYZZ group laws; field.hip.h fe_mul_sub2):
+// c is replaced by 64p - c limbwise (limbs < 2^31 for c limbs < 2^30), d must be carried (limbs < 2^29 + 8):
+// columns stay below 9 * 2^58 + 9 * 2^60 + 9 * 2^58 < 2^64.  c < 63p.
+template <class P> __device__ __forceinline__ F29<P> f29_mul_sub2(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d)
+{
+    F29<P> z;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z.v[i] = 0;
+    const F29<P> nc = f29_sub<64, 30>(z, c);
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29<P> r;
+#define BBG_X(K) f29_ab_terms<K>(acc, a.v, b.v); f29_ab_terms<K>(acc, nc.v, d.v); f29_close_column<P, K>(acc, m, r.v);
+    BBG_F29_COLUMNS(BBG_X)
+#undef BBG_X
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+} // namespace bbg

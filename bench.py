@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-sweeps", action="store_true", help="skip extra.host_path / extra.ntt_sweep / extra.msm_sweep (SURVEY 8d tables)")
     ap.add_argument("--reduce-priority", type=int, default=-1, help="A/B: 1 = low-priority auxiliary stream for the MSM reduce phase (library default), 0 = normal")
     ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, or a compiled width (A/B runs)")
+    ap.add_argument("--limbs29", type=int, default=-1, help="A/B: bucket accumulation on 9 x 29-bit limbs (1, default) or 8 x 32 (0)")
     ap.add_argument("--acc-waves", type=int, default=-1, help="A/B: lane segments per SIMD lane of the bucket accumulation (0 = automatic)")
     ap.add_argument("--reduce-quad", type=int, default=-1, help="A/B: msm_reduce_quad stage mask (library default 14)")
     args = ap.parse_args()
@@ -155,6 +156,8 @@ def main():
         bbg.set_option("msm_window", args.msm_window)
     if args.reduce_priority >= 0:
         bbg.set_option("msm_reduce_priority", args.reduce_priority)
+    if args.limbs29 >= 0:
+        bbg.set_option("msm_limbs29", args.limbs29)
     if args.acc_waves >= 0:
         bbg.set_option("msm_acc_waves", args.acc_waves)
     if args.reduce_quad >= 0:
