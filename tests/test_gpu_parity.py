@@ -446,6 +446,70 @@ def test_msm_option_matrix_is_bit_identical(pkg, oracle, bbg, srs16):
         bbg.set_option("msm_async_reduce", 0)
 
 
+def test_msm_limbs29_degenerate_runs(pkg, oracle, bbg, srs16):
+    """The 29-bit-limb accumulation (option msm_limbs29, default) does not test P = +-acc per addition: a run that meets one ends with
+    ZZ = 0 mod p and its bucket is recomputed by k_redo.  Inputs made of such runs -- all points equal (every addition a doubling), every
+    point twice with the same scalar, P and -P with the same scalar, points at infinity inside runs -- against the oracle and against the
+    32-bit-limb kernel, one-lane accumulation forced (small MSMs otherwise take the quad kernel), at every window width."""
+    pts = srs16.read(0, 4096)
+    zero4 = np.zeros((1, 4), dtype=np.uint64)
+    n = 4096
+    sc = pkg.synthetic_scalars(2929, n)
+    cases = {}
+    cases["all_points_equal"] = (np.tile(pts[:1], (n, 1)), sc)
+    twice = np.repeat(pts[:n // 2], 2, axis=0)
+    cases["every_point_twice_same_scalar"] = (twice, np.repeat(sc[:n // 2], 2, axis=0))
+    pm = twice.copy()
+    pm[1::2, 4:] = oracle.fe_sub(1, np.tile(zero4, (n // 2, 1)), pm[1::2, 4:])  # odd rows: -P
+    cases["p_and_minus_p_same_scalar"] = (pm, np.repeat(sc[:n // 2], 2, axis=0))
+    few = np.tile(pkg.synthetic_scalars(2930, 3), (n // 3 + 1, 1))[:n]
+    mixed_pts = np.tile(pts[:5], (n // 5 + 1, 1))[:n].copy()
+    mixed_pts[7::11] = 0
+    mixed_pts[7::11, 3] = np.uint64(1) << np.uint64(63)  # points at infinity (reference convention)
+    cases["five_points_three_scalars_with_infinities"] = (mixed_pts, few)
+    try:
+        bbg.set_option("msm_accumulate_quad", 0)
+        for name, (p_, s_) in cases.items():
+            srs = bbg.srs_register(p_)
+            want = oracle.msm_naive(s_, p_)  # complete group law, term by term
+            for window in MSM_WINDOWS:
+                bbg.set_option("msm_window", window)
+                res = []
+                for limbs29 in (1, 0):
+                    bbg.set_option("msm_limbs29", limbs29)
+                    for overlap in (0, 1):
+                        bbg.set_option("msm_async_reduce", overlap)
+                        res.append(bbg.msm(srs, s_))
+                for r_ in res:
+                    if int(want[3]) >> 63:
+                        assert int(r_[3]) >> 63 == 1, (name, window)
+                    else:
+                        assert np.array_equal(oracle.jac_to_affine(r_), want), (name, window)
+            srs.free()
+    finally:
+        bbg.set_option("msm_accumulate_quad", 1)
+        bbg.set_option("msm_limbs29", 1)
+        bbg.set_option("msm_async_reduce", 0)
+        bbg.set_option("msm_window", 0)
+
+
+def test_msm_limbs29_equals_limbs32_2_16(pkg, oracle, bbg, srs16):
+    """Default path at 2^16 (one-lane accumulation): both limb formats, all-equal points and hashed points, identical Jacobian results."""
+    n = 1 << 16
+    sc = pkg.synthetic_scalars(2931, n)
+    eq = bbg.srs_register(np.tile(srs16.read(0, 1), (n, 1)))
+    try:
+        for srs in (srs16, eq):
+            got = []
+            for limbs29 in (1, 0):
+                bbg.set_option("msm_limbs29", limbs29)
+                got.append(oracle.jac_to_affine(bbg.msm(srs, sc)))
+            assert np.array_equal(got[0], got[1])
+    finally:
+        bbg.set_option("msm_limbs29", 1)
+        eq.free()
+
+
 @pytest.mark.parametrize("window", [17, 19, 20, 22])
 def test_msm_wide_windows_vs_oracle(pkg, oracle, bbg, golden, srs16, window):
     """Every wider window configuration (chosen automatically only for large n) forced at small sizes: oracle parity, `from` offsets,
