@@ -17,6 +17,7 @@
 // is a division by 32 mod p: one 5-bit Montgomery step against a table of the multiples of p (f29_div32_to_fe).
 #pragma once
 #include "field.hip.h"
+#include "mad_chains29.hip.h"
 
 namespace bbg {
 
@@ -218,27 +219,51 @@ template <int K, int E = 30, class P> __device__ __forceinline__ F29<P> f29_sub(
 }
 
 // ---- Montgomery product, product scanning over 29-bit limbs
+// N products x[i] * y[-i] into acc (mad_chains29.hip.h: one asm statement)
+template <int N> __device__ __forceinline__ void mad_col_v(uint64_t& acc, const uint32_t* x, const uint32_t* y)
+{
+    if constexpr (N == 1) mad1_v(acc, x[0], y[0]);
+    else if constexpr (N == 2) mad2_v(acc, x[0], y[0], x[1], y[-1]);
+    else if constexpr (N == 3) mad3_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2]);
+    else if constexpr (N == 4) mad4_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3]);
+    else if constexpr (N == 5) mad5_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4]);
+    else if constexpr (N == 6) mad6_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5]);
+    else if constexpr (N == 7) mad7_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6]);
+    else if constexpr (N == 8)
+        mad8_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6], x[7], y[-7]);
+    else if constexpr (N == 9)
+        mad9_v(acc, x[0], y[0], x[1], y[-1], x[2], y[-2], x[3], y[-3], x[4], y[-4], x[5], y[-5], x[6], y[-6], x[7], y[-7], x[8], y[-8]);
+}
+// N products x[i] * p[J - i], modulus limbs as SGPR operands
+template <class P, int N, int J> __device__ __forceinline__ void mad_col_mod(uint64_t& acc, const uint32_t* x)
+{
+#define BBG_PL(I) P29<P, (J - (I) >= 0 && J - (I) <= 8) ? J - (I) : 0>::value
+    if constexpr (N == 1) mad1_s(acc, x[0], BBG_PL(0));
+    else if constexpr (N == 2) mad2_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1));
+    else if constexpr (N == 3) mad3_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2));
+    else if constexpr (N == 4) mad4_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2), x[3], BBG_PL(3));
+    else if constexpr (N == 5) mad5_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2), x[3], BBG_PL(3), x[4], BBG_PL(4));
+    else if constexpr (N == 6) mad6_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2), x[3], BBG_PL(3), x[4], BBG_PL(4), x[5], BBG_PL(5));
+    else if constexpr (N == 7)
+        mad7_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2), x[3], BBG_PL(3), x[4], BBG_PL(4), x[5], BBG_PL(5), x[6], BBG_PL(6));
+    else if constexpr (N == 8)
+        mad8_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2), x[3], BBG_PL(3), x[4], BBG_PL(4), x[5], BBG_PL(5), x[6], BBG_PL(6), x[7],
+               BBG_PL(7));
+    else if constexpr (N == 9)
+        mad9_s(acc, x[0], BBG_PL(0), x[1], BBG_PL(1), x[2], BBG_PL(2), x[3], BBG_PL(3), x[4], BBG_PL(4), x[5], BBG_PL(5), x[6], BBG_PL(6), x[7],
+               BBG_PL(7), x[8], BBG_PL(8));
+#undef BBG_PL
+}
 template <class P, int K> __device__ __forceinline__ void f29_mp_terms(uint64_t& acc, const uint32_t* m)
 {
     // sum over i of m[i] * p[K - i], i in [max(0, K - 8), min(K, 8)] except the i = K term of the low columns (added after m[K] exists)
     constexpr int lo = K > 8 ? K - 8 : 0, hi = K > 8 ? 8 : K - 1;
-    if constexpr (lo <= hi) {
-        if constexpr (lo <= 0 && 0 <= hi) acc += (uint64_t)m[0] * P29<P, (K - 0 >= 0 && K - 0 <= 8) ? K - 0 : 0>::value;
-        if constexpr (lo <= 1 && 1 <= hi) acc += (uint64_t)m[1] * P29<P, (K - 1 >= 0 && K - 1 <= 8) ? K - 1 : 0>::value;
-        if constexpr (lo <= 2 && 2 <= hi) acc += (uint64_t)m[2] * P29<P, (K - 2 >= 0 && K - 2 <= 8) ? K - 2 : 0>::value;
-        if constexpr (lo <= 3 && 3 <= hi) acc += (uint64_t)m[3] * P29<P, (K - 3 >= 0 && K - 3 <= 8) ? K - 3 : 0>::value;
-        if constexpr (lo <= 4 && 4 <= hi) acc += (uint64_t)m[4] * P29<P, (K - 4 >= 0 && K - 4 <= 8) ? K - 4 : 0>::value;
-        if constexpr (lo <= 5 && 5 <= hi) acc += (uint64_t)m[5] * P29<P, (K - 5 >= 0 && K - 5 <= 8) ? K - 5 : 0>::value;
-        if constexpr (lo <= 6 && 6 <= hi) acc += (uint64_t)m[6] * P29<P, (K - 6 >= 0 && K - 6 <= 8) ? K - 6 : 0>::value;
-        if constexpr (lo <= 7 && 7 <= hi) acc += (uint64_t)m[7] * P29<P, (K - 7 >= 0 && K - 7 <= 8) ? K - 7 : 0>::value;
-        if constexpr (lo <= 8 && 8 <= hi) acc += (uint64_t)m[8] * P29<P, (K - 8 >= 0 && K - 8 <= 8) ? K - 8 : 0>::value;
-    }
+    if constexpr (lo <= hi) mad_col_mod<P, hi - lo + 1, K - lo>(acc, m + lo);
 }
 template <int K> __device__ __forceinline__ void f29_ab_terms(uint64_t& acc, const uint32_t* a, const uint32_t* b)
 {
     constexpr int lo = K > 8 ? K - 8 : 0, hi = K > 8 ? 8 : K;
-#pragma unroll
-    for (int i = lo; i <= hi; i++) acc += (uint64_t)a[i] * b[K - i];
+    mad_col_v<hi - lo + 1>(acc, a + lo, b + (K - lo));
 }
 // the reduction half shared by every product shape: closes column K after its a*b terms were added
 template <class P, int K> __device__ __forceinline__ void f29_close_column(uint64_t& acc, uint32_t* m, uint32_t* r)
@@ -246,11 +271,11 @@ template <class P, int K> __device__ __forceinline__ void f29_close_column(uint6
     f29_mp_terms<P, K>(acc, m);
     if constexpr (K <= 8) {
         m[K] = ((uint32_t)acc * (P::INV & M29)) & M29;
-        acc += (uint64_t)m[K] * P29<P, 0>::value;
+        mad1_s(acc, m[K], P29<P, 0>::value);
     } else {
         r[K - 9] = (uint32_t)acc & M29;
     }
-    acc >>= 29;
+    asm("v_lshrrev_b64 %0, 29, %0" : "+v"(acc)); // (as asm like the chains: the compiler must not split the column sums off the carried-in value)
 }
 #define BBG_F29_COLUMNS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 
@@ -269,10 +294,9 @@ template <class P> __device__ __forceinline__ F29<P> f29_mul(const F29<P>& a, co
 // a^2: cross terms once against the doubled operand (limbs < 2^30: still inside the column bound)
 template <int K> __device__ __forceinline__ void f29_sq_terms(uint64_t& acc, const uint32_t* a, const uint32_t* d)
 {
-    constexpr int lo = K > 8 ? K - 8 : 0;
-#pragma unroll
-    for (int i = lo; 2 * i < K; i++) acc += (uint64_t)d[i] * a[K - i];
-    if constexpr (K % 2 == 0) acc += (uint64_t)a[K / 2] * a[K / 2];
+    constexpr int lo = K > 8 ? K - 8 : 0, n = (K + 1) / 2 - lo; // i = lo .. (K - 1) / 2
+    if constexpr (n > 0) mad_col_v<n>(acc, d + lo, a + (K - lo));
+    if constexpr (K % 2 == 0) mad1_v(acc, a[K / 2], a[K / 2]);
 }
 template <class P> __device__ __forceinline__ F29<P> f29_sqr(const F29<P>& a)
 {

@@ -236,7 +236,7 @@ def main():
                 "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
-    width = args.msm_window or (22 if n >= (1 << 23) else 20 if n >= (1 << 20) else 16)  # csrc/msm.hip msm_auto_window
+    width = args.msm_window or (22 if n >= (1 << 23) else 20 if n >= (1 << 21) else 19 if n >= (1 << 20) else 16)  # csrc/msm.hip msm_auto_window
     msm_windows = float((254 + width) // width)
     pass_ms = avg("ntt_pass")
     ntt_alg = 64.0 * n
@@ -256,10 +256,10 @@ def main():
         "timed_blocks_ms": [round(b[0] * 1e3, 3) for b in blocks], "reported_block": "median",
         "valu_issue": valu_issue(acc_ms, ntt_ms),
         "alu": {"unit": "T v_mad_u64_u32/s", "peak_measured": MAD_PEAK_TOPS,
-                # windows x n mixed additions x 10 Fq mul x 136 mads (13 windows of 20 bits from n = 2^20, else 16 of 16 bits);
-                # n/2*(lg - passes) + n*(passes-1) Fr mul x 136
+                # windows x n mixed additions x 1467 mads (k_accumulate29: 7 products of 162 + 2 squares of 126 + 1 double product of 243 on
+                # 29-bit limbs; 14 windows of 19 bits at n = 2^20); NTT: n/2*(lg - passes) + n*(passes-1) Fr products x 136 (32-bit limbs)
                 "msm_windows": msm_windows,
-                "msm_accumulate": round(msm_windows * n * 10 * 136 / (acc_ms * 1e-3) / 1e12, 2),
+                "msm_accumulate": round(msm_windows * n * 1467 / (acc_ms * 1e-3) / 1e12, 2),
                 "ntt": round((n / 2 * (lg - ntt_passes) + n * (ntt_passes - 1)) * 136 / (ntt_ms * 1e-3) / 1e12, 2)},
     }
 
