@@ -6,7 +6,7 @@
 #include <cstdint>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-constexpr int ITERS = 512;
+constexpr int ITERS = 8192;
 #define R8(X) X X X X X X X X
 
 template <int OP> __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed)
@@ -61,6 +61,20 @@ template <int OP> __global__ void __launch_bounds__(256) k(uint32_t* out, uint32
             asm volatile(R8("v_mul_u32_u24 %0, %1, %0\n\tv_mul_u32_u24 %2, %3, %2\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f));
         if (OP == 14) // 16 v_mul_hi_u32_u24
             asm volatile(R8("v_mul_hi_u32_u24 %0, %1, %0\n\tv_mul_hi_u32_u24 %2, %3, %2\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+        if (OP == 15) // 16 v_lshrrev_b32
+            asm volatile(R8("v_lshrrev_b32 %0, 3, %0\n\tv_lshrrev_b32 %2, 5, %2\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+        if (OP == 16) // 16 v_cndmask_b32
+            asm volatile(R8("v_cndmask_b32 %0, %1, %0, vcc\n\tv_cndmask_b32 %2, %3, %2, vcc\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "vcc");
+        if (OP == 18) { // 16 v_cndmask_b32 under an SGPR-pair mask (the form the compiler emits for selects)
+            const unsigned long long msk = __ballot((tid & 3) == 1);
+            asm volatile(R8("v_cndmask_b32_e64 %0, %1, %0, %4\n\tv_cndmask_b32_e64 %2, %3, %2, %4\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "s"(msk));
+        }
+        if (OP == 19) { // 16 v_cndmask_b32 alternating two destinations (no back-to-back dependence)
+            const unsigned long long msk = __ballot((tid & 3) == 1);
+            asm volatile(R8("v_cndmask_b32_e64 %0, %1, %3, %4\n\tv_cndmask_b32_e64 %2, %3, %1, %4\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "s"(msk));
+        }
+        if (OP == 17) // 16 v_alignbit_b32
+            asm volatile(R8("v_alignbit_b32 %0, %1, %0, 29\n\tv_alignbit_b32 %2, %3, %2, 29\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f));
     }
     out[tid] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7) ^ c ^ d ^ e ^ f;
 }
@@ -90,7 +104,7 @@ int main()
 {
     uint32_t* out;
     CK(hipMalloc(&out, 256 * 16 * 256 * 4));
-    for (int w : { 4, 8 }) {
+    for (int w : { 8 }) {
         run<2>("v_add_u32", 16, out, w);
         run<12>("v_and_b32", 16, out, w);
         run<3>("v_addc_co_u32", 16, out, w);
@@ -106,6 +120,10 @@ int main()
         run<7>("v_lshrrev_b64", 8, out, w);
         run<8>("v_lshl_add_u64", 8, out, w);
         run<11>("v_fma_f64", 8, out, w);
+        run<15>("v_lshrrev_b32", 16, out, w);
+        run<17>("v_alignbit_b32", 16, out, w);
+        run<18>("v_cndmask_b32 (SGPR mask)", 16, out, w);
+        run<19>("v_cndmask_b32 (SGPR mask, independent)", 16, out, w);
     }
     return 0;
 }
