@@ -60,14 +60,13 @@ __device__ __forceinline__ Xyzz29 xyzz29_from_affine(const Aff29& p)
 
 __device__ __forceinline__ Xyzz29 xyzz29_madd(const Xyzz29& a, const Aff29& p)
 {
-    const Fq29 U2 = f29_mul(p.x, a.zz);                  // < 32 * 1.4 p * 2^-7.4 + p = 1.3p
-    const Fq29 S2 = f29_mul(p.y, a.zzz);
+    // products in independent pairs (f29_mul2 ...: columns interleaved, see field29.hip.h)
+    Fq29 U2, S2, PP, RR, PPP, Q;
+    f29_mul2(p.x, a.zz, p.y, a.zzz, U2, S2);             // < 32 * 1.4 p * 2^-7.4 + p = 1.3p
     const Fq29 P = f29_carry(f29_sub<34>(U2, a.x));      // U2 - X1 + 34p < 35.3p
     const Fq29 R = f29_carry(f29_sub<34>(S2, a.y));      // < 35.3p
-    const Fq29 PP = f29_sqr(P);                          // < 35.3^2 * 2^-7.4 p + p = 8.4p
-    const Fq29 PPP = f29_mul(P, PP);                     // < 2.8p
-    const Fq29 Q = f29_mul(a.x, PP);                     // < 32 * 8.4 * 2^-7.4 p + p = 2.6p
-    const Fq29 RR = f29_sqr(R);                          // < 8.4p
+    f29_sqr2(P, R, PP, RR);                              // < 35.3^2 * 2^-7.4 p + p = 8.4p
+    f29_mul2(P, PP, a.x, PP, PPP, Q);                    // PPP < 2.8p; Q < 32 * 8.4 * 2^-7.4 p + p = 2.6p
     Xyzz29 r;
     // X3 = R^2 - PPP - 2Q + 12p: the subtrahend (< 8p) has limbs < 3 * 2^29, so this spread constant raises every limb by 2^31
     {
@@ -77,9 +76,8 @@ __device__ __forceinline__ Xyzz29 xyzz29_madd(const Xyzz29& a, const Aff29& p)
         r.x = f29_carry(f29_sub<12, 31>(RR, s));         // < 20.4p
     }
     const Fq29 T = f29_carry(f29_sub<24>(Q, r.x));       // Q - X3 + 24p < 26.6p
-    r.y = f29_mul_sub2(R, T, a.y, PPP);                  // (35.3 * 26.6 + 64 * 2.8) * 2^-7.4 p + p < 7.7p
+    f29_mul_sub2_mul(R, T, a.y, PPP, a.zzz, PPP, r.y, r.zzz); // Y3 < (35.3 * 26.6 + 64 * 2.8) * 2^-7.4 p + p < 7.7p; ZZZ3 = ZZZ1 PPP
     r.zz = f29_mul(a.zz, PP);                            // < 1.4 * 8.4 * 2^-7.4 p + p = 1.1p
-    r.zzz = f29_mul(a.zzz, PPP);
     return r;
 }
 

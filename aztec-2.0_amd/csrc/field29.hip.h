@@ -331,4 +331,83 @@ template <class P> __device__ __forceinline__ F29<P> f29_mul_sub2(const F29<P>& 
     return r;
 }
 
+// ---- two independent products, columns interleaved.  hipcc cannot see inside an asm statement and puts an `s_nop 0` behind every one whose
+// result the NEXT instruction reads (gfx940's trans-use hazard, assumed for any inline asm): ~45 per multiplication, 1.2 clocks each at three
+// waves per SIMD (bench_micro/issue_rates.hip) -- 5 % of the bucket accumulation.  With two products in flight every statement is followed by
+// the other product's, and the independent chains also hide each other's latency.
+enum F29Shape { F29_MUL, F29_SQR, F29_MULSUB2 };
+template <class P, int SHAPE> struct F29Job {
+    const uint32_t *a, *b, *c, *d; // MUL: a * b; SQR: a * a (b = doubled a); MULSUB2: a * b + c * d (c already negated)
+    uint64_t acc;
+    uint32_t m[9];
+    uint32_t* r;
+};
+template <class P, int SHAPE, int K> __device__ __forceinline__ void f29_job_terms(F29Job<P, SHAPE>& j)
+{
+    if constexpr (SHAPE == F29_SQR) f29_sq_terms<K>(j.acc, j.a, j.b);
+    else {
+        f29_ab_terms<K>(j.acc, j.a, j.b);
+        if constexpr (SHAPE == F29_MULSUB2) f29_ab_terms<K>(j.acc, j.c, j.d);
+    }
+}
+template <class P, int S1, int S2, int K> __device__ __forceinline__ void f29_pair_column(F29Job<P, S1>& x, F29Job<P, S2>& y)
+{
+    f29_job_terms<P, S1, K>(x);
+    f29_job_terms<P, S2, K>(y);
+    f29_mp_terms<P, K>(x.acc, x.m);
+    f29_mp_terms<P, K>(y.acc, y.m);
+    if constexpr (K <= 8) {
+        x.m[K] = ((uint32_t)x.acc * (P::INV & M29)) & M29;
+        y.m[K] = ((uint32_t)y.acc * (P::INV & M29)) & M29;
+        mad1_s(x.acc, x.m[K], P29<P, 0>::value);
+        mad1_s(y.acc, y.m[K], P29<P, 0>::value);
+    } else {
+        x.r[K - 9] = (uint32_t)x.acc & M29;
+        y.r[K - 9] = (uint32_t)y.acc & M29;
+    }
+    asm("v_lshrrev_b64 %0, 29, %0" : "+v"(x.acc));
+    asm("v_lshrrev_b64 %0, 29, %0" : "+v"(y.acc));
+}
+template <class P, int S1, int S2> __device__ __forceinline__ void f29_pair_run(F29Job<P, S1>& x, F29Job<P, S2>& y)
+{
+    x.acc = 0;
+    y.acc = 0;
+#define BBG_X(K) f29_pair_column<P, S1, S2, K>(x, y);
+    BBG_F29_COLUMNS(BBG_X)
+#undef BBG_X
+    x.r[8] = (uint32_t)x.acc;
+    y.r[8] = (uint32_t)y.acc;
+}
+// r1 = a1 * b1, r2 = a2 * b2
+template <class P> __device__ __forceinline__ void f29_mul2(const F29<P>& a1, const F29<P>& b1, const F29<P>& a2, const F29<P>& b2, F29<P>& r1, F29<P>& r2)
+{
+    F29Job<P, F29_MUL> x{ a1.v, b1.v, nullptr, nullptr, 0, {}, r1.v }, y{ a2.v, b2.v, nullptr, nullptr, 0, {}, r2.v };
+    f29_pair_run(x, y);
+}
+// r1 = a1^2, r2 = a2^2
+template <class P> __device__ __forceinline__ void f29_sqr2(const F29<P>& a1, const F29<P>& a2, F29<P>& r1, F29<P>& r2)
+{
+    uint32_t d1[9], d2[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        d1[i] = a1.v[i] << 1;
+        d2[i] = a2.v[i] << 1;
+    }
+    F29Job<P, F29_SQR> x{ a1.v, d1, nullptr, nullptr, 0, {}, r1.v }, y{ a2.v, d2, nullptr, nullptr, 0, {}, r2.v };
+    f29_pair_run(x, y);
+}
+// r1 = a * b - c * d (as f29_mul_sub2), r2 = e * f
+template <class P>
+__device__ __forceinline__ void f29_mul_sub2_mul(const F29<P>& a, const F29<P>& b, const F29<P>& c, const F29<P>& d, const F29<P>& e, const F29<P>& f,
+                                                 F29<P>& r1, F29<P>& r2)
+{
+    F29<P> z;
+#pragma unroll
+    for (int i = 0; i < 9; i++) z.v[i] = 0;
+    const F29<P> nc = f29_sub<64, 30>(z, c);
+    F29Job<P, F29_MULSUB2> x{ a.v, b.v, nc.v, d.v, 0, {}, r1.v };
+    F29Job<P, F29_MUL> y{ e.v, f.v, nullptr, nullptr, 0, {}, r2.v };
+    f29_pair_run(x, y);
+}
+
 } // namespace bbg

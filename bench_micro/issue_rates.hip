@@ -73,6 +73,14 @@ template <int OP> __global__ void __launch_bounds__(256) k(uint32_t* out, uint32
             const unsigned long long msk = __ballot((tid & 3) == 1);
             asm volatile(R8("v_cndmask_b32_e64 %0, %1, %3, %4\n\tv_cndmask_b32_e64 %2, %3, %1, %4\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "s"(msk));
         }
+        if (OP == 20) // 8 v_mad_u64_u32, an s_nop 0 after each (what hipcc puts behind every asm statement)
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\ts_nop 0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\ts_nop 0\n\tv_mad_u64_u32 %2, vcc, %8, %9, %2\n\ts_nop 0\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\ts_nop 0\n\t"
+                         "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\ts_nop 0\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\ts_nop 0\n\tv_mad_u64_u32 %6, vcc, %8, %9, %6\n\ts_nop 0\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7\n\ts_nop 0"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "vcc");
+        if (OP == 21) // 8 v_mad_u64_u32 in a DEPENDENT chain on one accumulator (a column of the 29-bit multiplier)
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %0, vcc, %9, %8, %0\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %0, vcc, %9, %8, %0\n\t"
+                         "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %0, vcc, %9, %8, %0\n\tv_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %0, vcc, %9, %8, %0"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "vcc");
         if (OP == 17) // 16 v_alignbit_b32
             asm volatile(R8("v_alignbit_b32 %0, %1, %0, 29\n\tv_alignbit_b32 %2, %3, %2, 29\n\t") : "+v"(c), "+v"(d), "+v"(e), "+v"(f));
     }
@@ -104,7 +112,7 @@ int main()
 {
     uint32_t* out;
     CK(hipMalloc(&out, 256 * 16 * 256 * 4));
-    for (int w : { 8 }) {
+    for (int w : { 3, 8 }) {
         run<2>("v_add_u32", 16, out, w);
         run<12>("v_and_b32", 16, out, w);
         run<3>("v_addc_co_u32", 16, out, w);
@@ -122,6 +130,8 @@ int main()
         run<11>("v_fma_f64", 8, out, w);
         run<15>("v_lshrrev_b32", 16, out, w);
         run<17>("v_alignbit_b32", 16, out, w);
+        run<20>("v_mad_u64_u32 + s_nop 0 (per mad)", 8, out, w);
+        run<21>("v_mad_u64_u32 dependent chain", 8, out, w);
         run<18>("v_cndmask_b32 (SGPR mask)", 16, out, w);
         run<19>("v_cndmask_b32 (SGPR mask, independent)", 16, out, w);
     }

@@ -330,6 +330,7 @@ int bbg_multi_ntt(bbg_multi* m, uint64_t* coeffs, unsigned log2n, int op);
  * in builds made with `make ROCPRIM_SORT=1`),
  * "msm_reduce_quad" (bit mask 0..15, default 14: reduce-phase stages with four lanes per EC operation -- bit 0 combine, 1 row/column sums, 2 bit
  * planes, 3 plane sum; 0 = the one-lane kernels), "msm_accumulate_quad" (1 = small MSMs accumulate with four threads per lane segment, default),
+ * "msm_limbs29" (1 = the bucket accumulation's field arithmetic on 9 x 29-bit limbs, default; 0 = on 8 x 32-bit limbs, A/B),
  * "msm_acc_waves" (0 = automatic; N > 0 = lane segments per SIMD lane of the bucket accumulation, A/B), "msm_reduce_priority" (1 = low-priority reduce streams, default), "msm_upload_pieces" (1..4, default 1: pieces the host scalars of bbg_msm travel in),
  * "quotient_fuse" (1 = arithmetic + range + logic widgets of a chain in one pass, default),
  * "ntt_kernel" (2 = register-resident radix-8 passes, default; 1 = radix-2 in LDS),
