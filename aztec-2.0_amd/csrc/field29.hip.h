@@ -331,6 +331,13 @@ template <class P> __device__ __forceinline__ F29<P> f29_mul_sub2(const F29<P>& 
     return r;
 }
 
+// a * b / 2^256 for 8 x u32 operands through the 29-bit multiplier: (a << 5) * b / 2^261.  Same contract as field.hip.h fe_mul: operands < 2p (or
+// < 4p and < p) give a result < 128 p^2 / 2^261 + p = 1.76p.
+template <class P> __device__ __forceinline__ Fe<P> fe_mul29(const Fe<P>& a, const Fe<P>& b)
+{
+    return f29_to_fe(f29_mul(f29_from_fe<P, 5>(a), f29_from_fe<P, 0>(b)));
+}
+
 // ---- two independent products, columns interleaved.  hipcc cannot see inside an asm statement and puts an `s_nop 0` behind every one whose
 // result the NEXT instruction reads (gfx940's trans-use hazard, assumed for any inline asm): ~45 per multiplication, 1.2 clocks each at three
 // waves per SIMD (bench_micro/issue_rates.hip) -- 5 % of the bucket accumulation.  With two products in flight every statement is followed by

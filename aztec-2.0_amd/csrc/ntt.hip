@@ -25,6 +25,10 @@
 
 #include <cstring>
 #include "field.hip.h"
+#ifdef BBG_NTT_MUL29 // A/B build: every product of the transform kernels through the 29-bit multiplier (field29.hip.h fe_mul29)
+#include "field29.hip.h"
+#define fe_mul fe_mul29
+#endif
 #include "ntt_consts.hip.h"
 
 namespace bbg {
