@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 SEED = 0xBB254
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-MAD_PEAK_TOPS = 28.0           # measured v_mad_u64_u32 issue rate, bench_micro/mulbench.hip (profiles/r01_mulbench.txt)
+MAD_PEAK_TOPS = 33.8           # v_mad_u64_u32 alone: 4.66 clocks per wave at 2.4 GHz on 1024 SIMDs (bench_micro/issue_rates.hip, profiles/r03_issue_rates.txt)
 
 
 def _latest_pmc_profile():
@@ -231,7 +231,7 @@ def main():
     acc_ms = avg("msm_accumulate")
     alg_bytes_msm = 96.0 * n                      # 32-B scalar + 64-B base per term, one launch covers all n terms
     achieved = alg_bytes_msm / (acc_ms * 1e-3) / 1e9
-    roofline = {"kernel": "k_accumulate (MSM bucket accumulation)", "bound": "hbm", "achieved": round(achieved, 2),
+    roofline = {"kernel": "k_accumulate29 (MSM bucket accumulation, 9 x 29-bit limbs)", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("k_accumulate"),
                 "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
