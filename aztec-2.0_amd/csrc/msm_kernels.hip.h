@@ -1010,6 +1010,9 @@ k_combine_long_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz*
 
 // QL logical lanes (4 QL threads) per row / column: each lane first sums its share serially, then a tree of log2 QL levels.  Fewer lanes =
 // more serial additions but fewer idle tree slots and fewer waves per SIMD (a tree level costs ~2.7 us with one wave per SIMD, ~7 with three).
+#ifndef BBG_ROWCOL_QL
+#define BBG_ROWCOL_QL 64 // logical lanes (quads) per row / column block
+#endif
 template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(const Xyzz* __restrict__ buckets, Xyzz* rows, Xyzz* cols)
 {
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
@@ -1315,7 +1318,7 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
         if (redo_pending) hipLaunchKernelGGL(k_redo<C>, dim3(128), dim3(256), 0, rst, svals, offsets, table, srs.n, redo, buckets);
         // 64 logical lanes per row / column (measured against 128 / 32 / 16: reduce phase 0.458 / 0.49 / 0.53 / 0.55 ms at 2^20 stand-alone,
         // 0.154 / 0.165 / 0.164 / 0.184 at 2^10; bench step equal for 64 and 128, worse below)
-        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, 64>), dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
+        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, BBG_ROWCOL_QL>), dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(4 * BBG_ROWCOL_QL), 0, rst, buckets, rows, cols);
         else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
         if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
         else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
