@@ -388,7 +388,9 @@ template <class P, int S1, int S2> __device__ __forceinline__ void f29_pair_run(
 // r1 = a1 * b1, r2 = a2 * b2
 template <class P> __device__ __forceinline__ void f29_mul2(const F29<P>& a1, const F29<P>& b1, const F29<P>& a2, const F29<P>& b2, F29<P>& r1, F29<P>& r2)
 {
-    F29Job<P, F29_MUL> x{ a1.v, b1.v, nullptr, nullptr, 0, {}, r1.v }, y{ a2.v, b2.v, nullptr, nullptr, 0, {}, r2.v };
+    F29Job<P, F29_MUL> x, y; // (no aggregate initialisation: it would zero the m digits, 18 v_mov per pair that nothing reads)
+    x.a = a1.v, x.b = b1.v, x.r = r1.v;
+    y.a = a2.v, y.b = b2.v, y.r = r2.v;
     f29_pair_run(x, y);
 }
 // r1 = a1^2, r2 = a2^2
@@ -400,7 +402,9 @@ template <class P> __device__ __forceinline__ void f29_sqr2(const F29<P>& a1, co
         d1[i] = a1.v[i] << 1;
         d2[i] = a2.v[i] << 1;
     }
-    F29Job<P, F29_SQR> x{ a1.v, d1, nullptr, nullptr, 0, {}, r1.v }, y{ a2.v, d2, nullptr, nullptr, 0, {}, r2.v };
+    F29Job<P, F29_SQR> x, y;
+    x.a = a1.v, x.b = d1, x.r = r1.v;
+    y.a = a2.v, y.b = d2, y.r = r2.v;
     f29_pair_run(x, y);
 }
 // r1 = a * b - c * d (as f29_mul_sub2), r2 = e * f
@@ -412,8 +416,10 @@ __device__ __forceinline__ void f29_mul_sub2_mul(const F29<P>& a, const F29<P>& 
 #pragma unroll
     for (int i = 0; i < 9; i++) z.v[i] = 0;
     const F29<P> nc = f29_sub<64, 30>(z, c);
-    F29Job<P, F29_MULSUB2> x{ a.v, b.v, nc.v, d.v, 0, {}, r1.v };
-    F29Job<P, F29_MUL> y{ e.v, f.v, nullptr, nullptr, 0, {}, r2.v };
+    F29Job<P, F29_MULSUB2> x;
+    F29Job<P, F29_MUL> y;
+    x.a = a.v, x.b = b.v, x.c = nc.v, x.d = d.v, x.r = r1.v;
+    y.a = e.v, y.b = f.v, y.r = r2.v;
     f29_pair_run(x, y);
 }
 
