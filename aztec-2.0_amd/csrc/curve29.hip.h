@@ -7,7 +7,7 @@
 // (bounds: a product is < a * b / 2^261 + p and p / 2^261 = 2^-7.4; the inline comments carry them through).
 // The special cases of a complete addition (P = +-acc) are NOT tested per addition: both make PP = (U2 - X1)^2 a multiple of p, so
 // ZZ becomes a multiple of p and stays one under every later addition -- the caller tests ZZ once at the end of a run
-// (xyzz29_finish) and recomputes the run with the complete 32-bit formulas if it is.
+// (xyzz29_finish) and, if it is, queues the run's bucket: k_redo recomputes that bucket with the complete 32-bit formulas (msm_kernels.hip.h).
 #pragma once
 #include "curve.hip.h"
 #include "field29.hip.h"
