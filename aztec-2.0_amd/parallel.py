@@ -47,10 +47,11 @@ def msm_sharded(bbg, srs_local, d_scalars_ptr, n_local, d_out_tensor, dist):
 
 
 class BbgOps:
-    """Adapter: the three device operations the sharded pipeline needs, on torch CUDA tensors."""
+    """Adapter: the three device operations the sharded pipeline needs, on torch CUDA tensors.  `bbg_side`: a second context whose stream is
+    the pipeline's side stream (the group sum of step i-1 then runs beside step i instead of in front of its NTT and the next sort)."""
 
-    def __init__(self, bbg, srs):
-        self.bbg, self.srs = bbg, srs
+    def __init__(self, bbg, srs, bbg_side=None):
+        self.bbg, self.srs, self.bbg_side = bbg, srs, bbg_side
 
     def msm(self, d_scalars, n, d_out):
         self.bbg.msm_device(self.srs, d_scalars.data_ptr(), n, d_out.data_ptr())
@@ -59,33 +60,58 @@ class BbgOps:
         self.bbg.join(lag)
 
     def g1_sum(self, d_jacobians, count, d_out):
-        self.bbg.g1_sum_device(d_jacobians.data_ptr(), count, d_out.data_ptr())
+        (self.bbg_side or self.bbg).g1_sum_device(d_jacobians.data_ptr(), count, d_out.data_ptr())
 
 
 class ShardedMsmPipeline:
     """One global MSM per submit(), sharded by point range over the ranks of `dist`, software-pipelined by one call:
     while rank-local MSM i is still in its bucket-reduction phase (auxiliary stream), the 96-byte partials of MSM i-1
     are all-gathered (RCCL) and summed.  flush() completes the last one.  Everything is stream-ordered; nothing
-    returns to the host.  results[i & 1] holds global result i after the corresponding finish step."""
+    returns to the host.  results[i & 1] holds global result i after the corresponding finish step.
 
-    def __init__(self, ops, dist, new_tensor):
+    `side_stream` (a torch.cuda.Stream, GPU runs): the all-gather and the group sum are issued there, ordered behind the local MSM by an event,
+    so that the main stream goes straight on with whatever the caller queues next (the bench step's NTT and the next MSM's sort); without it
+    they sit in the main stream between two steps (+5 % per step measured with a world of one)."""
+
+    def __init__(self, ops, dist, new_tensor, side_stream=None):
         self.ops, self.dist = ops, dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.partial = [new_tensor(12), new_tensor(12)]
         self.gathered = new_tensor(12 * self.world)
         self.results = [new_tensor(12), new_tensor(12)]
         self.count = 0
+        self.side = side_stream
+        if side_stream is not None:
+            import torch
+            self._torch = torch
+            self.ev_ready = [torch.cuda.Event(), torch.cuda.Event()]  # main stream: the partial of MSM j is final
+            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # side stream: partial[j & 1] read, results[j & 1] written
+            self.done_valid = [False, False]
 
-    def _finish(self, j, lag):
-        self.ops.join(lag)  # device-side wait for the reduction of MSM j (not for the one issued after it)
+    def _combine(self, j):
         if self.world > 1:
             self.dist.all_gather_into_tensor(self.gathered, self.partial[j & 1])
             self.ops.g1_sum(self.gathered, self.world, self.results[j & 1])
         else:
             self.results[j & 1].copy_(self.partial[j & 1])
 
+    def _finish(self, j, lag):
+        self.ops.join(lag)  # device-side wait for the reduction of MSM j (not for the one issued after it)
+        if self.side is None:
+            self._combine(j)
+            return
+        torch = self._torch
+        self.ev_ready[j & 1].record(torch.cuda.current_stream())
+        self.side.wait_event(self.ev_ready[j & 1])
+        with torch.cuda.stream(self.side):
+            self._combine(j)
+            self.ev_done[j & 1].record(self.side)
+        self.done_valid[j & 1] = True
+
     def submit(self, d_scalars, n):
         i = self.count
+        if self.side is not None and self.done_valid[i & 1]:  # MSM i overwrites partial[i & 1]: the side stream must have read MSM i-2's
+            self._torch.cuda.current_stream().wait_event(self.ev_done[i & 1])
         self.ops.msm(d_scalars, n, self.partial[i & 1])
         if i >= 1:
             self._finish(i - 1, 1)
@@ -94,6 +120,8 @@ class ShardedMsmPipeline:
     def flush(self):
         if self.count >= 1:
             self._finish(self.count - 1, 0)
+            if self.side is not None:
+                self._torch.cuda.current_stream().wait_stream(self.side)
         return self.results[(self.count - 1) & 1] if self.count else None
 
 

@@ -177,7 +177,13 @@ def main():
     # N > 1: one world*n-point MSM per step, sharded by point range; the all-gather + group sum of step i-1 is issued
     # while step i's local MSM is still reducing (parallel.ShardedMsmPipeline); flush() inside the timed region
     # completes the last one, so exactly K global MSMs are finished when the clock stops.
-    pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev)) if dist is not None else None
+    pipe = None
+    if dist is not None:
+        # the all-gather + group sum of step i-1 run on a side stream (a second context bound to it), beside step i
+        side = torch.cuda.Stream()
+        bbg_side = pkg.Bbg(local_rank)
+        bbg_side.set_stream(side.cuda_stream)
+        pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs, bbg_side), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev), side_stream=side)
 
     def step():
         if pipe is not None:
