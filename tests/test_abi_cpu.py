@@ -71,3 +71,21 @@ def test_reference_c_binding_names_exported(pkg):
     names = {l.split()[-1] for l in os.popen(f"nm -D --defined-only {so}").read().splitlines() if " T " in l}
     assert names == {"bbmalloc", "bbfree", "new_pippenger", "delete_pippenger", "pippenger_unsafe", "g1_sum", "coset_fft_with_generator_shift",
                      "ifft", "new_evaluation_domain", "delete_evaluation_domain"}, names
+
+
+def test_limb29_constants_match_the_field():
+    """The constants the 29-bit-limb arithmetic is built on (csrc/curve29.hip.h, field29.hip.h), recomputed with Python integers: 2^261 mod p
+    (the R'-form of one), -p^-1 mod 32 (the digit of the division by 32) and the column bound that lets 18 limb products share a 64-bit
+    accumulator."""
+    import re
+    p = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47  # BN254 Fq (fq.hpp:11-41)
+    src = open(os.path.join(ROOT, "aztec-2.0_amd", "csrc", "curve29.hip.h")).read()
+    words = re.search(r"FQ_R261\[8\] = \{([^}]*)\}", src).group(1)
+    value = sum(int(w.strip().rstrip("u"), 16) << (32 * i) for i, w in enumerate(words.split(",")))
+    assert value == pow(2, 261, p)
+    assert (-pow(p, -1, 32)) % 32 == (32 - pow(p, 7, 32)) % 32 == 9   # f29_div32_to_fe's digit multiplier
+    assert 18 * ((1 << 29) - 1) ** 2 < 1 << 63                          # 9 a*b + 9 m*p products per column never overflow
+    assert 9 * ((1 << 31) + (1 << 29)) * ((1 << 29) + 8) + 2 * 9 * ((1 << 29) + 8) ** 2 < 1 << 64  # f29_mul_sub2's three chains
+    for m_mult, e in ((34, 30), (24, 30), (12, 31), (64, 30)):          # the spread constants of curve29.hip.h: top limb stays positive
+        assert ((m_mult * p) >> 232) > (1 << (e - 29))
+    assert 128 * p < 1 << 261                                            # every lazily reduced value of the mixed addition fits nine limbs
