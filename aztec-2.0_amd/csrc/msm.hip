@@ -267,7 +267,7 @@ int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipSt
 // tests/tools/msm_window_sweep.py: pipelined MSMs, every compiled width, interleaved); msm_window = 0 selects them, a compiled width forces one.
 int msm_auto_window(size_t n)
 {
-    if (n >= ((size_t)1 << 23)) return 22; // 2^23: 10.1 vs 10.4 ms, 2^24: 19.0 vs 19.8 ms (22 vs 20 bits, pipelined); 2^22: 5.42 vs 5.13
+    if (n >= ((size_t)1 << 23)) return 22; // 2^23: 9.8 vs 10.1 ms, 2^24: 18.3 vs 19.1 ms (22 vs 20 bits, pipelined); 2^22: 5.25 vs 4.94
     if (n >= ((size_t)1 << 21)) return 20; // 2^21: 2.72 (20) / 2.73 (19) / 2.79 (17); 2^22: 5.13 (20) / 5.56 (19)
     if (n >= ((size_t)1 << 20)) return 19; // 2^20: MSM + NTT step 1.48 (19) / 1.49 (17) / 1.54 (20) / 1.53 (16): the 29-bit-limb accumulation made
                                            // an entry cheaper, so one more window and half the buckets pay (20 bits won with the 32-bit limbs)
