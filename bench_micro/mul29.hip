@@ -45,6 +45,27 @@ __global__ void __launch_bounds__(256) k_check(const uint32_t* in, int* bad, int
         const Fq w = fe_sub(fe_mul(x, y), fe_mul(y, y));
         if (!fe_eq(fe_canon(f29_to_fe(f29_carry(r2))), fe_canon(w))) fails |= 16;
     }
+    { // the interleaved pairs (what xyzz29_madd calls) against the single products: same limbs, not only the same residues
+        const F29<FqP> X = f29_from_fe<FqP, 5>(x), Y = f29_from_fe<FqP, 0>(y), Z = f29_from_fe<FqP, 0>(x);
+        const F29<FqP> s1 = f29_mul(X, Y), s2 = f29_mul(Y, Z);
+        bool same = true;
+        F29<FqP> q1, q2;
+        f29_mul2(X, Y, Y, Z, q1, q2);
+        for (int i = 0; i < 9; i++) same = same && q1.v[i] == s1.v[i] && q2.v[i] == s2.v[i];
+        if (!same) fails |= 32;
+        F29<FqP> t1, t2;
+        f29_sqr2(Y, Z, t1, t2);
+        const F29<FqP> u1 = f29_sqr(Y), u2 = f29_sqr(Z);
+        same = true;
+        for (int i = 0; i < 9; i++) same = same && t1.v[i] == u1.v[i] && t2.v[i] == u2.v[i];
+        if (!same) fails |= 64;
+        F29<FqP> w1, w2;
+        f29_mul_sub2_mul(X, Y, Z, Y, Y, Z, w1, w2);
+        const F29<FqP> v1 = f29_mul_sub2(X, Y, Z, Y), v2 = f29_mul(Y, Z);
+        same = true;
+        for (int i = 0; i < 9; i++) same = same && w1.v[i] == v1.v[i] && w2.v[i] == v2.v[i];
+        if (!same) fails |= 128;
+    }
     if (fails) atomicOr(bad, fails);
 }
 
