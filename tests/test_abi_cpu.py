@@ -89,3 +89,12 @@ def test_limb29_constants_match_the_field():
     for m_mult, e in ((34, 30), (24, 30), (12, 31), (64, 30)):          # the spread constants of curve29.hip.h: top limb stays positive
         assert ((m_mult * p) >> 232) > (1 << (e - 29))
     assert 128 * p < 1 << 261                                            # every lazily reduced value of the mixed addition fits nine limbs
+
+
+def test_generated_mad_chains_are_in_sync():
+    """csrc/mad_chains29.hip.h is generated (scripts/gen_mad29.py): the committed header must be what the generator renders."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_mad29", os.path.join(ROOT, "scripts", "gen_mad29.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.render() == open(mod.PATH).read()
