@@ -89,7 +89,7 @@ class ShardedMsmPipeline:
             self.done_valid = [False, False]
 
     def _combine(self, j):
-        if self.world > 1:
+        if self.dist is not None:  # also with a world of one (BBG_FORCE_DIST=1): the emulation makes every call the N > 1 path makes
             self.dist.all_gather_into_tensor(self.gathered, self.partial[j & 1])
             self.ops.g1_sum(self.gathered, self.world, self.results[j & 1])
         else:
