@@ -64,65 +64,92 @@ class BbgOps:
 
 
 class ShardedMsmPipeline:
-    """One global MSM per submit(), sharded by point range over the ranks of `dist`, software-pipelined by one call:
-    while rank-local MSM i is still in its bucket-reduction phase (auxiliary stream), the 96-byte partials of MSM i-1
-    are all-gathered (RCCL) and summed.  flush() completes the last one.  Everything is stream-ordered; nothing
-    returns to the host.  results[i & 1] holds global result i after the corresponding finish step.
+    """One global MSM per submit(), sharded by point range over the ranks of `dist`, software-pipelined: while rank-local MSM i is still in its
+    bucket-reduction phase (auxiliary stream), the 96-byte partials of earlier MSMs are all-gathered (RCCL) and summed.  flush() completes what
+    is outstanding.  Everything is stream-ordered; nothing returns to the host.  results[i % (2 * depth)] holds global result i after its
+    finish step; last_result() is the newest.
 
-    `side_stream` (a torch.cuda.Stream, GPU runs): the all-gather and the group sum are issued there, ordered behind the local MSM by an event,
-    so that the main stream goes straight on with whatever the caller queues next (the bench step's NTT and the next MSM's sort); without it
-    they sit in the main stream between two steps (+5 % per step measured with a world of one)."""
+    `depth`: partials are exchanged `depth` MSMs at a time (ONE all-gather of depth x 96 bytes and `depth` group sums): the exchange is a handful of
+    microsecond-sized operations whose fixed cost -- not their bytes -- is what a step pays (0.08 ms of a 1.48 ms step with a world of one).
+    `side_stream` (a torch.cuda.Stream, GPU runs): the exchange is issued there, ordered behind the local MSMs by an event, so that the main
+    stream goes straight on with whatever the caller queues next (the bench step's NTT and the next MSM's sort)."""
 
-    def __init__(self, ops, dist, new_tensor, side_stream=None):
-        self.ops, self.dist = ops, dist
+    def __init__(self, ops, dist, new_tensor, side_stream=None, depth=1):
+        self.ops, self.dist, self.depth = ops, dist, depth
         self.world = dist.get_world_size() if dist is not None else 1
-        self.partial = [new_tensor(12), new_tensor(12)]
-        self.gathered = new_tensor(12 * self.world)
-        self.results = [new_tensor(12), new_tensor(12)]
-        self.count = 0
+        self.ring = 2 * depth
+        self.partial_block = new_tensor(12 * self.ring)
+        self.partial = [self.partial_block[12 * k:12 * k + 12] for k in range(self.ring)]
+        self.gathered = new_tensor(12 * depth * self.world)
+        self.results = [new_tensor(12) for _ in range(self.ring)]
         self.side = side_stream
         if side_stream is not None:
             import torch
             self._torch = torch
-            self.ev_ready = [torch.cuda.Event(), torch.cuda.Event()]  # main stream: the partial of MSM j is final
-            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # side stream: partial[j & 1] read, results[j & 1] written
-            self.done_valid = [False, False]
+            self.ev_ready = [torch.cuda.Event(), torch.cuda.Event()]  # main stream: the partials of this half of the ring are final
+            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # side stream: this half's partials read, its results written
+        self.reset()
 
-    def _combine(self, j):
+    def reset(self):
+        """Forget finished work (call only after flush() and a device synchronisation)."""
+        self.count = 0     # MSMs submitted
+        self.finished = 0  # MSMs whose global result has been issued
+        self.done_valid = [False, False]
+
+    def last_result(self):
+        return self.results[(self.count - 1) % self.ring] if self.count else None
+
+    def _combine(self, j0, cnt):
+        lo = 12 * (j0 % self.ring)
+        block = self.partial_block[lo:lo + 12 * cnt]
         if self.dist is not None:  # also with a world of one (BBG_FORCE_DIST=1): the emulation makes every call the N > 1 path makes
-            self.dist.all_gather_into_tensor(self.gathered, self.partial[j & 1])
-            self.ops.g1_sum(self.gathered, self.world, self.results[j & 1])
+            gathered = self.gathered[:12 * cnt * self.world]
+            self.dist.all_gather_into_tensor(gathered, block)
+            if cnt == 1:
+                self.ops.g1_sum(gathered, self.world, self.results[j0 % self.ring])
+            else:  # [rank][k][12] -> [k][rank][12]: each MSM's partials contiguous for the group sum
+                per_msm = gathered.view(self.world, cnt, 12).transpose(0, 1).contiguous()
+                for k in range(cnt):
+                    self.ops.g1_sum(per_msm[k].reshape(-1), self.world, self.results[(j0 + k) % self.ring])
         else:
-            self.results[j & 1].copy_(self.partial[j & 1])
+            for k in range(cnt):
+                self.results[(j0 + k) % self.ring].copy_(self.partial[(j0 + k) % self.ring])
 
-    def _finish(self, j, lag):
-        self.ops.join(lag)  # device-side wait for the reduction of MSM j (not for the one issued after it)
+    def _finish(self, j0, cnt, lag):
+        """Global results of MSMs j0 .. j0 + cnt - 1 (one half of the ring, or the head of one)."""
+        self.ops.join(lag)  # device-side wait for the reductions of everything but the `lag` most recent MSMs
         if self.side is None:
-            self._combine(j)
+            self._combine(j0, cnt)
             return
-        torch = self._torch
-        self.ev_ready[j & 1].record(torch.cuda.current_stream())
-        self.side.wait_event(self.ev_ready[j & 1])
+        torch, h = self._torch, (j0 // self.depth) & 1
+        self.ev_ready[h].record(torch.cuda.current_stream())
+        self.side.wait_event(self.ev_ready[h])
         with torch.cuda.stream(self.side):
-            self._combine(j)
-            self.ev_done[j & 1].record(self.side)
-        self.done_valid[j & 1] = True
+            self._combine(j0, cnt)
+            self.ev_done[h].record(self.side)
+        self.done_valid[h] = True
 
     def submit(self, d_scalars, n):
         i = self.count
-        if self.side is not None and self.done_valid[i & 1]:  # MSM i overwrites partial[i & 1]: the side stream must have read MSM i-2's
-            self._torch.cuda.current_stream().wait_event(self.ev_done[i & 1])
-        self.ops.msm(d_scalars, n, self.partial[i & 1])
-        if i >= 1:
-            self._finish(i - 1, 1)
+        if self.side is not None and i % self.depth == 0:  # MSM i starts overwriting a half of the ring: the side stream must be done with it
+            h = (i // self.depth) & 1
+            if self.done_valid[h]:
+                self._torch.cuda.current_stream().wait_event(self.ev_done[h])
+        self.ops.msm(d_scalars, n, self.partial[i % self.ring])
         self.count += 1
+        if self.count - self.finished == self.depth + 1:  # a whole batch lies behind the MSM just issued
+            self._finish(self.finished, self.depth, 1)
+            self.finished += self.depth
 
     def flush(self):
-        if self.count >= 1:
-            self._finish(self.count - 1, 0)
-            if self.side is not None:
-                self._torch.cuda.current_stream().wait_stream(self.side)
-        return self.results[(self.count - 1) & 1] if self.count else None
+        lag = 0
+        while self.finished < self.count:
+            cnt = min(self.depth, self.count - self.finished)
+            self._finish(self.finished, cnt, lag)  # the first call waits for every outstanding reduction
+            self.finished += cnt
+        if self.side is not None and self.count:
+            self._torch.cuda.current_stream().wait_stream(self.side)
+        return self.last_result()
 
 
 def msm_sharded_async(bbg, srs_local, d_scalars_ptr, n_local, d_partial, d_gathered, d_result, dist):

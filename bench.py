@@ -179,11 +179,11 @@ def main():
     # completes the last one, so exactly K global MSMs are finished when the clock stops.
     pipe = None
     if dist is not None:
-        # the all-gather + group sum of step i-1 run on a side stream (a second context bound to it), beside step i
+        # the all-gather + group sums of earlier steps run on a side stream (a second context bound to it), four steps' partials at a time
         side = torch.cuda.Stream()
         bbg_side = pkg.Bbg(local_rank)
         bbg_side.set_stream(side.cuda_stream)
-        pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs, bbg_side), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev), side_stream=side)
+        pipe = par.ShardedMsmPipeline(par.BbgOps(bbg, srs, bbg_side), dist, lambda k: torch.zeros(k, dtype=torch.int64, device=dev), side_stream=side, depth=4)
 
     def step():
         if pipe is not None:
@@ -208,7 +208,7 @@ def main():
     blocks = []
     for _ in range(max(1, args.blocks)):
         if pipe is not None:
-            pipe.count = 0
+            pipe.reset()
         bbg.profile_enable(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -281,7 +281,7 @@ def main():
     }
 
     if pipe is not None:
-        d_result = pipe.results[(pipe.count - 1) & 1]
+        d_result = pipe.last_result()
     # ---- CPU baseline + bit-exact check against it (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, value)
@@ -521,7 +521,7 @@ def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
         torch.cuda.synchronize()
 
     def msm_step():
-        pipe.count = 0
+        pipe.reset()
         pipe.submit(d_scalars, count)
         last["msm"] = pipe.flush()
 

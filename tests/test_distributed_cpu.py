@@ -62,6 +62,23 @@ got.append(pipe.flush().numpy().view(np.uint64).copy())
 for b in range(3):
     assert np.array_equal(O.jac_to_affine(got[b]), O.pippenger(batches[b], pts)), ("pipeline", b)
 
+# the same pipeline exchanging two MSMs' partials per all-gather (depth 2), five MSMs: two full batches and a flushed remainder
+pipe2 = par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64), depth=2)
+batches5 = [pkg.synthetic_scalars(200 + b, n) for b in range(5)]
+seen = {}
+for b in range(5):
+    pipe2.submit(torch.from_numpy(batches5[b][start:start + count].view(np.int64).copy()), count)
+    for j in range(pipe2.finished):  # results stay valid until their ring slot is reused (2 * depth MSMs later)
+        if j not in seen and b - j < 4:
+            seen[j] = pipe2.results[j % 4].numpy().view(np.uint64).copy()
+last = pipe2.flush().numpy().view(np.uint64).copy()
+for j in range(pipe2.finished):
+    if j not in seen:
+        seen[j] = pipe2.results[j % 4].numpy().view(np.uint64).copy()
+assert pipe2.finished == 5 and np.array_equal(last, seen[4])
+for b in range(5):
+    assert np.array_equal(O.jac_to_affine(seen[b]), O.pippenger(batches5[b], pts)), ("pipeline depth 2", b)
+
 # NTT sharded by residue class with one all-to-all: device ops emulated with the oracle
 class CpuNttOps:
     def _np(self, t): return t.numpy().view(np.uint64).reshape(-1, 4)
