@@ -71,6 +71,12 @@ def load_library():
         "bbg_srs_retain": (cint, [vp]),
         "bbg_msm": (cint, [vp, vp, vp, sz, sz, vp]),
         "bbg_msm_device": (cint, [vp, vp, vp, sz, sz, vp]),
+        "bbg_msm_batch": (cint, [vp, vp, sz, vp, vp, vp, vp]),
+        "bbg_msm_batch_device": (cint, [vp, vp, sz, vp, vp, vp, vp]),
+        "bbg_msm_plan": (cint, [vp, vp, sz, ctypes.POINTER(cint), ctypes.POINTER(cint)]),
+        "bbg_memory_report": (cint, [vp, vp]),
+        "bbg_memory_trim": (cint, [vp, cint, ctypes.POINTER(sz)]),
+        "bbg_prover_device_bytes": (cint, [vp, ctypes.POINTER(sz)]),
         "bbg_g1_sum": (cint, [vp, vp, sz, vp]),
         "bbg_g1_sum_device": (cint, [vp, vp, sz, vp]),
         "bbg_g1_normalize": (cint, [vp, vp, sz, vp]),
@@ -138,7 +144,8 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
-    "bbg_srs_free", "bbg_srs_retain", "bbg_msm", "bbg_msm_device", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device", "bbg_permutation_grand_product_device", "bbg_poly_evaluate", "bbg_kate_opening",
+    "bbg_srs_free", "bbg_srs_retain", "bbg_msm", "bbg_msm_device", "bbg_msm_batch", "bbg_msm_batch_device", "bbg_msm_plan", "bbg_memory_report",
+    "bbg_memory_trim", "bbg_prover_device_bytes", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device", "bbg_permutation_grand_product_device", "bbg_poly_evaluate", "bbg_kate_opening",
     "bbg_divide_by_pseudo_vanishing",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
     "bbg_divide_by_pseudo_vanishing_device", "bbg_dev_alloc", "bbg_dev_free",
@@ -149,6 +156,13 @@ EXPORTED_SYMBOLS = [
     "bbg_multi_create", "bbg_multi_destroy", "bbg_multi_count", "bbg_multi_ctx", "bbg_multi_sync", "bbg_multi_srs_register",
     "bbg_multi_srs_synth_hashed", "bbg_multi_srs_num_points", "bbg_multi_msm", "bbg_multi_ntt_device", "bbg_multi_ntt", "bbg_multi_set_option",
 ]
+
+
+class MemoryInfo(ctypes.Structure):
+    """bbg_memory_info (include/bbg.h)."""
+    _fields_ = [(k, ctypes.c_size_t) for k in ("srs_points", "srs_tables", "ntt_tables", "msm_arena", "scratch", "prover_keys", "total",
+                                               "device_total", "device_free")] + \
+               [(k, ctypes.c_uint) for k in ("live_srs", "live_provers", "ntt_domains")]
 
 
 def _u64(a, shape_last):
@@ -257,6 +271,41 @@ class Bbg:
 
     def msm_device(self, srs, d_scalars, n, d_out, start=0):
         self._ck(self.lib.bbg_msm_device(self.ctx, srs.handle, ctypes.c_void_p(d_scalars), start, n, ctypes.c_void_p(d_out)))
+
+    def msm_batch(self, srs, scalar_list, starts=None):
+        """bbg_msm_batch: len(scalar_list) MSMs over one SRS through ONE launch set; returns (count, 12) Jacobians."""
+        scs = [_u64(s, 4) for s in scalar_list]
+        cnt = len(scs)
+        ptrs = (ctypes.c_void_p * cnt)(*[ctypes.c_void_p(s.ctypes.data) for s in scs])
+        ns = (ctypes.c_size_t * cnt)(*[s.shape[0] for s in scs])
+        fr = None if starts is None else (ctypes.c_size_t * cnt)(*[int(v) for v in starts])
+        out = np.zeros((cnt, 12), dtype=np.uint64)
+        self._ck(self.lib.bbg_msm_batch(self.ctx, srs.handle, cnt, ptrs, fr, ns, out.ctypes.data))
+        return out
+
+    def msm_batch_device(self, srs, d_scalar_ptrs, ns, d_out, starts=None):
+        cnt = len(d_scalar_ptrs)
+        ptrs = (ctypes.c_void_p * cnt)(*[ctypes.c_void_p(int(p)) for p in d_scalar_ptrs])
+        nn = (ctypes.c_size_t * cnt)(*[int(v) for v in ns])
+        fr = None if starts is None else (ctypes.c_size_t * cnt)(*[int(v) for v in starts])
+        self._ck(self.lib.bbg_msm_batch_device(self.ctx, srs.handle, cnt, ptrs, fr, nn, ctypes.c_void_p(d_out)))
+
+    def msm_plan(self, n, srs=None):
+        """(window bits C, windows) an n-term MSM would run with now (bbg_msm_plan)."""
+        c, w = ctypes.c_int(), ctypes.c_int()
+        self._ck(self.lib.bbg_msm_plan(self.ctx, srs.handle if srs is not None else None, n, ctypes.byref(c), ctypes.byref(w)))
+        return c.value, w.value
+
+    def memory_report(self):
+        """bbg_memory_report as a dict (bytes by purpose, live handle counts, hipMemGetInfo)."""
+        info = MemoryInfo()
+        self._ck(self.lib.bbg_memory_report(self.ctx, ctypes.byref(info)))
+        return {k: int(getattr(info, k)) for k, _ in MemoryInfo._fields_}
+
+    def memory_trim(self, tables=False):
+        rel = ctypes.c_size_t()
+        self._ck(self.lib.bbg_memory_trim(self.ctx, 1 if tables else 0, ctypes.byref(rel)))
+        return int(rel.value)
 
     def g1_sum(self, jacobians):
         j = _u64(jacobians, 12)

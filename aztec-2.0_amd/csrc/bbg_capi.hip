@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <set>
 
 namespace bbg {
 
@@ -34,6 +35,12 @@ int ensure_buffer(void** buf, size_t* have, size_t need)
 }
 int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipStream_t st);
 int msm_pick_window(const bbg_ctx* ctx, size_t n);
+void prover_report(const bbg_ctx* ctx, size_t* bytes, unsigned* count); // prover.hip: live bbg_prover handles of a context
+
+// every live SRS handle of the process (bbg_memory_report totals the ones of a context; a handle may outlive its context, so the
+// registry is not a member of bbg_ctx)
+static std::mutex g_srs_mu;
+static std::set<bbg_srs*> g_live_srs;
 int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
                               void* d_z, hipStream_t st);
 int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
@@ -41,6 +48,8 @@ int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsign
                     uint64_t* alpha_out, hipStream_t st);
 int msm_windows_for(int c);
 int msm_width_slot(int c);
+int msm_width_of_slot(int slot);
+constexpr size_t DPV_CONSTS_BYTES = 4096; // poly.hip: one block of Z*_H division constants per (src, target, roots cut)
 int g1_normalize_device(const void* d_jacs, size_t n, void* d_out, hipStream_t st);
 
 static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs** out)
@@ -68,6 +77,11 @@ static int make_srs(bbg_ctx* ctx, const void* d_plain_points, size_t n, bbg_srs*
         }
         s->s.points = table; // window 0 = the plain points
         s->s.tables[msm_width_slot(c)] = table;
+        s->s.home_slot = msm_width_slot(c);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_srs_mu);
+        g_live_srs.insert(s);
     }
     *out = s;
     return BBG_OK;
@@ -242,6 +256,11 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_accumulate_quad = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "prover_msm_batch")) {
+        if (value < 0 || value > BBG_MSM_BATCH_MAX) { set_error("prover_msm_batch must be 0 .. BBG_MSM_BATCH_MAX"); return BBG_E_INVALID; }
+        ctx->prover_msm_batch = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "quotient_fuse")) {
         ctx->quotient_fuse = value != 0;
         return BBG_OK;
@@ -283,6 +302,79 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
     BBG_HIP(hipDeviceSynchronize());
     for (auto& kv : ctx->domains) ntt_free_domain(kv.second);
     ctx->domains.clear();
+    return BBG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ HBM budget
+int bbg_memory_report(bbg_ctx* ctx, bbg_memory_info* out)
+{
+    CHECK_CTX(ctx);
+    if (!out) { set_error("bbg_memory_report: null out"); return BBG_E_INVALID; }
+    memset(out, 0, sizeof(*out));
+    {
+        std::lock_guard<std::mutex> lk(g_srs_mu);
+        for (const bbg_srs* s : g_live_srs) {
+            if (s->ctx != ctx) continue;
+            out->live_srs++;
+            for (int k = 0; k < Srs::MAX_WIDTHS; k++)
+                if (s->s.tables[k]) out->srs_tables += s->s.n * (size_t)msm_windows_for(msm_width_of_slot(k)) * 64;
+        }
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (const auto& kv : ctx->domains) {
+        out->ntt_tables += kv.second.bytes;
+        out->ntt_domains++;
+    }
+    out->msm_arena = ctx->msm.bytes;
+    out->scratch = ctx->ntt_scratch_bytes + ctx->staging_bytes + ctx->poly_scratch_bytes + ctx->gp_totals_bytes + ctx->quot_setup_bytes +
+                   ctx->dpv_consts.size() * (size_t)DPV_CONSTS_BYTES;
+    prover_report(ctx, &out->prover_keys, &out->live_provers);
+    out->total = out->srs_points + out->srs_tables + out->ntt_tables + out->msm_arena + out->scratch + out->prover_keys;
+    BBG_HIP(hipMemGetInfo(&out->device_free, &out->device_total));
+    return BBG_OK;
+}
+
+int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
+{
+    CHECK_CTX(ctx);
+    bbg_memory_info before, after;
+    int rc = bbg_memory_report(ctx, &before);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        BBG_HIP(hipDeviceSynchronize()); // nothing queued may still read what goes away
+        for (auto& kv : ctx->domains) ntt_free_domain(kv.second);
+        ctx->domains.clear();
+        for (auto& kv : ctx->dpv_consts) (void)hipFree(kv.second);
+        ctx->dpv_consts.clear();
+        auto drop = [](void** buf, size_t* bytes) {
+            if (*buf) (void)hipFree(*buf);
+            *buf = nullptr;
+            *bytes = 0;
+        };
+        drop(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes);
+        drop(&ctx->staging, &ctx->staging_bytes);
+        drop(&ctx->poly_scratch, &ctx->poly_scratch_bytes);
+        drop(&ctx->gp_totals, &ctx->gp_totals_bytes);
+        drop(&ctx->quot_setup, &ctx->quot_setup_bytes);
+        drop(&ctx->msm.buf, &ctx->msm.bytes);
+        ctx->msm_layout_n = 0; // the arena's counters are re-initialised with the next layout
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) ctx->ev_done_valid[k] = false;
+        if (tables) {
+            std::lock_guard<std::mutex> lk2(g_srs_mu);
+            for (bbg_srs* s : g_live_srs) {
+                if (s->ctx != ctx) continue;
+                for (int k = 0; k < Srs::MAX_WIDTHS; k++)
+                    if (s->s.tables[k] && k != s->s.home_slot) { // the registration table holds the plain points: it stays
+                        (void)hipFree(s->s.tables[k]);
+                        s->s.tables[k] = nullptr;
+                    }
+            }
+        }
+    }
+    rc = bbg_memory_report(ctx, &after);
+    if (rc) return rc;
+    if (released) *released = before.total - after.total;
     return BBG_OK;
 }
 
@@ -635,6 +727,10 @@ void bbg_srs_free(bbg_srs* srs)
 {
     if (!srs) return;
     if (srs->refs.fetch_sub(1) > 1) return; // another owner (a bbg_prover, a second cache entry) still uses it
+    {
+        std::lock_guard<std::mutex> lk(g_srs_mu);
+        g_live_srs.erase(srs);
+    }
     (void)hipSetDevice(srs->s.device); // the handle's own record: the context may already be gone (bbg_destroy before bbg_srs_free)
     (void)hipDeviceSynchronize();
     for (void* t : srs->s.tables)
@@ -649,6 +745,60 @@ int bbg_msm_device(bbg_ctx* ctx, bbg_srs* srs, const void* d_scalars, size_t fro
     if (!srs || (!d_scalars && n) || !d_out_jacobian) { set_error("bbg_msm_device: null argument"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     return msm_run(ctx, srs->s, d_scalars, from, n, d_out_jacobian, ctx->stream);
+}
+
+int bbg_msm_batch_device(bbg_ctx* ctx, bbg_srs* srs, size_t count, const void* const* d_scalars, const size_t* from, const size_t* n,
+                         void* d_out_jacobians)
+{
+    CHECK_CTX(ctx);
+    if (!srs || !d_scalars || !n || !d_out_jacobians) { set_error("bbg_msm_batch_device: null argument"); return BBG_E_INVALID; }
+    if (count < 1 || count > BBG_MSM_BATCH_MAX) { set_error("bbg_msm_batch_device: 1 .. BBG_MSM_BATCH_MAX MSMs per batch"); return BBG_E_INVALID; }
+    size_t zero[BBG_MSM_BATCH_MAX] = { 0 };
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return msm_run_batch(ctx, srs->s, (int)count, d_scalars, from ? from : zero, n, d_out_jacobians, ctx->stream);
+}
+
+int bbg_msm_batch(bbg_ctx* ctx, bbg_srs* srs, size_t count, const uint64_t* const* scalars, const size_t* from, const size_t* n, uint64_t* out_jacobians)
+{
+    CHECK_CTX(ctx);
+    if (!srs || !scalars || !n || !out_jacobians) { set_error("bbg_msm_batch: null argument"); return BBG_E_INVALID; }
+    if (count < 1 || count > BBG_MSM_BATCH_MAX) { set_error("bbg_msm_batch: 1 .. BBG_MSM_BATCH_MAX MSMs per batch"); return BBG_E_INVALID; }
+    size_t zero[BBG_MSM_BATCH_MAX] = { 0 }, total = 0;
+    for (size_t k = 0; k < count; k++) {
+        if (n[k] && !scalars[k]) { set_error("bbg_msm_batch: null scalars"); return BBG_E_INVALID; }
+        total += n[k];
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ensure_buffer(&ctx->staging, &ctx->staging_bytes, total * 32 + 1024);
+    if (rc) return rc;
+    char* st = (char*)ctx->staging; // results (count x 96 B <= 768 B) | scalars of MSM 0 | MSM 1 | ...
+    const void* d_ptrs[BBG_MSM_BATCH_MAX];
+    size_t at = 1024;
+    for (size_t k = 0; k < count; k++) {
+        d_ptrs[k] = st + at;
+        if (n[k]) BBG_HIP(hipMemcpyAsync(st + at, scalars[k], n[k] * 32, hipMemcpyHostToDevice, ctx->stream));
+        at += n[k] * 32;
+    }
+    rc = msm_run_batch(ctx, srs->s, (int)count, d_ptrs, from ? from : zero, n, st, ctx->stream);
+    if (rc) return rc;
+    rc = msm_join(ctx, ctx->stream);
+    if (rc) return rc;
+    BBG_HIP(hipMemcpyAsync(out_jacobians, st, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    BBG_HIP(hipStreamSynchronize(ctx->stream));
+    return BBG_OK;
+}
+
+int bbg_msm_plan(bbg_ctx* ctx, const bbg_srs* srs, size_t n, int* window_bits, int* windows)
+{
+    CHECK_CTX(ctx);
+    if (!window_bits || !windows) { set_error("bbg_msm_plan: null out"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int c = 0;
+    int rc = msm_plan(ctx, srs ? &srs->s : nullptr, n, &c);
+    if (rc) return rc;
+    *window_bits = c;
+    *windows = msm_windows_for(c);
+    return BBG_OK;
 }
 
 int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, size_t n, uint64_t out_jacobian[12])

@@ -48,7 +48,8 @@ struct Srs {
     size_t n = 0;          // number of (plain) points
     void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical (= window 0 of a table below)
     static constexpr int MAX_WIDTHS = 5;
-    void* tables[MAX_WIDTHS] = {}; // window tables T[w][i] = 2^(C w) P_i per compiled width C (slot = msm_width_slot(C), msm.hip); built on first use
+    void* tables[MAX_WIDTHS] = {}; // window tables T[w][i] = 2^(MsmCfg<C>::table_offset(w)) P_i (balanced windows, halved weight for the narrow ones: msm_cfg.h) per compiled width C (slot = msm_width_slot(C), msm.hip); built on first use
+    int home_slot = -1;    // the table built at registration: its window 0 IS `points`, so it is never released before the handle
     int device = 0;
 };
 
@@ -98,8 +99,9 @@ struct bbg_ctx {
     int msm_upload_pieces = 1; // option "msm_upload_pieces": 1 = one copy in front of the MSM (default: measured FASTER, profiles/r02_host_msm_ab.txt)
     bool ev_done_valid[MSM_SLOTS] = {};
     unsigned long msm_seq = 0;
-    size_t msm_layout_n = 0; // (n, window width) of the layout the scratch arena currently holds: a change of either moves
-    int msm_layout_c = 0;    // every region, so pending reduce phases are joined first (msm_run_c)
+    size_t msm_layout_n = 0; // (scalars of the batch, MSMs in it, window width) of the layout the scratch arena currently holds: a change of any
+    int msm_layout_sets = 0; // moves every region, so pending reduce phases are joined first (msm_run_c)
+    int msm_layout_c = 0;
     int msm_layout_sort = 1; // (the sort path is part of the layout: the library-sort path reserves rocPRIM's temporary storage)
     bool msm_async_reduce = false;
     int msm_reduce_quad = 14;   // reduce stages with four lanes per EC operation (curve_quad.hip.h): bit 0 combine (a THROUGHPUT kernel over all buckets: one lane per operation is cheaper, measured), 1 row/col, 2 planes, 3 sum
@@ -112,6 +114,7 @@ struct bbg_ctx {
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    int prover_msm_batch = 4; // option "prover_msm_batch": commitments of a prover round per launch set (0 / 1 = one each; prover.hip commit())
     bool quotient_fuse = true; // option "quotient_fuse": arithmetic + range + logic widgets of a chain in one pass over the wires (0 = one kernel each, A/B)
     int msm_window = 0; // 0 = automatic (msm_auto_window), or one of the compiled widths (BBG_MSM_WIDTHS)
     int msm_sort = 1; // 1 = fused recode + MSD partition sort (msm.hip), 0 = k_recode + rocPRIM radix sort + k_offsets
@@ -175,6 +178,11 @@ int field_op_device(int which, int op, const void* a, const void* b, void* out, 
 // itself, piece by piece, overlapped with its first pass
 int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac,
             hipStream_t stream, const void* h_scalars = nullptr);
+// `sets` MSMs over one SRS through ONE launch set (msm_cfg.h); result k at d_out_jac + 96 k
+int msm_run_batch(bbg_ctx* ctx, Srs& srs, int sets, const void* const* d_scalars, const size_t* from, const size_t* n, void* d_out_jac, hipStream_t stream,
+                  const void* h_scalars = nullptr);
+// widest window an n-term MSM over srs (may be null) would use now (no table is built)
+int msm_plan(bbg_ctx* ctx, const Srs* srs, size_t n, int* c_out);
 int srs_synth_linear(bbg_ctx* ctx, uint64_t a, uint64_t s, size_t n, void* d_points, hipStream_t stream);
 int msm_join(bbg_ctx* ctx, hipStream_t stream);
 int srs_synth_hashed(bbg_ctx* ctx, uint64_t seed, size_t n, void* d_points, hipStream_t stream);

@@ -28,6 +28,7 @@
 #include "curve.hip.h"
 #include "curve_quad.hip.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace bbg {
@@ -151,6 +152,8 @@ static __device__ __forceinline__ Xyzz block_reduce_q4(Xyzz v, Xyzz* sm, int nlo
 __global__ void __launch_bounds__(64, 1) k_final_sum(const Xyzz* __restrict__ planes, int nplanes, Jacobian* out)
 {
     __shared__ Xyzz sm[16];
+    planes += (size_t)blockIdx.x * MSM_MAX_PLANES; // one block per MSM of the batch
+    out += blockIdx.x;
     Xyzz v = (int)threadIdx.x < nplanes ? xyzz_load(planes + threadIdx.x) : xyzz_inf();
     v = block_reduce(v, sm, MSM_MAX_PLANES);
     if (threadIdx.x == 0) {
@@ -164,6 +167,8 @@ __global__ void __launch_bounds__(4 * MSM_MAX_PLANES) k_final_sum_q(const Xyzz* 
 {
     __shared__ Xyzz sm[MSM_MAX_PLANES / 2];
     const int lt = threadIdx.x >> 2;
+    planes += (size_t)blockIdx.x * MSM_MAX_PLANES; // one block per MSM of the batch
+    out += blockIdx.x;
     Xyzz v = lt < nplanes ? xyzz_load(planes + lt) : xyzz_inf();
     int width = 1;
     while (width < nplanes) width <<= 1; // 15 planes -> 4 levels, not 5
@@ -175,10 +180,10 @@ __global__ void __launch_bounds__(4 * MSM_MAX_PLANES) k_final_sum_q(const Xyzz* 
         fe_store<FqP>(&out->z, j.z);
     }
 }
-int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st)
+int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st, int sets)
 {
-    if (quad) hipLaunchKernelGGL(k_final_sum_q, dim3(1), dim3(4 * MSM_MAX_PLANES), 0, st, (const Xyzz*)d_planes, nplanes, (Jacobian*)d_out_jac);
-    else hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(64), 0, st, (const Xyzz*)d_planes, nplanes, (Jacobian*)d_out_jac);
+    if (quad) hipLaunchKernelGGL(k_final_sum_q, dim3(sets), dim3(4 * MSM_MAX_PLANES), 0, st, (const Xyzz*)d_planes, nplanes, (Jacobian*)d_out_jac);
+    else hipLaunchKernelGGL(k_final_sum, dim3(sets), dim3(64), 0, st, (const Xyzz*)d_planes, nplanes, (Jacobian*)d_out_jac);
     BBG_HIP(hipGetLastError());
     return BBG_OK;
 }
@@ -241,6 +246,7 @@ int msm_width_slot(int c)
         if (MSM_WIDTHS[k] == c) return k;
     return -1;
 }
+int msm_width_of_slot(int slot) { return slot >= 0 && slot < MSM_NUM_WIDTHS ? MSM_WIDTHS[slot] : 0; }
 int msm_windows_for(int c)
 {
     switch (c) {
@@ -297,25 +303,11 @@ int srs_synth_hashed(bbg_ctx*, uint64_t seed, size_t n, void* d_points, hipStrea
     return BBG_OK;
 }
 
-int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st, const void* h_scalars)
+// window width and table for MSMs of at most max_n terms over `srs`; build = false only answers (bbg_msm_plan)
+static int msm_choose(bbg_ctx* ctx, Srs& srs, size_t max_n, bool build, hipStream_t st, int* c_out)
 {
-    if (from > srs.n || n > srs.n - from) {
-        set_error("bbg_msm: range [from, from+n) exceeds the registered SRS");
-        return BBG_E_INVALID;
-    }
-    if (srs.n > ((size_t)1 << MSM_IDX_BITS)) {
-        set_error("bbg_msm: SRS larger than 2^26 points per device is not supported (shard it across devices)");
-        return BBG_E_INVALID;
-    }
-    if (n == 0) {
-        // pippenger(): n == 0 -> point at infinity (scalar_multiplication.cpp:868-872)
-        uint64_t inf[12] = { 0, 0, 0, 1ULL << 63, 0, 0, 0, 0, 0, 0, 0, 0 };
-        BBG_HIP(hipMemcpyAsync(d_out_jac, inf, 96, hipMemcpyHostToDevice, st));
-        BBG_HIP(hipStreamSynchronize(st));
-        return BBG_OK;
-    }
-    int c = msm_pick_window(ctx, n);
-    if (!ctx->msm_window && !srs.tables[msm_width_slot(c)] && n * 4 <= srs.n) {
+    int c = msm_pick_window(ctx, max_n);
+    if (!ctx->msm_window && !srs.tables[msm_width_slot(c)] && max_n * 4 <= srs.n) {
         // a short MSM over a long SRS (automatic width only): the width chosen for n has no table yet and building one costs
         // windows x srs.n x 64 bytes for a call that touches a fraction of it -- use the resident table whose width is nearest instead
         int best = -1;
@@ -323,6 +315,8 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
             if (srs.tables[k] && (best < 0 || abs(MSM_WIDTHS[k] - c) < abs(MSM_WIDTHS[best] - c))) best = k;
         if (best >= 0) c = MSM_WIDTHS[best];
     }
+    *c_out = c;
+    if (!build) return BBG_OK;
     void*& table = srs.tables[msm_width_slot(c)];
     if (!table) { // first MSM of this width on this SRS: build its window tables from the plain points (one-off)
         hipError_t e = hipMalloc(&table, srs.n * (size_t)msm_windows_for(c) * sizeof(Affine));
@@ -337,13 +331,64 @@ int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n
             return rc;
         }
     }
+    return BBG_OK;
+}
+int msm_plan(bbg_ctx* ctx, const Srs* srs, size_t n, int* c_out)
+{
+    if (!srs) {
+        *c_out = msm_pick_window(ctx, n);
+        return BBG_OK;
+    }
+    return msm_choose(ctx, const_cast<Srs&>(*srs), n, false, nullptr, c_out);
+}
+
+int msm_run_batch(bbg_ctx* ctx, Srs& srs, int sets, const void* const* d_scalars, const size_t* from, const size_t* n, void* d_out_jac, hipStream_t st,
+                  const void* h_scalars)
+{
+    if (sets < 1 || sets > BBG_MSM_BATCH_MAX) {
+        set_error("bbg_msm_batch: 1 .. BBG_MSM_BATCH_MAX MSMs per batch");
+        return BBG_E_INVALID;
+    }
+    if (srs.n > ((size_t)1 << MSM_IDX_BITS)) {
+        set_error("bbg_msm: SRS larger than 2^26 points per device is not supported (shard it across devices)");
+        return BBG_E_INVALID;
+    }
+    size_t max_n = 0;
+    for (int k = 0; k < sets; k++) {
+        if (from[k] > srs.n || n[k] > srs.n - from[k]) {
+            set_error("bbg_msm: range [from, from+n) exceeds the registered SRS");
+            return BBG_E_INVALID;
+        }
+        if (n[k] && !d_scalars[k]) {
+            set_error("bbg_msm: null scalars");
+            return BBG_E_INVALID;
+        }
+        max_n = std::max(max_n, n[k]);
+    }
+    if (max_n == 0) {
+        // pippenger(): n == 0 -> point at infinity (scalar_multiplication.cpp:868-872)
+        uint64_t inf[12 * BBG_MSM_BATCH_MAX] = { 0 };
+        for (int k = 0; k < sets; k++) inf[12 * k + 3] = 1ULL << 63;
+        BBG_HIP(hipMemcpyAsync(d_out_jac, inf, (size_t)96 * sets, hipMemcpyHostToDevice, st));
+        BBG_HIP(hipStreamSynchronize(st));
+        return BBG_OK;
+    }
+    int c = 0;
+    int rc = msm_choose(ctx, srs, max_n, true, st, &c);
+    if (rc) return rc;
+    const void* table = srs.tables[msm_width_slot(c)];
     switch (c) {
-#define X(c) case c: return msm_run_c<c>(ctx, srs, table, d_scalars, from, n, d_out_jac, st, h_scalars);
+#define X(c) case c: return msm_run_c<c>(ctx, srs, table, sets, d_scalars, from, n, d_out_jac, st, h_scalars);
         BBG_MSM_WIDTHS(X)
 #undef X
     }
     set_error("bbg_msm: window width not compiled");
     return BBG_E_INVALID;
+}
+
+int msm_run(bbg_ctx* ctx, Srs& srs, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st, const void* h_scalars)
+{
+    return msm_run_batch(ctx, srs, 1, &d_scalars, &from, &n, d_out_jac, st, h_scalars);
 }
 
 // makes the context stream wait for every reduce phase queued on the auxiliary stream (no host sync)

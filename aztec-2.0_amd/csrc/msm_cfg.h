@@ -42,13 +42,14 @@ constexpr int MSM_MAX_PLANES = 32;
 // every width with a translation unit msm_wNN.hip (X-macro: dispatch tables in msm.hip, option parsing, table slots in Srs)
 #define BBG_MSM_WIDTHS(X) X(16) X(17) X(19) X(20) X(22)
 
-// one n-term MSM with C-bit windows over `table` (window tables of this width); defined in msm_kernels.hip.h, instantiated in msm_wNN.hip
+// a batch of `sets` MSMs (1 .. BBG_MSM_BATCH_MAX; MSM k: n[k] terms from point from[k], result at d_out_jac + 96 k) with C-bit windows over
+// `table` (window tables of this width) through one launch set; defined in msm_kernels.hip.h, instantiated in msm_wNN.hip
 template <int C>
-int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st,
-              const void* h_scalars);
+int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table, int sets, const void* const* d_scalars, const size_t* from, const size_t* n,
+              void* d_out_jac, hipStream_t st, const void* h_scalars);
 // table[w * n + i] = 2^(MsmCfg<C>::table_offset(w)) P_i
 template <int C> int srs_build_tables_c(const void* d_points, size_t n, void* d_table, hipStream_t st);
 // the last reduce stage (sum of the bit planes -> Jacobian), shared by all widths (msm.hip)
-int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st);
+int msm_launch_final_sum(bool quad, const void* d_planes, int nplanes, void* d_out_jac, hipStream_t st, int sets);
 
 } // namespace bbg

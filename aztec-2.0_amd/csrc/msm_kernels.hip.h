@@ -118,6 +118,18 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, 
 constexpr int SORT_PAD = 2048;   // partition table size (power of two >= MsmCfg::parts = 1025)
 constexpr int SORT_BLOCK = 1024; // scalars per block in the A kernels
 
+// A BATCH of MSMs over one SRS that travels through ONE launch set (bbg_msm_batch*, the reference's unit of work is a round's queue of
+// commitments: prover.cpp:66-74, :120-135, work_queue.hpp:208-282).  MSM k's entries are filed under bucket set k: global bucket number
+// k * 2^(C-1) + |digit|, partition tables / rows / columns / planes per set.  blockIdx.y selects the set in the kernels that work per MSM
+// (the sort's first level, row / column sums, bit planes); the accumulation and the combine kernels see one long bucket array.  A single
+// MSM is a batch of one: the same kernels, the same code path.
+constexpr int MSM_BATCH_MAX = BBG_MSM_BATCH_MAX;
+struct MsmBatch {
+    const Fr* scalars[MSM_BATCH_MAX];
+    uint32_t n[MSM_BATCH_MAX];
+    uint32_t from[MSM_BATCH_MAX];
+};
+
 // LDS counter bump that stays fast when a whole wave hits one counter (all-equal scalars): one atomic per wave then.
 // Inactive lanes are masked off (no traffic); returns the lane's rank within the counter.
 __device__ __forceinline__ uint32_t lds_take(uint32_t* ctr, uint32_t key, bool active)
@@ -166,11 +178,16 @@ constexpr int COUNT_THREADS = 256;
 constexpr int COUNT_MAX_BLOCKS = 2048; // 8 blocks per CU
 // STRIDE = false (n <= 2^21: one group per block) keeps the kernel at 56 VGPRs -- a wave of it then fits beside the three 152-VGPR waves per SIMD of
 // the previous MSM's row / column sums (3 x 152 + 56 = 512); the loop costs four more registers, which is 0.1 ms of waiting per bench step.
-template <int C, bool STRIDE> __global__ void __launch_bounds__(COUNT_THREADS) k_sortA_count(const Fr* __restrict__ scalars, size_t n, uint32_t* part_count)
+template <int C, bool STRIDE> __global__ void __launch_bounds__(COUNT_THREADS) k_sortA_count(const MsmBatch batch, uint32_t* part_count)
 {
     constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
     __shared__ uint32_t hist[SORT_PAD];
     const int tid = threadIdx.x;
+    const int set = blockIdx.y;
+    const Fr* __restrict__ scalars = batch.scalars[set];
+    const size_t n = batch.n[set];
+    if (!STRIDE && (size_t)blockIdx.x * SORT_BLOCK >= n) return; // a shorter MSM of the batch: whole blocks leave before any barrier
+    part_count += set * SORT_PAD;
     for (int h = tid; h < SORT_PAD; h += COUNT_THREADS) hist[h] = 0;
     __syncthreads();
     // grid-stride over groups of SORT_BLOCK scalars: a large MSM is counted by COUNT_MAX_BLOCKS blocks, each flushing its histogram ONCE
@@ -201,32 +218,45 @@ template <int C, bool STRIDE> __global__ void __launch_bounds__(COUNT_THREADS) k
 // The counters are cleared again once they have been read (and the call's long-bucket counter with them), so that no MSM needs a memset of
 // its own in front of the counting pass: the runtime's fill kernel cost 20-34 us of the main stream's critical path per MSM (r03 timeline).
 template <int C>
-__global__ void __launch_bounds__(1024) k_sortA_scan(uint32_t* part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets, uint32_t* long_count)
+__global__ void __launch_bounds__(1024) k_sortA_scan(uint32_t* part_count, uint32_t* part_base, uint32_t* cursor, uint32_t* offsets, uint32_t* long_count, int sets)
 {
     constexpr int SORT_PARTS = MsmCfg<C>::parts, MSM_BUCKETS = MsmCfg<C>::buckets;
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
     const int tid = threadIdx.x;
-    uint32_t excl, c0, c1;
-    block_scan_pairs(part_count, wsum, excl, c0, c1); // part_count[SORT_PARTS ..) is zero
     const int h0 = 2 * tid, h1 = 2 * tid + 1;
-    part_count[h0] = 0;
-    part_count[h1] = 0;
     if (tid == 0) long_count[0] = long_count[1] = 0; // the long-bucket queue and the redo queue (its count is the word behind) start empty
-    if (h0 <= SORT_PARTS) part_base[h0] = excl; // part_base[SORT_PARTS] = total
-    if (h1 <= SORT_PARTS) part_base[h1] = excl + c0;
-    if (h0 < SORT_PARTS) cursor[h0] = excl;
-    if (h1 < SORT_PARTS) cursor[h1] = excl + c0;
-    if (h0 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl;
-    if (h1 == SORT_PARTS) offsets[MSM_BUCKETS + 1] = excl + c0;
+    uint32_t carry = 0; // entries of the sets before this one: set k's partitions follow set k-1's in the entry array
+    for (int k = 0; k < sets; k++) {
+        uint32_t excl, c0, c1;
+        block_scan_pairs(part_count + k * SORT_PAD, wsum, excl, c0, c1); // part_count[SORT_PARTS ..) is zero
+        excl += carry;
+        part_count[k * SORT_PAD + h0] = 0;
+        part_count[k * SORT_PAD + h1] = 0;
+        if (h0 <= SORT_PARTS) part_base[k * SORT_PAD + h0] = excl; // part_base[SORT_PARTS] = entries up to and including this set
+        if (h1 <= SORT_PARTS) part_base[k * SORT_PAD + h1] = excl + c0;
+        if (h0 < SORT_PARTS) cursor[k * SORT_PAD + h0] = excl;
+        if (h1 < SORT_PARTS) cursor[k * SORT_PAD + h1] = excl + c0;
+        if (h0 == SORT_PARTS) carry_s = excl;
+        if (h1 == SORT_PARTS) carry_s = excl + c0;
+        __syncthreads(); // also: wsum is free again
+        carry = carry_s;
+    }
+    if (tid == 0) offsets[(size_t)sets * MSM_BUCKETS + 1] = carry;
 }
 // The block's <= 16 Ki entries are first grouped by partition in LDS (values + bucket ids, 128 KiB) and then written
 // out with consecutive threads on consecutive addresses: every (block, partition) chunk is one contiguous burst instead
 // of independent 8-byte stores issued at random times.
 template <int C> __global__ void __launch_bounds__(SORT_BLOCK)
-k_sortA_scatter(const Fr* __restrict__ scalars, size_t n, size_t from, uint32_t* cursor, uint64_t* entries)
+k_sortA_scatter(const MsmBatch batch, uint32_t* cursor, uint64_t* entries)
 {
     constexpr int MSM_WINDOWS = MsmCfg<C>::windows, SORT_LO_BITS = MsmCfg<C>::lo_bits, SORT_PARTS = MsmCfg<C>::parts;
     constexpr int CAP = SORT_BLOCK * MSM_WINDOWS;
+    const int set = blockIdx.y;
+    const Fr* __restrict__ scalars = batch.scalars[set];
+    const size_t n = batch.n[set], from = batch.from[set];
+    if ((size_t)blockIdx.x * SORT_BLOCK >= n) return; // a shorter MSM of the batch
+    cursor += set * SORT_PAD;
     __shared__ uint32_t hist[SORT_PAD];   // per-partition count, then rank counter
     __shared__ uint32_t lstart[SORT_PAD]; // first LDS slot of each partition
     __shared__ uint32_t gbase[SORT_PAD];  // this block's first global slot in each partition, minus lstart
@@ -335,8 +365,8 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t stage[CAP];
     const int tid = threadIdx.x;
-    const uint32_t h = blockIdx.x;
-    const uint32_t pb = part_base[h], pe = part_base[h + 1];
+    const uint32_t h = blockIdx.x, set = blockIdx.y;
+    const uint32_t pb = part_base[set * SORT_PAD + h], pe = part_base[set * SORT_PAD + h + 1];
     const uint32_t len = pe - pb;
     const bool fast = len <= (uint32_t)CAP;
     for (int b = tid; b < BINS; b += TPB) hist[b] = 0;
@@ -371,7 +401,9 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     __syncthreads();
     for (int b = tid; b < BINS; b += TPB) {
         const uint32_t bucket = (h << SORT_LO_BITS) + (uint32_t)b;
-        if (bucket <= (uint32_t)MSM_BUCKETS) offsets[bucket] = pb + off[b];
+        // global bucket number = set * 2^(C-1) + bucket; a later set's bucket 0 (zero digits: never sorted, always empty) would be the
+        // previous set's LAST bucket, whose offset that set's own top partition writes
+        if (bucket <= (uint32_t)MSM_BUCKETS && (bucket != 0 || set == 0)) offsets[(size_t)set * MSM_BUCKETS + bucket] = pb + off[b];
     }
     __syncthreads();
     if (fast) {
@@ -475,9 +507,9 @@ __device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ ta
 
 template <int C> __global__ void __launch_bounds__(256)
 k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-             size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets)
+             size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     const uint32_t total = offsets[MSM_BUCKETS + 1]; // the partition sort drops zero digits: the count lives on the device
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = offsets[1]; // entries with key 0 (zero digits) sort first and are skipped
@@ -526,9 +558,9 @@ k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off
 // quad-cooperative addition costs ~1.5x the instructions of a one-lane one.
 template <int C> __global__ void __launch_bounds__(256)
 k_accumulate_q4(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-                size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets)
+                size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t lane = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int qd = threadIdx.x & 3;
@@ -591,9 +623,9 @@ __device__ __forceinline__ void redo_push(const RedoQueue& rq, uint32_t b)
 
 template <int C> __global__ void __launch_bounds__(256)
 k_accumulate29(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
-               size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets, RedoQueue redo)
+               size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets, RedoQueue redo, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     __shared__ __attribute__((aligned(16))) uint32_t div32[32 * DIV32_ROW]; // multiples of p for the R'-form -> R-form step at the end of a run
     if (threadIdx.x < 32) f29_fill_div32_table<FqP>(div32, threadIdx.x);
     __syncthreads();
@@ -694,9 +726,9 @@ __device__ __forceinline__ Xyzz bucket_piece(const Xyzz* __restrict__ head, cons
 // Buckets spanning more than MSM_LONG_SPAN lanes (skewed scalar distributions) are queued for k_combine_long.
 template <int C> __global__ void __launch_bounds__(256, 1)
 k_combine(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-          Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+          Xyzz* buckets, uint32_t* long_count, uint32_t* long_list, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     __shared__ uint32_t work[256]; // buckets of this block whose pieces have to be ADDED
     __shared__ uint32_t nwork;
     const uint32_t total = offsets[MSM_BUCKETS + 1];
@@ -707,7 +739,9 @@ k_combine(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __rest
     // entries of odd ones and span more lane segments; a wave that mixes both runs the long loop for everybody (2^24, C = 22: 0.83 vs 0.61 ms).
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < MSM_BUCKETS) {
-        const uint32_t b = t < MSM_BUCKETS / 2 ? 2 * (t + 1) : 2 * (t - MSM_BUCKETS / 2) + 1;
+        constexpr uint32_t PER_SET = MsmCfg<C>::buckets;
+        const uint32_t set = t / PER_SET, r = t % PER_SET;
+        const uint32_t b = set * PER_SET + (r < PER_SET / 2 ? 2 * (r + 1) : 2 * (r - PER_SET / 2) + 1);
         const uint32_t sb = offsets[b], eb = offsets[b + 1];
         if (sb == eb) {
             xyzz_store(buckets + (b - 1), xyzz_inf());
@@ -763,9 +797,9 @@ __device__ __forceinline__ Xyzz xyzz_shfl_xor(const Xyzz& v, int mask)
 constexpr int MSM_COMBINE_LANES = 4;
 template <int C> __global__ void __launch_bounds__(256, 1)
 k_combine_lanes(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+           Xyzz* buckets, uint32_t* long_count, uint32_t* long_list, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / MSM_COMBINE_LANES + 1;
@@ -848,6 +882,9 @@ template <int C> __global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* 
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[128];
     const int tid = threadIdx.x;
+    buckets += (size_t)blockIdx.y * MsmCfg<C>::buckets; // bucket set of MSM blockIdx.y of the batch
+    rows += (size_t)blockIdx.y * ROWS;
+    cols += (size_t)blockIdx.y * COLS;
     if (blockIdx.x < ROWS) {
         const int hi = blockIdx.x;
         Xyzz v = xyzz_load(buckets + (size_t)hi * COLS + tid);
@@ -873,6 +910,9 @@ template <int C> __global__ void __launch_bounds__(256, 1) k_final_planes(const 
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols, LOGC = MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[128];
     const int t = blockIdx.x, tid = threadIdx.x;
+    rows += (size_t)blockIdx.y * ROWS;
+    cols += (size_t)blockIdx.y * COLS;
+    planes += (size_t)blockIdx.y * MSM_MAX_PLANES;
     Xyzz v = xyzz_inf();
     if (t <= LOGC)
         for (int lo = tid; lo < COLS; lo += 256)
@@ -906,9 +946,9 @@ constexpr int Q_LOGICAL = 128, Q_THREADS = 4 * Q_LOGICAL;
 
 template <int C> __global__ void __launch_bounds__(Q_THREADS)
 k_combine_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+            Xyzz* buckets, uint32_t* long_count, uint32_t* long_list, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t gl = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int q = threadIdx.x & 3;
@@ -944,9 +984,9 @@ k_combine_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __re
 // MSM_COMBINE_LANES logical lanes (16 threads) per bucket, butterfly across the logical lanes (shuffle distances 8 and 4)
 template <int C> __global__ void __launch_bounds__(Q_THREADS)
 k_combine_lanes_q(const uint32_t* __restrict__ offsets, uint32_t seg, const Xyzz* __restrict__ head, const Xyzz* __restrict__ tail,
-                  Xyzz* buckets, uint32_t* long_count, uint32_t* long_list)
+                  Xyzz* buckets, uint32_t* long_count, uint32_t* long_list, uint32_t nb)
 {
-    constexpr uint32_t MSM_BUCKETS = MsmCfg<C>::buckets;
+    const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t gl = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int q = threadIdx.x & 3;
@@ -1018,6 +1058,9 @@ template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(co
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[QL / 2];
     const int q = threadIdx.x & 3;
+    buckets += (size_t)blockIdx.y * MsmCfg<C>::buckets; // bucket set of MSM blockIdx.y of the batch
+    rows += (size_t)blockIdx.y * ROWS;
+    cols += (size_t)blockIdx.y * COLS;
     // serial phase: every THREAD sums its own share with one-lane additions (a quad-cooperative addition costs 1.55x the instructions of a
     // one-lane one -- it buys latency, and there is none to buy while all four lanes have items of their own); then the four partial sums of
     // a quad are added with four-lane operations, then the tree over the QL quads
@@ -1040,6 +1083,9 @@ template <int C> __global__ void __launch_bounds__(Q_THREADS) k_final_planes_q(c
     constexpr int ROWS = 1 << MsmCfg<C>::log_rows, COLS = 1 << MsmCfg<C>::log_cols, LOGC = MsmCfg<C>::log_cols;
     __shared__ Xyzz sm[Q_LOGICAL / 2];
     const int t = blockIdx.x, lt = threadIdx.x >> 2, q = threadIdx.x & 3;
+    rows += (size_t)blockIdx.y * ROWS;
+    cols += (size_t)blockIdx.y * COLS;
+    planes += (size_t)blockIdx.y * MSM_MAX_PLANES;
     Xyzz v = xyzz_inf();
     if (t <= LOGC)
         for (int lo = lt; lo < COLS; lo += Q_LOGICAL)
@@ -1093,11 +1139,13 @@ static uint32_t msm_seg_len(size_t entries, size_t buckets, int waves_override)
     return (uint32_t)seg;
 }
 
-template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L, int acc_waves = 0)
+// total_n = scalars of all `sets` MSMs of the batch together
+template <int C> static int msm_layout(size_t total_n, int sets, bool library_sort, MsmLayout& L, int acc_waves = 0)
 {
     using K = MsmCfg<C>;
-    L.entries = n * K::windows;
-    L.seg = msm_seg_len(L.entries, K::buckets, acc_waves);
+    const size_t nbuckets = (size_t)sets * K::buckets;
+    L.entries = total_n * K::windows;
+    L.seg = msm_seg_len(L.entries, nbuckets, acc_waves);
     L.lanes = (L.entries + L.seg - 1) / L.seg;
     size_t tmp = 0;
 #ifdef BBG_ROCPRIM_SORT
@@ -1119,16 +1167,16 @@ template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L
     for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) L.off_vals0[k] = take(L.entries * 4);
     L.off_vals1 = take(library_sort ? L.entries * 4 : 0); // second value buffer of the library sort's double buffer (A/B build only)
     L.off_sort = take(L.sort_bytes);
-    L.off_parts = take(3 * SORT_PAD * 4);
+    L.off_parts = take((size_t)3 * sets * SORT_PAD * 4); // per set: partition counts | bases | cursors
     for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
-        L.off_offsets[k] = take(((size_t)K::buckets + 2) * 4);
+        L.off_offsets[k] = take((nbuckets + 2) * 4);
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
         L.off_tail[k] = take(L.lanes * sizeof(Xyzz));
-        L.off_buckets[k] = take((size_t)K::buckets * sizeof(Xyzz));
-        L.off_rows[k] = take(((size_t)(1 << K::log_rows) + MSM_MAX_PLANES) * sizeof(Xyzz)); // row sums + bit planes
-        L.off_cols[k] = take((size_t)(1 << K::log_cols) * sizeof(Xyzz));
-        L.off_long[k] = take(((size_t)K::buckets + 2) * 4);
-        L.off_redo[k] = take(((size_t)2 * K::buckets) * 4); // RedoQueue: list, flags (the count lives beside the long-bucket count)
+        L.off_buckets[k] = take(nbuckets * sizeof(Xyzz));
+        L.off_rows[k] = take((size_t)sets * ((size_t)(1 << K::log_rows) + MSM_MAX_PLANES) * sizeof(Xyzz)); // row sums of every set, then their bit planes
+        L.off_cols[k] = take((size_t)sets * (size_t)(1 << K::log_cols) * sizeof(Xyzz));
+        L.off_long[k] = take((nbuckets + 2) * 4);
+        L.off_redo[k] = take((2 * nbuckets) * 4); // RedoQueue: list, flags (the count lives beside the long-bucket count)
     }
     L.total = o;
     return BBG_OK;
@@ -1137,13 +1185,30 @@ template <int C> static int msm_layout(size_t n, bool library_sort, MsmLayout& L
 static inline char* base_of(bbg_ctx* ctx) { return (char*)ctx->msm.buf; }
 
 template <int C>
-int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_scalars, size_t from, size_t n, void* d_out_jac, hipStream_t st,
-              const void* h_scalars)
+int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const void* const* d_scalars_v, const size_t* from_v, const size_t* n_v,
+              void* d_out_jac, hipStream_t st, const void* h_scalars)
 {
     const Affine* table = (const Affine*)table_v;
     using K = MsmCfg<C>;
+    MsmBatch batch;
+    size_t total_n = 0, max_n = 0;
+    for (int k = 0; k < MSM_BATCH_MAX; k++) {
+        batch.scalars[k] = k < sets ? (const Fr*)d_scalars_v[k] : nullptr;
+        batch.n[k] = k < sets ? (uint32_t)n_v[k] : 0u;
+        batch.from[k] = k < sets ? (uint32_t)from_v[k] : 0u;
+        if (k < sets) {
+            total_n += n_v[k];
+            max_n = std::max(max_n, n_v[k]);
+        }
+    }
+    if (total_n * K::windows >= ((size_t)1 << 32)) {
+        set_error("bbg_msm: more than 2^32 sorted entries in one launch set (split the batch)");
+        return BBG_E_INVALID;
+    }
+    const size_t n = max_n; // grid extent of the per-scalar kernels (blockIdx.y = MSM of the batch; shorter ones leave early)
+    const uint32_t nbuckets = (uint32_t)sets * K::buckets;
     MsmLayout L;
-    int rc = msm_layout<C>(n, ctx->msm_sort == 0, L, ctx->msm_acc_waves);
+    int rc = msm_layout<C>(total_n, sets, ctx->msm_sort == 0, L, ctx->msm_acc_waves);
     if (rc) return rc;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
@@ -1159,18 +1224,19 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
         }
         ctx->aux_stream = ctx->aux_streams[0];
     }
-    if (ctx->msm_layout_n != n || ctx->msm_layout_c != C || ctx->msm_layout_sort != ctx->msm_sort) {
-        // a different (n, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
+    if (ctx->msm_layout_n != total_n || ctx->msm_layout_sets != sets || ctx->msm_layout_c != C || ctx->msm_layout_sort != ctx->msm_sort) {
+        // a different (n, sets, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
         // regions this call is about to overwrite, so the main stream first waits for both slots (no host sync)
         for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++)
             if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
-        ctx->msm_layout_n = n;
+        ctx->msm_layout_n = total_n;
+        ctx->msm_layout_sets = sets;
         ctx->msm_layout_c = C;
         ctx->msm_layout_sort = ctx->msm_sort;
         // the partition counters moved with the layout: cleared once here, then kept clear by k_sortA_scan
-        BBG_HIP(hipMemsetAsync(base_of(ctx) + L.off_parts, 0, SORT_PAD * 4, st));
+        BBG_HIP(hipMemsetAsync(base_of(ctx) + L.off_parts, 0, (size_t)sets * SORT_PAD * 4, st));
         // the redo queues likewise: count and per-bucket flags are zero between MSMs (k_redo clears what it was given)
-        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) BBG_HIP(hipMemsetAsync(base_of(ctx) + L.off_redo[k], 0, ((size_t)2 * K::buckets) * 4, st));
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) BBG_HIP(hipMemsetAsync(base_of(ctx) + L.off_redo[k], 0, ((size_t)2 * nbuckets) * 4, st));
     }
     const int slot = (int)(ctx->msm_seq++ % bbg_ctx::MSM_SLOTS);
     char* base = (char*)ctx->msm.buf;
@@ -1186,7 +1252,7 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
     Xyzz* buckets = (Xyzz*)(base + L.off_buckets[slot]);
     Xyzz* rows = (Xyzz*)(base + L.off_rows[slot]);
     Xyzz* cols = (Xyzz*)(base + L.off_cols[slot]);
-    Xyzz* planes = rows + (1 << K::log_rows);
+    Xyzz* planes = rows + (size_t)sets * (1 << K::log_rows);
     uint32_t* long_count = (uint32_t*)(base + L.off_long[slot]);
     uint32_t* long_list = long_count + 2; // word 1: the redo queue's count
     const bool overlap = ctx->msm_async_reduce;
@@ -1195,15 +1261,16 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
     // this slot's offsets / head / tail / buckets were last read by the reduce phase of the MSM MSM_SLOTS calls ago
     if (ctx->ev_done_valid[slot]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[slot], 0));
     const uint32_t* svals;
-    const int pieces = (h_scalars && ctx->msm_sort == 1 && n >= ((size_t)1 << 16)) ? ctx->msm_upload_pieces : 1;
+    const void* d_scalars = d_scalars_v[0]; // host-buffer uploads exist for a batch of one only (bbg_msm)
+    const int pieces = (h_scalars && sets == 1 && ctx->msm_sort == 1 && n >= ((size_t)1 << 16)) ? ctx->msm_upload_pieces : 1;
     if (h_scalars && pieces <= 1) // small n / library sort / option: one copy in front of everything
         BBG_HIP(hipMemcpyAsync((void*)d_scalars, h_scalars, n * 32, hipMemcpyHostToDevice, st));
     if (ctx->msm_sort == 1) {
         // fused recode + MSD partition sort (keys0 area = 64-bit entries, vals0 = final values, keys1 head = partition tables)
         uint64_t* entries = (uint64_t*)keys0; // keys0 and keys1 are adjacent: 2 x 4 x 16n bytes = 8 x 16n
         uint32_t* part_count = (uint32_t*)(base + L.off_parts);
-        uint32_t* part_base = part_count + SORT_PAD;
-        uint32_t* cursor = part_count + 2 * SORT_PAD;
+        uint32_t* part_base = part_count + (size_t)sets * SORT_PAD;
+        uint32_t* cursor = part_count + (size_t)2 * sets * SORT_PAD;
         const int nblk = grid_for(n, SORT_BLOCK);
         {
             ProfScope ps(ctx, "msm_recode", st);
@@ -1227,32 +1294,39 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
                                            ctx->upload_stream));
                     BBG_HIP(hipEventRecord(ctx->ev_upload[k], ctx->upload_stream));
                     BBG_HIP(hipStreamWaitEvent(st, ctx->ev_upload[k], 0));
-                    hipLaunchKernelGGL((k_sortA_count<C, true>), dim3(std::min(grid_for(len, SORT_BLOCK), COUNT_MAX_BLOCKS)), dim3(COUNT_THREADS), 0, st,
-                                       (const Fr*)d_scalars + lo, len, part_count);
+                    MsmBatch piece = batch;
+                    piece.scalars[0] = (const Fr*)d_scalars + lo;
+                    piece.n[0] = (uint32_t)len;
+                    hipLaunchKernelGGL((k_sortA_count<C, true>), dim3(std::min(grid_for(len, SORT_BLOCK), COUNT_MAX_BLOCKS)), dim3(COUNT_THREADS), 0, st, piece,
+                                       part_count);
                 }
             } else {
                 if (nblk > COUNT_MAX_BLOCKS)
-                    hipLaunchKernelGGL((k_sortA_count<C, true>), dim3(COUNT_MAX_BLOCKS), dim3(COUNT_THREADS), 0, st, (const Fr*)d_scalars, n, part_count);
+                    hipLaunchKernelGGL((k_sortA_count<C, true>), dim3(COUNT_MAX_BLOCKS, sets), dim3(COUNT_THREADS), 0, st, batch, part_count);
                 else
-                    hipLaunchKernelGGL((k_sortA_count<C, false>), dim3(nblk), dim3(COUNT_THREADS), 0, st, (const Fr*)d_scalars, n, part_count);
+                    hipLaunchKernelGGL((k_sortA_count<C, false>), dim3(nblk, sets), dim3(COUNT_THREADS), 0, st, batch, part_count);
             }
-            hipLaunchKernelGGL(k_sortA_scan<C>, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets, long_count);
+            hipLaunchKernelGGL(k_sortA_scan<C>, dim3(1), dim3(1024), 0, st, part_count, part_base, cursor, offsets, long_count, sets);
         }
         {
             ProfScope ps(ctx, "msm_sort", st);
-            hipLaunchKernelGGL(k_sortA_scatter<C>, dim3(nblk), dim3(SORT_BLOCK), 0, st, (const Fr*)d_scalars, n, from, cursor, entries);
+            hipLaunchKernelGGL(k_sortA_scatter<C>, dim3(nblk, sets), dim3(SORT_BLOCK), 0, st, batch, cursor, entries);
             // partitions of a few hundred entries (n <= 2^17 at 16 windows): 256-thread blocks; skewed input is still handled (chunked path)
-            if (L.entries / 1024 <= (size_t)SORTB_PER_THREAD * 256 / 2)
-                hipLaunchKernelGGL((k_sortB<C, 256>), dim3(K::parts), dim3(256), 0, st, entries, part_base, offsets, vals0);
+            if (L.entries / ((size_t)1024 * sets) <= (size_t)SORTB_PER_THREAD * 256 / 2)
+                hipLaunchKernelGGL((k_sortB<C, 256>), dim3(K::parts, sets), dim3(256), 0, st, entries, part_base, offsets, vals0);
             else
-                hipLaunchKernelGGL((k_sortB<C, 1024>), dim3(K::parts), dim3(1024), 0, st, entries, part_base, offsets, vals0);
+                hipLaunchKernelGGL((k_sortB<C, 1024>), dim3(K::parts, sets), dim3(1024), 0, st, entries, part_base, offsets, vals0);
         }
         svals = vals0;
     } else {
 #ifdef BBG_ROCPRIM_SORT
+        if (sets != 1) {
+            set_error("msm_sort = 0 (library sort, A/B only) runs single MSMs only");
+            return BBG_E_INVALID;
+        }
         {
             ProfScope ps(ctx, "msm_recode", st);
-            hipLaunchKernelGGL(k_recode<C>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from, keys0, vals0);
+            hipLaunchKernelGGL(k_recode<C>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const Fr*)d_scalars, n, from_v[0], keys0, vals0);
         }
         rocprim::double_buffer<uint32_t> dk(keys0, keys1), dv(vals0, vals1);
         {
@@ -1262,7 +1336,9 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
             if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs", __FILE__, __LINE__);
         }
         const uint32_t* skeys = dk.current();
-        svals = dv.current();
+        if (dv.current() != vals0) // k_redo (reduce stream) re-reads the sorted values while the next MSM sorts: they live in this slot's buffer
+            BBG_HIP(hipMemcpyAsync(vals0, dv.current(), L.entries * 4, hipMemcpyDeviceToDevice, st));
+        svals = vals0;
         {
             ProfScope ps(ctx, "msm_offsets", st);
             hipLaunchKernelGGL(k_offsets<C>, dim3(grid_for(L.entries + 1, 256)), dim3(256), 0, st, skeys, L.entries, offsets);
@@ -1274,20 +1350,21 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
     }
     bool redo_pending = false; // k_accumulate29 ran: buckets it could not sum are queued
     uint32_t* redo_words = reinterpret_cast<uint32_t*>(base + L.off_redo[slot]);
-    const RedoQueue redo{ long_count + 1, redo_words, redo_words + K::buckets };
+    const RedoQueue redo{ long_count + 1, redo_words, redo_words + nbuckets };
     {
         ProfScope ps(ctx, "msm_accumulate", st);
         if (ctx->msm_sort != 1) BBG_HIP(hipMemsetAsync(long_count, 0, 8, st)); // the partition sort's scan kernel clears both counts
         // few lanes (n <= 2^14 or so): the kernel's time is one lane's chain of dependent mixed additions -- four threads per lane shorten it
         if (ctx->msm_accumulate_quad && L.lanes <= MSM_QUAD_ACC_MAX_LANES)
             hipLaunchKernelGGL(k_accumulate_q4<C>, dim3(grid_for(L.lanes * 4, 256)), dim3(256), 0, st, svals, offsets, table, srs.n, L.seg, head, tail,
-                               buckets);
+                               buckets, nbuckets);
         else if (ctx->msm_limbs29) {
             redo_pending = true;
             hipLaunchKernelGGL(k_accumulate29<C>, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, table, srs.n, L.seg, head, tail, buckets,
-                               redo);
+                               redo, nbuckets);
         } else
-            hipLaunchKernelGGL(k_accumulate<C>, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, table, srs.n, L.seg, head, tail, buckets);
+            hipLaunchKernelGGL(k_accumulate<C>, dim3(grid_for(L.lanes, 256)), dim3(256), 0, st, svals, offsets, table, srs.n, L.seg, head, tail, buckets,
+                               nbuckets);
     }
     if (overlap) {
         BBG_HIP(hipEventRecord(ctx->ev_acc[slot], st));
@@ -1299,33 +1376,34 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, const void* d_s
         // operation (curve_quad.hip.h: the same chain, ~3x shorter in time) or with one (the round-1 kernels, kept for A/B)
         const int quad = ctx->msm_reduce_quad;
         if (quad & 1) {
-            if (L.lanes > (size_t)2 * K::buckets)
-                hipLaunchKernelGGL(k_combine_lanes_q<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst,
-                                   offsets, L.seg, head, tail, buckets, long_count, long_list);
+            if (L.lanes > (size_t)2 * nbuckets)
+                hipLaunchKernelGGL(k_combine_lanes_q<C>, dim3(grid_for((size_t)nbuckets * MSM_COMBINE_LANES * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst,
+                                   offsets, L.seg, head, tail, buckets, long_count, long_list, nbuckets);
             else
-                hipLaunchKernelGGL(k_combine_q<C>, dim3(grid_for((size_t)K::buckets * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail,
-                                   buckets, long_count, long_list);
+                hipLaunchKernelGGL(k_combine_q<C>, dim3(grid_for((size_t)nbuckets * 4, Q_THREADS)), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail,
+                                   buckets, long_count, long_list, nbuckets);
             hipLaunchKernelGGL(k_combine_long_q<C>, dim3(256), dim3(Q_THREADS), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
         } else {
-            if (L.lanes > (size_t)2 * K::buckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
-                hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)K::buckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
-                                   L.seg, head, tail, buckets, long_count, long_list);
+            if (L.lanes > (size_t)2 * nbuckets) // several pieces per bucket: lane groups + butterfly; else one lane per bucket
+                hipLaunchKernelGGL(k_combine_lanes<C>, dim3(grid_for((size_t)nbuckets * MSM_COMBINE_LANES, 256)), dim3(256), 0, rst, offsets,
+                                   L.seg, head, tail, buckets, long_count, long_list, nbuckets);
             else
-                hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)K::buckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
-                                   buckets, long_count, long_list);
+                hipLaunchKernelGGL(k_combine<C>, dim3(grid_for((size_t)nbuckets, 256)), dim3(256), 0, rst, offsets, L.seg, head, tail,
+                                   buckets, long_count, long_list, nbuckets);
             hipLaunchKernelGGL(k_combine_long<C>, dim3(256), dim3(256), 0, rst, offsets, L.seg, head, tail, buckets, long_count, long_list);
         }
         if (redo_pending) hipLaunchKernelGGL(k_redo<C>, dim3(128), dim3(256), 0, rst, svals, offsets, table, srs.n, redo, buckets);
         // 64 logical lanes per row / column (measured against 128 / 32 / 16: reduce phase 0.458 / 0.49 / 0.53 / 0.55 ms at 2^20 stand-alone,
         // 0.154 / 0.165 / 0.164 / 0.184 at 2^10; bench step equal for 64 and 128, worse below)
-        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, BBG_ROWCOL_QL>), dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(4 * BBG_ROWCOL_QL), 0, rst, buckets, rows, cols);
-        else hipLaunchKernelGGL(k_rowcol<C>, dim3((1 << K::log_rows) + (1 << K::log_cols)), dim3(256), 0, rst, buckets, rows, cols);
-        if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes), dim3(Q_THREADS), 0, rst, rows, cols, planes);
-        else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes), dim3(256), 0, rst, rows, cols, planes);
+        const dim3 rc_grid((1 << K::log_rows) + (1 << K::log_cols), sets);
+        if (quad & 2) hipLaunchKernelGGL((k_rowcol_q<C, BBG_ROWCOL_QL>), rc_grid, dim3(4 * BBG_ROWCOL_QL), 0, rst, buckets, rows, cols);
+        else hipLaunchKernelGGL(k_rowcol<C>, rc_grid, dim3(256), 0, rst, buckets, rows, cols);
+        if (quad & 4) hipLaunchKernelGGL(k_final_planes_q<C>, dim3(K::planes, sets), dim3(Q_THREADS), 0, rst, rows, cols, planes);
+        else hipLaunchKernelGGL(k_final_planes<C>, dim3(K::planes, sets), dim3(256), 0, rst, rows, cols, planes);
         // (the plane sum stays a launch of its own: folded into the planes kernel as "the last block to finish adds the planes", its
         // device-scope fences write back and invalidate the L2 of every XCD a block runs on -- the accumulation running beside it lost
         // 2 % (1.120 vs 1.098 ms, bench step 1.672 vs 1.647), and a small MSM gained nothing: 87-98 us against 64 + 20)
-        rc = msm_launch_final_sum((quad & 8) != 0, planes, (int)K::planes, d_out_jac, rst);
+        rc = msm_launch_final_sum((quad & 8) != 0, planes, (int)K::planes, d_out_jac, rst, sets);
         if (rc) return rc;
     }
     if (overlap) {

@@ -1,6 +1,6 @@
 // 20-bit windows: every templated kernel of the bucket MSM instantiated for MsmCfg<20> (msm_kernels.hip.h).
 #include "msm_kernels.hip.h"
 namespace bbg {
-template int msm_run_c<20>(bbg_ctx*, const Srs&, const void*, const void*, size_t, size_t, void*, hipStream_t, const void*);
+template int msm_run_c<20>(bbg_ctx*, const Srs&, const void*, int, const void* const*, const size_t*, const size_t*, void*, hipStream_t, const void*);
 template int srs_build_tables_c<20>(const void*, size_t, void*, hipStream_t);
 } // namespace bbg

@@ -15,7 +15,9 @@
 // runs on the context's auxiliary stream and overlaps the next kernels; each round ends with ONE host synchronisation.
 #include "bbg_internal.h"
 
+#include <algorithm>
 #include <cstring>
+#include <set>
 #include "field.hip.h"
 #include "ntt_consts.hip.h"
 
@@ -87,7 +89,23 @@ struct bbg_prover {
     hipEvent_t ev_up[4] = {};
     int stage = 0; // rounds completed in the current proof (guards the call order)
     std::vector<void*> allocs;
+    size_t device_bytes = 0; // sum of `allocs` (bbg_prover_device_bytes, bbg_memory_report)
 };
+
+namespace bbg {
+// live handles of the process: bbg_memory_report totals the ones of a context
+static std::mutex g_prover_mu;
+static std::set<bbg_prover*> g_live_provers;
+void prover_report(const bbg_ctx* ctx, size_t* bytes, unsigned* count)
+{
+    std::lock_guard<std::mutex> lk(g_prover_mu);
+    for (const bbg_prover* p : g_live_provers)
+        if (p->ctx == ctx) {
+            *bytes += p->device_bytes;
+            (*count)++;
+        }
+}
+} // namespace bbg
 
 namespace {
 
@@ -102,6 +120,22 @@ int dev_alloc(bbg_prover* p, void** out, size_t bytes)
 {
     BBG_HIP(hipMalloc(out, bytes));
     p->allocs.push_back(*out);
+    p->device_bytes += bytes;
+    return BBG_OK;
+}
+
+// The independent commitments of a round -- the reference queues them and processes the queue as one unit (prover.cpp:66-74 the wires,
+// :120-135 the quotient parts, work_queue.hpp:208-282) -- go through ONE sort / accumulate / reduce launch set, `max_batch` at a time
+// (option "prover_msm_batch": 0 / 1 = one launch set per commitment, the round-3 behaviour, A/B).  Result k lands at d_jac + 96 (first + k).
+int commit(bbg_prover* p, int count, const void* const* d_polys, const size_t* lens, int first, hipStream_t st)
+{
+    const int max_batch = std::max(1, std::min(p->ctx->prover_msm_batch, BBG_MSM_BATCH_MAX));
+    const size_t zero[BBG_MSM_BATCH_MAX] = { 0 };
+    for (int k = 0; k < count; k += max_batch) {
+        const int c = std::min(max_batch, count - k);
+        int rc = msm_run_batch(p->ctx, p->srs->s, c, d_polys + k, zero, lens + k, (char*)p->d_jac + (size_t)(first + k) * 96, st);
+        if (rc) return rc;
+    }
     return BBG_OK;
 }
 int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
@@ -232,6 +266,10 @@ int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int fl
         bbg_prover_destroy(p);
         return rc;
     }
+    {
+        std::lock_guard<std::mutex> lk2(g_prover_mu);
+        g_live_provers.insert(p);
+    }
     *out = p;
     return BBG_OK;
 }
@@ -239,6 +277,10 @@ int bbg_prover_create_flavour(bbg_ctx* ctx, bbg_srs* srs, unsigned log2n, int fl
 void bbg_prover_destroy(bbg_prover* p)
 {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_prover_mu);
+        g_live_provers.erase(p);
+    }
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     for (void* a : p->allocs) (void)hipFree(a);
@@ -334,15 +376,27 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     hipStream_t st = p->ctx->stream;
     AsyncReduce ar(p->ctx);
     const size_t n = p->n;
-    for (int k = 0; k < p->width; k++) {
+    for (int k = 0; k < p->width; k++)
         if (!wires_lagrange[k]) { set_error("bbg_prover_round1: null wire"); return BBG_E_INVALID; }
-        // upload on the copy stream: wire k+1 travels while wire k is transformed and committed
+    // The wires travel on the copy stream; the commitments go in groups through one launch set each (commit()).  A group starts as soon as
+    // ITS wires have landed and been transformed: small circuits (upload negligible) commit all wires at once, large ones in pairs so
+    // that the second pair travels while the first is committed (4 x 32 MiB is 2.6 ms of PCIe at 2^20 gates).
+    const int max_batch = std::max(1, std::min(p->ctx->prover_msm_batch, BBG_MSM_BATCH_MAX));
+    const int group = max_batch == 1 ? 1 : (p->log2n <= 17 ? std::min(max_batch, p->width) : std::min(max_batch, 2));
+    const size_t lens[4] = { n, n, n, n };
+    for (int k = 0; k < p->width; k++) {
         BBG_HIP(hipMemcpyAsync(p->wire_lagrange[k], wires_lagrange[k], n * 32, hipMemcpyHostToDevice, p->copy_stream));
         BBG_HIP(hipEventRecord(p->ev_up[k], p->copy_stream));
-        BBG_HIP(hipStreamWaitEvent(st, p->ev_up[k], 0));
-        BBG_HIP(hipMemcpyAsync(p->wire_coeff[k], p->wire_lagrange[k], n * 32, hipMemcpyDeviceToDevice, st));
-        int rc = ntt_run(p->ctx, p->wire_coeff[k], p->log2n, BBG_IFFT, 0, nullptr, st);
-        if (!rc) rc = msm_run(p->ctx, p->srs->s, p->wire_coeff[k], 0, n, (char*)p->d_jac + k * 96, st);
+    }
+    for (int k0 = 0; k0 < p->width; k0 += group) {
+        const int cnt = std::min(group, p->width - k0);
+        for (int k = k0; k < k0 + cnt; k++) {
+            BBG_HIP(hipStreamWaitEvent(st, p->ev_up[k], 0));
+            BBG_HIP(hipMemcpyAsync(p->wire_coeff[k], p->wire_lagrange[k], n * 32, hipMemcpyDeviceToDevice, st));
+            int rc = ntt_run(p->ctx, p->wire_coeff[k], p->log2n, BBG_IFFT, 0, nullptr, st);
+            if (rc) return rc;
+        }
+        int rc = commit(p, cnt, p->wire_coeff + k0, lens, k0, st);
         if (rc) return rc;
     }
     int rc = fetch_commitments(p, (size_t)p->width, commitments, st);
@@ -417,9 +471,15 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
     if (!rc) rc = poly_divide_pseudo_vanishing(p->ctx, p->quotient, p->log2n, p->log2n + 2, 4, st);
     if (!rc) rc = ntt_run(p->ctx, p->quotient, p->log2n + 2, BBG_COSET_IFFT, 0, nullptr, st);
     // T_1 .. T_width: n coefficients each; t_high of StandardPLONK has n + 1 (compute_quotient_pre_commitment, prover.cpp:117-137)
-    for (int k = 0; k < p->width && !rc; k++)
-        rc = msm_run(p->ctx, p->srs->s, (char*)p->quotient + (size_t)k * n * 32, 0, (p->width == 3 && k == 2) ? n + 1 : n,
-                     (char*)p->d_jac + k * 96, st);
+    if (!rc) {
+        const void* parts[4];
+        size_t lens[4];
+        for (int k = 0; k < p->width; k++) {
+            parts[k] = (char*)p->quotient + (size_t)k * n * 32;
+            lens[k] = (p->width == 3 && k == 2) ? n + 1 : n;
+        }
+        rc = commit(p, p->width, parts, lens, 0, st);
+    }
     if (rc) return rc;
     rc = fetch_commitments(p, (size_t)p->width, t_commitments, st);
     if (rc) return rc;
@@ -509,7 +569,8 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
         f_len = n + 1;
     }
     rc = poly_kate_opening_async(p->ctx, p->tmp, p->opening[0], f_len, zeta, nullptr, st);
-    if (!rc) rc = msm_run(p->ctx, p->srs->s, p->opening[0], 0, n, p->d_jac, st);
+    const bool together = p->ctx->prover_msm_batch >= 2; // PI_Z and PI_Z_OMEGA through one launch set (commit())
+    if (!rc && !together) rc = msm_run(p->ctx, p->srs->s, p->opening[0], 0, n, p->d_jac, st);
     if (rc) return rc;
     for (size_t k = 0; k < count_omega; k++) {
         rc = coeff_poly(p, ids_omega[k], &ptrs[k], &len);
@@ -517,7 +578,11 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
     }
     rc = poly_lincomb(ptrs, scalars_omega, count_omega, nullptr, p->tmp, n, st);
     if (!rc) rc = poly_kate_opening_async(p->ctx, p->tmp, p->opening[1], n, zeta_omega, nullptr, st);
-    if (!rc) rc = msm_run(p->ctx, p->srs->s, p->opening[1], 0, n, (char*)p->d_jac + 96, st);
+    if (!rc && !together) rc = msm_run(p->ctx, p->srs->s, p->opening[1], 0, n, (char*)p->d_jac + 96, st);
+    if (!rc && together) {
+        const size_t lens[2] = { n, n };
+        rc = commit(p, 2, p->opening, lens, 0, st);
+    }
     if (rc) return rc;
     uint64_t both[24];
     rc = fetch_commitments(p, 2, both, st);
@@ -525,6 +590,13 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
     memcpy(pi_z, both, 96);
     memcpy(pi_z_omega, both + 12, 96);
     p->stage = 0;
+    return BBG_OK;
+}
+
+int bbg_prover_device_bytes(const bbg_prover* p, size_t* bytes)
+{
+    if (!p || !bytes) { set_error("bbg_prover_device_bytes: null argument"); return BBG_E_INVALID; }
+    *bytes = p->device_bytes;
     return BBG_OK;
 }
 

@@ -74,7 +74,13 @@ class ShardedMsmPipeline:
     `side_stream` (a torch.cuda.Stream, GPU runs): the exchange is issued there, ordered behind the local MSMs by an event, so that the main
     stream goes straight on with whatever the caller queues next (the bench step's NTT and the next MSM's sort)."""
 
-    def __init__(self, ops, dist, new_tensor, side_stream=None, depth=1):
+    def __init__(self, ops, dist, new_tensor, side_stream=None, depth=1, cuda=None):
+        """`cuda`: the stream / event API (default torch.cuda); the CPU tests pass a recording stand-in to check the ordering protocol."""
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        if side_stream is not None and getattr(ops, "bbg_side", self) is None:
+            # the group sums would run on the MAIN context's stream while the all-gather that feeds them runs on the side stream: a race
+            raise ValueError("side_stream needs ops with a side context bound to it (BbgOps(bbg, srs, bbg_side))")
         self.ops, self.dist, self.depth = ops, dist, depth
         self.world = dist.get_world_size() if dist is not None else 1
         self.ring = 2 * depth
@@ -84,20 +90,24 @@ class ShardedMsmPipeline:
         self.results = [new_tensor(12) for _ in range(self.ring)]
         self.side = side_stream
         if side_stream is not None:
-            import torch
-            self._torch = torch
-            self.ev_ready = [torch.cuda.Event(), torch.cuda.Event()]  # main stream: the partials of this half of the ring are final
-            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # side stream: this half's partials read, its results written
+            if cuda is None:
+                import torch
+                cuda = torch.cuda
+            self._cuda = cuda
+            self.ev_ready = [cuda.Event(), cuda.Event()]  # main stream: the partials of this half of the ring are final
+            self.ev_done = [cuda.Event(), cuda.Event()]   # side stream: this half's partials read, its results written
         self.reset()
 
     def reset(self):
         """Forget finished work (call only after flush() and a device synchronisation)."""
-        self.count = 0     # MSMs submitted
-        self.finished = 0  # MSMs whose global result has been issued
+        self.count = 0     # ring position of the next MSM (= MSMs submitted, plus the slots flush() skipped to end a partial batch)
+        self.finished = 0  # ring position up to which global results have been issued
+        self.submitted = 0  # MSMs submitted since reset()
+        self.last_slot = None
         self.done_valid = [False, False]
 
     def last_result(self):
-        return self.results[(self.count - 1) % self.ring] if self.count else None
+        return self.results[self.last_slot] if self.last_slot is not None else None
 
     def _combine(self, j0, cnt):
         lo = 12 * (j0 % self.ring)
@@ -117,29 +127,35 @@ class ShardedMsmPipeline:
 
     def _finish(self, j0, cnt, lag):
         """Global results of MSMs j0 .. j0 + cnt - 1 (one half of the ring, or the head of one)."""
+        assert j0 % self.depth == 0 and cnt <= self.depth, "a batch is one half of the ring"
         self.ops.join(lag)  # device-side wait for the reductions of everything but the `lag` most recent MSMs
         if self.side is None:
             self._combine(j0, cnt)
             return
-        torch, h = self._torch, (j0 // self.depth) & 1
-        self.ev_ready[h].record(torch.cuda.current_stream())
+        cuda, h = self._cuda, (j0 // self.depth) & 1
+        self.ev_ready[h].record(cuda.current_stream())
         self.side.wait_event(self.ev_ready[h])
-        with torch.cuda.stream(self.side):
+        with cuda.stream(self.side):
             self._combine(j0, cnt)
             self.ev_done[h].record(self.side)
         self.done_valid[h] = True
 
     def submit(self, d_scalars, n):
+        """Issues the local MSM; returns the index into `results` where this MSM's global result appears (valid after the batch it belongs
+        to has been finished -- at the latest after flush() -- until 2 * depth further submits)."""
         i = self.count
         if self.side is not None and i % self.depth == 0:  # MSM i starts overwriting a half of the ring: the side stream must be done with it
             h = (i // self.depth) & 1
             if self.done_valid[h]:
-                self._torch.cuda.current_stream().wait_event(self.ev_done[h])
+                self._cuda.current_stream().wait_event(self.ev_done[h])
         self.ops.msm(d_scalars, n, self.partial[i % self.ring])
         self.count += 1
+        self.submitted += 1
+        self.last_slot = i % self.ring
         if self.count - self.finished == self.depth + 1:  # a whole batch lies behind the MSM just issued
             self._finish(self.finished, self.depth, 1)
             self.finished += self.depth
+        return self.last_slot
 
     def flush(self):
         lag = 0
@@ -147,8 +163,11 @@ class ShardedMsmPipeline:
             cnt = min(self.depth, self.count - self.finished)
             self._finish(self.finished, cnt, lag)  # the first call waits for every outstanding reduction
             self.finished += cnt
+        # A flushed remainder ends its batch: the next submit starts a fresh half of the ring.  (Continuing inside the partial batch would
+        # make the following batch straddle the ring's end -- a truncated all-gather block -- and break the half <-> event pairing.)
+        self.count = self.finished = -(-self.count // self.depth) * self.depth
         if self.side is not None and self.count:
-            self._torch.cuda.current_stream().wait_stream(self.side)
+            self._cuda.current_stream().wait_stream(self.side)
         return self.last_result()
 
 

@@ -134,13 +134,33 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # Shapes the sharded paths cannot take are refused HERE, before any process group exists: every rank sees the same arguments and
+    # leaves, rank 0 with a JSON line that says why -- never a rank waiting in a collective the others did not enter.
+    problem = None
+    if world != args.gpus:
+        problem = "WORLD_SIZE = %d but --gpus %d" % (world, args.gpus)
+    elif world & (world - 1) or world > 8:
+        problem = "the residue-class NTT split needs a power-of-two world <= 8 (got %d)" % world
+    elif not args.no_config5 and ((1 << args.config5_log2n) // world) % world:
+        problem = "config 5: G^2 must divide n (G = %d, n = 2^%d)" % (world, args.config5_log2n)
+    elif args.log2n < 1 or args.log2n > 26:
+        problem = "--log2n must be 1 .. 26 (2^26 points per device is the entry format's cap)"
+    if problem:
+        if rank == 0:
+            os.write(REAL_STDOUT, (json.dumps({"metric": "BN254 G1 MSM Mscalar-mults/s (+ Fr NTT Gfield-ops/s in extra) at n=2^%d" % args.log2n, "value": None,
+                                               "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": problem}) + "\n").encode())
+        raise SystemExit(2)
     dist = None
     force_dist = os.environ.get("BBG_FORCE_DIST") == "1"  # exercise the RCCL + pipeline code path with a world of 1
     if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:  # only without a launcher, i.e. a world of one (BBG_FORCE_DIST): any free port will do
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
@@ -242,8 +262,8 @@ def main():
                 "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
-    width = args.msm_window or (22 if n >= (1 << 23) else 20 if n >= (1 << 21) else 19 if n >= (1 << 20) else 16)  # csrc/msm.hip msm_auto_window
-    msm_windows = float((254 + width) // width)
+    width, msm_windows = bbg.msm_plan(n, srs)  # what the library ran with (bbg_msm_plan), not a copy of its rule
+    msm_windows = float(msm_windows)
     pass_ms = avg("ntt_pass")
     ntt_alg = 64.0 * n
     ntt_passes = prof["ntt_pass"][1] / max(1, args.steps)

@@ -103,6 +103,21 @@ void bbg_srs_free(bbg_srs* srs);
 int bbg_msm(bbg_ctx* ctx, bbg_srs* srs, const uint64_t* scalars, size_t from, size_t n, uint64_t out_jacobian[12]);
 /* Device-resident variant: d_scalars and d_out_jacobian (96 B) are device pointers; asynchronous on the context stream. */
 int bbg_msm_device(bbg_ctx* ctx, bbg_srs* srs, const void* d_scalars, size_t from, size_t n, void* d_out_jacobian);
+/* A round's independent commitments as ONE unit of work -- what the reference queues and processes together (the four wire commitments of
+ * round 1, prover.cpp:66-74; the quotient parts of round 4, :120-135; work_queue.hpp:208-282): `count` (<= BBG_MSM_BATCH_MAX) MSMs over the SAME
+ * SRS go through ONE sort / accumulate / reduce launch set, MSM k's entries filed under bucket set k (count x 2^(C-1) buckets), instead of
+ * `count` latency chains.  out_jacobians[k] = sum_{i<n[k]} scalars[k][i] * P_{from[k]+i}; from == NULL means all zero; the n[k] may differ
+ * (StandardPLONK's t_high has n + 1 coefficients).  Each result is the same group element bbg_msm gives for that MSM alone. */
+#define BBG_MSM_BATCH_MAX 8
+int bbg_msm_batch(bbg_ctx* ctx, bbg_srs* srs, size_t count, const uint64_t* const* scalars, const size_t* from, const size_t* n,
+                  uint64_t* out_jacobians /* count x 12 limbs */);
+/* Device-resident variant: d_scalars[k] are device pointers, d_out_jacobians holds count x 96 B; asynchronous on the context stream. */
+int bbg_msm_batch_device(bbg_ctx* ctx, bbg_srs* srs, size_t count, const void* const* d_scalars, const size_t* from, const size_t* n,
+                         void* d_out_jacobians);
+/* The configuration an n-term MSM over `srs` (may be NULL: a fresh SRS of n points) would run with now: *window_bits = the widest bucket
+ * window C (buckets = 2^(C-1)), *windows = the number of windows, i.e. table gathers and mixed additions per scalar.  Follows the option
+ * "msm_window" and the resident-table rule for short MSMs over long SRSs. */
+int bbg_msm_plan(bbg_ctx* ctx, const bbg_srs* srs, size_t n, int* window_bits, int* windows);
 /* g1_sum (c_bind.cpp:39-46): sum of n Jacobian points (host arrays, 96 B each). */
 int bbg_g1_sum(bbg_ctx* ctx, const uint64_t* jacobians, size_t n, uint64_t out_jacobian[12]);
 /* Same on device buffers, asynchronous on the context stream (the multi-GPU combine after an all-gather of partials). */
@@ -288,6 +303,8 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
                       const uint64_t* t_high_top_scalar, uint64_t pi_z[12], uint64_t pi_z_omega[12]);
 /* Copies a resident polynomial back (tests; a host that wants the reference's post-proof state): id / form as above. */
 int bbg_prover_read_poly(bbg_prover* p, int id, int form, uint64_t* out, size_t count);
+/* Device bytes this handle owns (key polynomials in every form + the per-proof working set); what a key cache budgets with. */
+int bbg_prover_device_bytes(const bbg_prover* p, size_t* bytes);
 
 /* ---- several GPUs in one process: one MSM / one (coset) NTT spread over a group of contexts, one per device of the node
  *      (device indices may repeat: several contexts on one GPU, which is how the split is tested on a single-GPU box).
@@ -322,9 +339,29 @@ int bbg_multi_ntt_device(bbg_multi* m, void* const* d_shards, unsigned log2n, in
  * that gather and PCIe, not by the GPUs -- the resident form above is the one to build a multi-GPU prover on). */
 int bbg_multi_ntt(bbg_multi* m, uint64_t* coeffs, unsigned log2n, int op);
 
+/* ---- HBM budget: what a context holds on its device, by purpose.  Everything here is allocated on first use and then kept (the
+ *      pippenger_runtime_state / evaluation_domain analogue: runtime_states.cpp:14-66, evaluation_domain.cpp:57-76); this call is how a
+ *      host sees and bounds the total.  bbg_memory_trim releases what can be rebuilt on demand. ---- */
+typedef struct bbg_memory_info {
+    size_t srs_points;     /* plain SRS points not part of a window table (none today: window 0 of a table IS the plain points) */
+    size_t srs_tables;     /* window tables of every live SRS of this context, all widths */
+    size_t ntt_tables;     /* per-domain twiddle / coset tables (5 x 32n bytes per prepared size) */
+    size_t msm_arena;      /* the MSM scratch arena (entries, sorted values, per-slot bucket sets) */
+    size_t scratch;        /* NTT ping-pong buffer, host-entry staging, evaluation partials, widget constants */
+    size_t prover_keys;    /* every live bbg_prover handle of this context (bbg_prover_device_bytes) */
+    size_t total;          /* sum of the above */
+    size_t device_total;   /* hipMemGetInfo: the device's memory ... */
+    size_t device_free;    /* ... and what is free right now (other processes and the runtime included) */
+    unsigned live_srs, live_provers, ntt_domains;
+} bbg_memory_info;
+int bbg_memory_report(bbg_ctx* ctx, bbg_memory_info* out);
+/* Frees the rebuildable part after a device synchronisation: NTT tables of every size, the MSM arena, scratch and staging buffers, and --
+ * with tables != 0 -- every window table except the one each SRS was registered with.  Returns the bytes released in *released (may be NULL). */
+int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
+
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
- * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [16 bits below 2^20 terms, 20 from 2^20, 22 from 2^23],
+ * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [16 bits below 2^20 terms, 19 at 2^20, 20 from 2^21, 22 from 2^23 -- bbg_msm_plan reports it],
  * or a compiled width 16 / 17 / 19 / 20 / 22; windows are BALANCED -- 255 bits split as evenly as the window count allows --; a width's window tables
  * are built the first time it is used on an SRS), "msm_sort" (1 = fused recode + two-level partition sort, default; 0 = recode + rocPRIM radix sort, only
  * in builds made with `make ROCPRIM_SORT=1`),

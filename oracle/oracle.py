@@ -480,6 +480,8 @@ PROVER_SO = os.path.join(_HERE, "_ref", "libbbprover.so")
 # same objects + shim/bbg_barretenberg_shim.cpp + -Wl,--wrap flags + libbbg.so: the reference prover with its MSM / FFT
 # entry points wrapped onto the GPU library at link time.  Needs the HIP runtime: import torch first.
 PROVER_GPU_SO = os.path.join(_HERE, "_ref", "libbbprover_gpu.so")
+# the CPU build's own driver object linked with BOTH shim TUs: construct_proof() itself is wrapped (oracle/Makefile prover_wrap)
+PROVER_WRAP_SO = os.path.join(_HERE, "_ref", "libbbprover_wrap.so")
 
 
 def prover_available():
@@ -507,14 +509,26 @@ class RefProver:
                                   ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_void_p)
 
-    def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False, flavour=0):
+    def __init__(self, num_gates, circuit_seed, points, x_mont, gpu_linked=False, flavour=0, wrap_linked=False):
         """flavour 0 = TurboPLONK (TurboComposer / TurboProver), 1 = StandardPLONK (StandardComposer / Prover) over the same circuit,
-        2 = MiMCComposer (MiMC rounds + the arithmetic chain; Prover with the MiMC widget)."""
-        if not prover_available() or (gpu_linked and not os.path.exists(PROVER_GPU_SO)):
-            raise RuntimeError("oracle/_ref/libbbprover[_gpu].so not available on this machine")
-        L = self.lib = ctypes.CDLL(PROVER_GPU_SO if gpu_linked else PROVER_SO, mode=os.RTLD_NOW)
+        2 = MiMCComposer (MiMC rounds + the arithmetic chain; Prover with the MiMC widget).
+        gpu_linked: libbbprover_gpu.so (MSM / FFT entry points wrapped + the explicit resident glue); wrap_linked: libbbprover_wrap.so (the
+        CPU build's driver object, construct_proof() itself wrapped: prove_reference() IS the resident prover there)."""
+        so = PROVER_WRAP_SO if wrap_linked else PROVER_GPU_SO if gpu_linked else PROVER_SO
+        if not prover_available() or not os.path.exists(so):
+            raise RuntimeError(f"{so} not available on this machine")
+        L = self.lib = ctypes.CDLL(so, mode=os.RTLD_NOW)
         L.refp_gpu_linked.restype = cint
-        assert bool(L.refp_gpu_linked()) == bool(gpu_linked)
+        L.refp_wrap_linked.restype = cint
+        assert bool(L.refp_gpu_linked()) == bool(gpu_linked or wrap_linked) and bool(L.refp_wrap_linked()) == bool(wrap_linked)
+        L.refp_wrap_set_enabled.argtypes = [cint]
+        L.refp_wrap_set_replay.argtypes = [vp, sz]
+        L.refp_wrap_set_budget.argtypes = [sz]
+        L.refp_wrap_cached_keys.restype = sz
+        L.refp_wrap_bytes.restype = sz
+        L.refp_wrap_trim.restype = sz
+        L.refp_wrap_stats.argtypes = [vp]
+        L.refp_reset.argtypes = [vp]
         L.refp_new_flavour.argtypes = [cint, sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new_flavour.restype = vp
         L.refp_program_width.argtypes = [vp]; L.refp_program_width.restype = sz
         L.refp_construct_proof_recording.argtypes = [vp, vp]; L.refp_construct_proof_recording.restype = cint
@@ -562,11 +576,47 @@ class RefProver:
             raise RuntimeError(f"refp_construct_proof_recording failed ({rc})")
         return self._proof(), blind
 
-    def prove_reference(self):
-        """ProverBase::construct_proof() as shipped, one call (shim-linked build: MSM / FFT entry points on the GPU)."""
-        if self.lib.refp_construct_proof_reference(self.h) != 0:
-            raise RuntimeError("refp_construct_proof_reference failed")
+    def prove_reference(self, replay=None, reset=False):
+        """ProverBase::construct_proof() as shipped, one call (shim-linked build: MSM / FFT entry points on the GPU; wrap-linked build: the
+        resident prover behind the wrapped symbol).  replay (wrap-linked only): blinding scalars for this proof; reset: ProverBase::reset()
+        first (a second proof on the same prover object)."""
+        if reset:
+            self.lib.refp_reset(self.h)
+        if replay is not None:
+            r = _arr(replay, 4)
+            self.lib.refp_wrap_set_replay(r.ctypes.data, r.shape[0])
+        try:
+            if self.lib.refp_construct_proof_reference(self.h) != 0:
+                raise RuntimeError("refp_construct_proof_reference failed: " + (self.lib.refp_last_error(self.h) or b"").decode())
+        finally:
+            if replay is not None:
+                self.lib.refp_wrap_set_replay(None, 0)
         return self._proof()
+
+    # ---- the wrapped construct_proof() (wrap-linked build): controls and counters of shim/bbg_prover_wrap.cpp
+    def wrap_set_enabled(self, on):
+        self.lib.refp_wrap_set_enabled(1 if on else 0)
+
+    def wrap_set_budget(self, nbytes):
+        self.lib.refp_wrap_set_budget(nbytes)
+
+    def wrap_cached_keys(self):
+        return int(self.lib.refp_wrap_cached_keys())
+
+    def wrap_bytes(self):
+        return int(self.lib.refp_wrap_bytes())
+
+    def wrap_trim(self):
+        return int(self.lib.refp_wrap_trim())
+
+    def wrap_clear(self):
+        self.lib.refp_wrap_clear()
+
+    def wrap_stats(self):
+        """(proofs through the resident path, fallbacks to the reference body, evictions)."""
+        out = (ctypes.c_uint64 * 3)()
+        self.lib.refp_wrap_stats(out)
+        return tuple(int(v) for v in out)
 
     def resident_key_create(self):
         """bbg_shim::ResidentKey for this circuit's proving key (shim-linked build only); seconds."""

@@ -47,6 +47,18 @@ using namespace barretenberg;
 
 // present only in the build that is linked with the drop-in shim (libbbprover_gpu.so)
 extern "C" void bbg_shim_unregister_point_table(const void* endo_table) __attribute__((weak));
+// present only in the build whose construct_proof() is wrapped as well (libbbprover_wrap.so: shim/bbg_prover_wrap.cpp)
+extern "C" {
+void bbg_shim_resident_set_enabled(int on) __attribute__((weak));
+int bbg_shim_resident_enabled(void) __attribute__((weak));
+void bbg_shim_resident_set_random(void (*draw)(void* user, uint64_t out[4]), void* user) __attribute__((weak));
+void bbg_shim_resident_set_budget(size_t bytes) __attribute__((weak));
+size_t bbg_shim_resident_cached_keys(void) __attribute__((weak));
+size_t bbg_shim_resident_bytes(void) __attribute__((weak));
+size_t bbg_shim_resident_trim(void) __attribute__((weak));
+void bbg_shim_resident_clear(void) __attribute__((weak));
+void bbg_shim_resident_stats(uint64_t out[3]) __attribute__((weak));
+}
 
 namespace {
 
@@ -128,6 +140,7 @@ struct Session {
     virtual void execute_round(int k) = 0;
     virtual void compute_quotient_pre_commitment() = 0;
     virtual void construct_proof_reference() = 0; // ProverBase::construct_proof as shipped (CPU, or the shim's wrapped entry points)
+    virtual void reset_prover() = 0;
     virtual std::vector<uint8_t> export_proof() = 0;
     virtual int verify(const std::vector<uint8_t>& proof_data) = 0;
     virtual size_t program_width() const = 0;
@@ -270,6 +283,7 @@ template <typename Composer, typename Prover, typename Verifier> struct SessionT
     }
     void compute_quotient_pre_commitment() override { prover->compute_quotient_pre_commitment(); }
     void construct_proof_reference() override { prover->construct_proof(); }
+    void reset_prover() override { prover->reset(); }
     std::vector<uint8_t> export_proof() override { return prover->export_proof().proof_data; }
     int verify(const std::vector<uint8_t>& proof_data) override
     {
@@ -601,18 +615,24 @@ int refp_construct_proof_recording(void* h, uint64_t* blind_out)
         return -1;
     }
 }
-// ProverBase::construct_proof() as shipped, in one call (in the shim-linked build: MSM / FFT on the GPU through --wrap)
+// ProverBase::construct_proof() as shipped, in one call (in the shim-linked build: MSM / FFT on the GPU through --wrap; in the build
+// that wraps construct_proof() too: the resident prover)
 int refp_construct_proof_reference(void* h)
 {
+    auto* s = (Session*)h;
     try {
-        auto* s = (Session*)h;
         s->construct_proof_reference();
         s->proof = s->export_proof();
         return 0;
+    } catch (const std::exception& e) {
+        s->error = e.what();
+        return -1;
     } catch (...) {
         return -1;
     }
 }
+// a fresh transcript on the same prover (ProverBase::reset): the session proves again
+void refp_reset(void* h) { ((Session*)h)->reset_prover(); }
 // bbg_shim::ResidentKey for this session's proving key (once per circuit); seconds, or < 0 without the shim
 double refp_resident_key_create(void* h)
 {
@@ -647,6 +667,50 @@ int refp_resident_check_key(void* h)
     }
 }
 const char* refp_last_error(void* h) { return ((Session*)h)->error.c_str(); }
+
+// ---- the wrapped construct_proof() (libbbprover_wrap.so only): controls and counters of shim/bbg_prover_wrap.cpp, reached through
+// weak symbols so that this one object file serves the CPU build and the wrapped build alike
+int refp_wrap_linked(void) { return bbg_shim_resident_set_enabled ? 1 : 0; }
+void refp_wrap_set_enabled(int on)
+{
+    if (bbg_shim_resident_set_enabled) bbg_shim_resident_set_enabled(on);
+}
+namespace {
+struct WrapReplay {
+    std::vector<uint64_t> values;
+    size_t next = 0;
+    static void draw(void* user, uint64_t out[4])
+    {
+        auto* r = (WrapReplay*)user;
+        if (4 * r->next + 4 > r->values.size()) throw std::runtime_error("replay: the prover drew more blinding scalars than were recorded");
+        std::memcpy(out, r->values.data() + 4 * r->next++, 32);
+    }
+} g_wrap_replay;
+} // namespace
+// count x 4 limbs handed to the next proofs' blinding draws in order; count = 0 restores the kernel CSPRNG
+void refp_wrap_set_replay(const uint64_t* values, size_t count)
+{
+    if (!bbg_shim_resident_set_random) return;
+    g_wrap_replay.values.assign(values, values + 4 * count);
+    g_wrap_replay.next = 0;
+    bbg_shim_resident_set_random(count ? &WrapReplay::draw : nullptr, &g_wrap_replay);
+}
+void refp_wrap_set_budget(size_t bytes)
+{
+    if (bbg_shim_resident_set_budget) bbg_shim_resident_set_budget(bytes);
+}
+size_t refp_wrap_cached_keys(void) { return bbg_shim_resident_cached_keys ? bbg_shim_resident_cached_keys() : 0; }
+size_t refp_wrap_bytes(void) { return bbg_shim_resident_bytes ? bbg_shim_resident_bytes() : 0; }
+size_t refp_wrap_trim(void) { return bbg_shim_resident_trim ? bbg_shim_resident_trim() : 0; }
+void refp_wrap_clear(void)
+{
+    if (bbg_shim_resident_clear) bbg_shim_resident_clear();
+}
+void refp_wrap_stats(uint64_t out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    if (bbg_shim_resident_stats) bbg_shim_resident_stats(out);
+}
 
 // io::read_transcript_g1 (srs/io.cpp:134-162), the reference's own transcript reader: out = degree x 8 limbs
 int refio_read_transcript_g1(const char* dir, size_t degree, uint64_t* out)

@@ -98,3 +98,27 @@ def test_generated_mad_chains_are_in_sync():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.render() == open(mod.PATH).read()
+
+
+def test_bench_refuses_impossible_shapes_before_any_process_group():
+    """bench.py validates the shapes the sharded paths cannot take (G^2 | n for the residue-class NTT split, a power-of-two world <= 8,
+    WORLD_SIZE == --gpus) BEFORE any rendezvous: every rank leaves with status 2, rank 0 prints a JSON line with an `error` field -- no
+    GPU and no process group is touched, so the check runs here."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    cases = [
+        (["--gpus", "8", "--config5-log2n", "5"], {"WORLD_SIZE": "8", "RANK": "0"}, "G^2"),
+        (["--gpus", "3"], {"WORLD_SIZE": "3", "RANK": "0"}, "power-of-two"),
+        (["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0"}, "WORLD_SIZE"),
+        (["--gpus", "1", "--log2n", "27"], {"WORLD_SIZE": "1", "RANK": "0"}, "2^26"),
+    ]
+    for argv, envx, needle in cases:
+        r = subprocess.run([sys.executable, bench] + argv, env=dict(os.environ, **envx), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 2, (argv, r.stderr.decode()[-500:])
+        line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+        assert line["value"] is None and needle in line["error"], line
+    # a rank other than 0 leaves silently with the same status
+    r = subprocess.run([sys.executable, bench, "--gpus", "3"], env=dict(os.environ, WORLD_SIZE="3", RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and not r.stdout.decode().strip()

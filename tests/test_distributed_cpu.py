@@ -1,6 +1,10 @@
-"""world_size-2 gloo test of the multi-GPU decomposition (aztec-2.0_amd/parallel.py) on CPU: the point-range sharding,
-the all_gather of 96-byte partials and the final group sum reproduce the single-process MSM.  The per-rank "device
-MSM" is emulated with the oracle (this is a CPU test of the host logic; the GPU kernels are covered by -m gpu)."""
+"""gloo tests (world 2, 4 and 8) of the multi-GPU decomposition (aztec-2.0_amd/parallel.py) on CPU: the point-range sharding,
+the all_gather of 96-byte partials and the final group sum reproduce the single-process MSM; the residue-class NTT with its ONE
+all-to-all, the natural-order gather and the exchange-free 4n coset split reproduce the single-process transforms -- at exactly the
+shapes `bench.py --gpus N` runs (ShardedMsmPipeline at depth 4 with a side stream, >= 9 MSMs; ntt_sharded fft / ifft / coset;
+gather_natural_order; coset_fft_split_sharded).  The per-rank "device" operations are emulated with the oracle (this is a CPU test
+of the host logic and the index arithmetic; the GPU kernels are covered by -m gpu), the stream / event API by a recording stand-in
+whose log is checked against the ordering protocol."""
 import os
 import socket
 import subprocess
@@ -62,22 +66,92 @@ got.append(pipe.flush().numpy().view(np.uint64).copy())
 for b in range(3):
     assert np.array_equal(O.jac_to_affine(got[b]), O.pippenger(batches[b], pts)), ("pipeline", b)
 
-# the same pipeline exchanging two MSMs' partials per all-gather (depth 2), five MSMs: two full batches and a flushed remainder
-pipe2 = par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64), depth=2)
-batches5 = [pkg.synthetic_scalars(200 + b, n) for b in range(5)]
-seen = {}
-for b in range(5):
-    pipe2.submit(torch.from_numpy(batches5[b][start:start + count].view(np.int64).copy()), count)
-    for j in range(pipe2.finished):  # results stay valid until their ring slot is reused (2 * depth MSMs later)
-        if j not in seen and b - j < 4:
-            seen[j] = pipe2.results[j % 4].numpy().view(np.uint64).copy()
-last = pipe2.flush().numpy().view(np.uint64).copy()
-for j in range(pipe2.finished):
-    if j not in seen:
-        seen[j] = pipe2.results[j % 4].numpy().view(np.uint64).copy()
-assert pipe2.finished == 5 and np.array_equal(last, seen[4])
-for b in range(5):
-    assert np.array_equal(O.jac_to_affine(seen[b]), O.pippenger(batches5[b], pts)), ("pipeline depth 2", b)
+# depth 2 (two MSMs' partials per all-gather): three submits, flush (a partial batch), three more submits on the SAME pipeline without
+# reset(), flush -- the ring must not wrap inside a batch and no MSM may be dropped (round-3 advisor finding)
+def run_pipeline(pipe, seeds, flush_after=()):
+    batches = [pkg.synthetic_scalars(s, n) for s in seeds]
+    slots, snap = [], {}
+    def collect(upto):  # results stay valid until their ring slot is reused (2 * depth MSMs later): copy them as soon as they are issued
+        for j in range(upto):
+            if j not in snap:
+                snap[j] = pipe.results[slots[j]].numpy().view(np.uint64).copy()
+    for b, sc_b in enumerate(batches):
+        before = pipe.finished
+        slots.append(pipe.submit(torch.from_numpy(sc_b[start:start + count].view(np.int64).copy()), count))
+        if pipe.finished != before:  # a whole batch was finished behind this submit: everything but the MSM just issued
+            collect(b)
+        if b + 1 in flush_after:
+            last = pipe.flush()
+            collect(b + 1)
+            assert np.array_equal(last.numpy().view(np.uint64), snap[b])
+    last = pipe.flush()
+    collect(len(batches))
+    assert np.array_equal(last.numpy().view(np.uint64), snap[len(batches) - 1])
+    for b, sc_b in enumerate(batches):
+        assert np.array_equal(O.jac_to_affine(snap[b]), O.pippenger(sc_b, pts)), ("pipeline", pipe.depth, b)
+    assert pipe.submitted == len(batches)
+run_pipeline(par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64), depth=2), range(200, 206), flush_after=(3,))
+run_pipeline(par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64), depth=2), range(210, 215))
+
+# depth 4 WITH a side stream -- the configuration of bench.py --gpus N -- and ten MSMs (two full batches + a remainder of two), then a
+# second timed block on the same pipeline after reset().  torch.cuda is replaced by a recording stand-in: operations execute at once (CPU),
+# the log is checked against the protocol the streams must follow.
+class Log(list):
+    pass
+LOG = Log()
+class FakeStream:
+    def __init__(self, name): self.name = name
+    def wait_event(self, ev): LOG.append(("wait_event", self.name, ev.name, ev.recorded_on))
+    def wait_stream(self, other): LOG.append(("wait_stream", self.name, other.name))
+class FakeEvent:
+    count = 0
+    def __init__(self):
+        self.name = "ev%d" % FakeEvent.count; FakeEvent.count += 1; self.recorded_on = None
+    def record(self, stream): self.recorded_on = stream.name; LOG.append(("record", stream.name, self.name))
+class FakeCuda:
+    Event = FakeEvent
+    def __init__(self): self.main = FakeStream("main"); self.cur = self.main
+    def current_stream(self): return self.cur
+    def stream(self, s):
+        outer = self
+        class Ctx:
+            def __enter__(self_): self_.prev = outer.cur; outer.cur = s
+            def __exit__(self_, *a): outer.cur = self_.prev
+        return Ctx()
+fake = FakeCuda()
+class CpuOpsSide(CpuOps):
+    bbg_side = object()
+    def msm(self, scal, cnt, out):
+        LOG.append(("msm", fake.cur.name)); CpuOps.msm(self, scal, cnt, out)
+    def join(self, lag): LOG.append(("join", fake.cur.name, lag))
+    def g1_sum(self, gathered, cnt, out):
+        LOG.append(("g1_sum", fake.cur.name)); CpuOps.g1_sum(self, gathered, cnt, out)
+side = FakeStream("side")
+pipe4 = par.ShardedMsmPipeline(CpuOpsSide(), dist, lambda k: torch.zeros(k, dtype=torch.int64), side_stream=side, depth=4, cuda=fake)
+run_pipeline(pipe4, range(300, 310))
+assert pipe4.count == pipe4.finished == 12  # the flushed remainder ended its batch
+# protocol: every local MSM is issued on the main stream, every group sum on the side stream, each exchange waits (on the side stream) for an
+# event recorded on the main stream after a join, and the main stream ends by waiting for the side stream
+assert all(e[1] == "main" for e in LOG if e[0] == "msm") and sum(e[0] == "msm" for e in LOG) == 10
+assert all(e[1] == "side" for e in LOG if e[0] == "g1_sum") and sum(e[0] == "g1_sum" for e in LOG) == 10
+assert LOG[-1] == ("wait_stream", "main", "side")
+for i, e in enumerate(LOG):
+    if e[0] == "g1_sum":  # the nearest preceding wait on the side stream is for an event recorded on main
+        waits = [w for w in LOG[:i] if w[0] == "wait_event" and w[1] == "side"]
+        assert waits and waits[-1][3] == "main", ("side stream ran ahead of the local MSMs", i)
+# half h of the ring is overwritten by MSMs 8, 9 (h = 0): the main stream waited for the side stream's ev_done of that half first
+idx_msm = [i for i, e in enumerate(LOG) if e[0] == "msm"]
+assert any(w[0] == "wait_event" and w[1] == "main" and w[3] == "side" for w in LOG[idx_msm[7]:idx_msm[8]]), "ring half reused without waiting for its exchange"
+del LOG[:]
+pipe4.reset()
+run_pipeline(pipe4, range(320, 329))  # nine: two full batches + one
+try:
+    par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64), side_stream=side, depth=4, cuda=fake)
+    CpuOps.bbg_side = None
+    par.ShardedMsmPipeline(CpuOps(), dist, lambda k: torch.zeros(k, dtype=torch.int64), side_stream=side, depth=4, cuda=fake)
+    raise AssertionError("a side stream without a side context must be refused")
+except ValueError:
+    pass
 
 # NTT sharded by residue class with one all-to-all: device ops emulated with the oracle
 class CpuNttOps:
@@ -140,6 +214,8 @@ else:
     assert nat is None
 # the prover's 4n coset FFT with n non-zero coefficients: ext independent size-n coset FFTs, no arithmetic exchange (8e row 3)
 for lg6, ext in ((6, 4), (5, 8), (6, 2)):
+    if ext % world:
+        continue  # the cosets are dealt out whole: ext must be a multiple of the world size (world 8: ext = 8 only)
     c6 = O.canon(0, pkg.synthetic_scalars(778 + ext, 1 << lg6))
     xt = torch.from_numpy(c6.copy().view(np.int64).reshape(-1))
     res = par.coset_fft_split_sharded(CpuNttOps(), dist, xt, lg6, ext)
@@ -159,22 +235,41 @@ def _free_port():
     return p
 
 
-def test_sharded_msm_gloo_world2(tmp_path):
+def _run_world(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BBG_ROOT=ROOT,
-                   OMP_NUM_THREADS="2")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BBG_ROOT=ROOT,
+                   OMP_NUM_THREADS="1" if world > 2 else "2")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
-    for p in procs:
-        out, _ = p.communicate(timeout=300)
-        outs.append(out.decode())
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=600)
+            outs.append(out.decode())
+    finally:
+        for p in procs:  # the exact processes started above, never a pattern
+            if p.poll() is None:
+                p.kill()
     for rank, p in enumerate(procs):
         assert p.returncode == 0, outs[rank]
         assert f"rank {rank} ok" in outs[rank]
+
+
+def test_sharded_msm_gloo_world2(tmp_path):
+    _run_world(tmp_path, 2)
+
+
+def test_sharded_paths_gloo_world4(tmp_path):
+    """The shapes of `bench.py --gpus 4` (reference precedent for the split: c_bind.cpp:31-46, work_queue.hpp:166-199)."""
+    _run_world(tmp_path, 4)
+
+
+def test_sharded_paths_gloo_world8(tmp_path):
+    """The shapes of `bench.py --gpus 8`: G = 8 residue classes (G^2 | n), eight cosets dealt out one per rank, depth-4 pipeline."""
+    _run_world(tmp_path, 8)
 
 
 def test_shard_range_partitions():

@@ -510,6 +510,128 @@ def test_msm_limbs29_equals_limbs32_2_16(pkg, oracle, bbg, srs16):
         eq.free()
 
 
+def _affine_or_inf(oracle, jac):
+    return None if int(jac[3]) >> 63 else oracle.jac_to_affine(jac)
+
+
+def test_msm_batch_vs_oracle(pkg, oracle, bbg, srs16):
+    """bbg_msm_batch: the independent commitments of a prover round (prover.cpp:66-74, :120-135; work_queue.hpp:208-282) through ONE sort /
+    accumulate / reduce launch set, MSM k under bucket set k.  Every result against the oracle on its own inputs: batches of 1 .. 8, ragged
+    lengths (StandardPLONK's n + 1 beside n; an empty MSM; a 1-term MSM), `from` offsets, zero / mixed / all-equal scalars in some sets, at
+    every window width and through all three accumulation kernels (four-lane small-MSM kernel, 29-bit limbs, 32-bit limbs)."""
+    pts = srs16.read(0, 6000)
+    one = oracle.to_mont(0, np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    def scal(seed, n):
+        return pkg.synthetic_scalars(seed, n)
+    batches = [
+        [(scal(11, 1024), 0)],
+        [(scal(12, 1024), 0), (scal(13, 1025), 0)],
+        [(scal(14, 1000), 0), (scal(15, 1000), 17), (scal(16, 1000), 300)],
+        [(scal(17, 4096), 0), (scal(18, 4096), 0), (scal(19, 4097), 0), (scal(20, 4096), 0)],  # round 4 of StandardPLONK: n, n, n + 1 (+ one more)
+        [(scal(21, 777), 5), (np.zeros((0, 4), dtype=np.uint64), 0), (scal(22, 1), 4999), (np.zeros((333, 4), dtype=np.uint64), 0),
+         (pkg.inputs.mixed_scalars(23, 2000, lambda p: oracle.to_mont(0, p)), 1), (np.tile(scal(24, 1), (1500, 1)), 0), (np.tile(one, (900, 1)), 100),
+         (scal(25, 5000), 1000)],
+    ]
+    try:
+        for window in MSM_WINDOWS:
+            bbg.set_option("msm_window", window)
+            for quad_acc, limbs29 in ((1, 1), (0, 1), (0, 0)):
+                bbg.set_option("msm_accumulate_quad", quad_acc)
+                bbg.set_option("msm_limbs29", limbs29)
+                for batch in batches:
+                    if window != 16 and quad_acc == 1 and len(batch) == 3:
+                        continue  # keep the matrix affordable: the three-way batch runs at every width through the two one-lane kernels
+                    got = bbg.msm_batch(srs16, [b[0] for b in batch], [b[1] for b in batch])
+                    for k, (sc, start) in enumerate(batch):
+                        want = oracle.pippenger(sc, pts[start:start + sc.shape[0]]) if sc.shape[0] else None
+                        g = _affine_or_inf(oracle, got[k])
+                        if want is None or int(want[3]) >> 63:
+                            assert g is None, (window, quad_acc, limbs29, len(batch), k)
+                        else:
+                            assert g is not None and np.array_equal(g, want), (window, quad_acc, limbs29, len(batch), k)
+    finally:
+        bbg.set_option("msm_window", 0)
+        bbg.set_option("msm_accumulate_quad", 1)
+        bbg.set_option("msm_limbs29", 1)
+
+
+def test_msm_batch_golden_and_single_msm_agree_2_16(pkg, oracle, bbg, golden, srs16):
+    """At 2^16 (the one-lane 29-bit-limb accumulation, 1024-thread second sort level): a batch of four whose first member is the reference's
+    golden 2^16 MSM, with a ragged member (2^16 - 1 terms) and a mixed-scalar member.  Every member equals the same MSM issued alone; the
+    golden member equals the compiled reference's result.  With the reduce phase on the auxiliary stream and shapes changing between
+    calls (batch of 4 -> single -> batch of 2 -> batch of 4)."""
+    n = 1 << 16
+    rec = next(r for r in golden["msm"] if r["srs"] == "hashed" and r["n"] == n and r["from"] == 0 and r.get("scalar_kind") != "mixed")
+    members = [pkg.synthetic_scalars(rec["scalar_seed"], n), pkg.synthetic_scalars(501, n), pkg.synthetic_scalars(502, n - 1),
+               pkg.inputs.mixed_scalars(503, n, lambda p: oracle.to_mont(0, p))]
+    alone = [oracle.jac_to_affine(bbg.msm(srs16, m)) for m in members]
+    assert np.array_equal(alone[0], unhex(rec["result"], 8)[0])
+    try:
+        bbg.set_option("msm_async_reduce", 1)
+        a = bbg.msm_batch(srs16, members)
+        b = bbg.msm(srs16, members[1])
+        c = bbg.msm_batch(srs16, members[2:])
+        d = bbg.msm_batch(srs16, list(reversed(members)))
+        for k in range(4):
+            assert np.array_equal(oracle.jac_to_affine(a[k]), alone[k]), k
+            assert np.array_equal(oracle.jac_to_affine(d[3 - k]), alone[k]), k
+        assert np.array_equal(oracle.jac_to_affine(b), alone[1])
+        assert np.array_equal(oracle.jac_to_affine(c[0]), alone[2]) and np.array_equal(oracle.jac_to_affine(c[1]), alone[3])
+    finally:
+        bbg.set_option("msm_async_reduce", 0)
+
+
+def test_msm_batch_degenerate_runs_per_set(pkg, oracle, bbg, srs16):
+    """The 29-bit-limb accumulation's redo queue (runs that met P = +-acc) with several bucket sets: one set made of all-equal points, one of
+    P / -P pairs, one ordinary -- the queued buckets carry GLOBAL numbers (set x 2^(C-1) + bucket) and must be recomputed in the right set."""
+    n = 2048
+    base = srs16.read(0, n)
+    zero4 = np.zeros((1, 4), dtype=np.uint64)
+    pts = base.copy()
+    pts[:512] = base[0]                                   # points 0 .. 511 all equal
+    pm = np.repeat(base[600:856], 2, axis=0)              # points 512 .. 1023: P, -P, P', -P', ...
+    pm[1::2, 4:] = oracle.fe_sub(1, np.tile(zero4, (256, 1)), pm[1::2, 4:])
+    pts[512:1024] = pm
+    srs = bbg.srs_register(pts)
+    sc_eq = pkg.synthetic_scalars(611, 512)
+    sc_pm = np.repeat(pkg.synthetic_scalars(612, 256), 2, axis=0)
+    sc_ok = pkg.synthetic_scalars(613, 1024)
+    batch = [(sc_ok, 1024), (sc_eq, 0), (sc_pm, 512), (sc_eq[:300], 100)]
+    want = [oracle.msm_naive(sc, pts[st:st + sc.shape[0]]) for sc, st in batch]
+    try:
+        bbg.set_option("msm_accumulate_quad", 0)
+        for window in MSM_WINDOWS:
+            bbg.set_option("msm_window", window)
+            for overlap in (0, 1):
+                bbg.set_option("msm_async_reduce", overlap)
+                got = bbg.msm_batch(srs, [b[0] for b in batch], [b[1] for b in batch])
+                for k in range(len(batch)):
+                    g = _affine_or_inf(oracle, got[k])
+                    if int(want[k][3]) >> 63:
+                        assert g is None, (window, overlap, k)
+                    else:
+                        assert g is not None and np.array_equal(g, want[k]), (window, overlap, k)
+    finally:
+        bbg.set_option("msm_accumulate_quad", 1)
+        bbg.set_option("msm_async_reduce", 0)
+        bbg.set_option("msm_window", 0)
+        srs.free()
+
+
+def test_msm_batch_error_paths_and_plan(pkg, bbg, srs16):
+    sc = pkg.synthetic_scalars(1, 16)
+    with pytest.raises(pkg.BbgError):
+        bbg.msm_batch(srs16, [sc] * 9)                      # more than BBG_MSM_BATCH_MAX
+    with pytest.raises(pkg.BbgError):
+        bbg.msm_batch(srs16, [sc, sc], [0, (1 << 16) - 3])  # second range leaves the SRS
+    # bbg_msm_plan: the automatic rule (msm.hip msm_auto_window), the forced width, the resident-table rule for short MSMs over long SRSs
+    assert bbg.msm_plan(1 << 12) == (16, 16) and bbg.msm_plan(1 << 20) == (19, 14) and bbg.msm_plan(1 << 21) == (20, 13) and bbg.msm_plan(1 << 24) == (22, 12)
+    bbg.set_option("msm_window", 17)
+    assert bbg.msm_plan(1 << 20) == (17, 15)
+    bbg.set_option("msm_window", 0)
+    assert bbg.msm_plan(1 << 10, srs16)[0] in MSM_WINDOWS
+
+
 @pytest.mark.parametrize("window", [17, 19, 20, 22])
 def test_msm_wide_windows_vs_oracle(pkg, oracle, bbg, golden, srs16, window):
     """Every wider window configuration (chosen automatically only for large n) forced at small sizes: oracle parity, `from` offsets,
@@ -939,7 +1061,8 @@ def test_bench_contract_and_dist_path():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BBG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env = dict(os.environ, BBG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("MASTER_PORT", None)  # bench.py picks a free port for its world of one: two suites on one box cannot collide
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "16", "--config5-log2n", "18"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -1220,6 +1343,95 @@ def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     P.free()
 
 
+@pytest.mark.parametrize("flavour,log2_gates", [(0, 9), (1, 9), (2, 9), (3, 9), (4, 9), (0, 13), (1, 13), (2, 13), (3, 13), (4, 13)])
+def test_wrapped_construct_proof_reproduces_the_reference_proof(pkg, oracle, bbg, flavour, log2_gates):
+    """ZERO source edits (INTEGRATION.md 2a'): oracle/_ref/libbbprover_wrap.so is the CPU build's own driver object -- no glue call, a plain
+    `prover->construct_proof()` -- linked with shim/bbg_barretenberg_shim.cpp + shim/bbg_prover_wrap.cpp and both --wrap flag files.  The call
+    reaches the resident prover through the wrapped symbol of ProverBase<settings>::construct_proof (prover.cpp:420-436, :445-448) for all five
+    prover types the reference's composers build; on the blinding scalars a reference CPU proof drew, the proof bytes are IDENTICAL to the CPU
+    prover's and the reference verifier accepts.  Opting out (bbg_shim_resident_set_enabled(0) / BBG_SHIM_RESIDENT=0) gives the reference body
+    back (MSM / FFT entry points still on the GPU)."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << log2_gates) + 2)
+    A = RefProver(1 << log2_gates, 21 + flavour, pts, x, flavour=flavour)
+    proof_cpu, blind = A.prove_recording()
+    assert A.verify() == 1
+    B = RefProver(1 << log2_gates, 21 + flavour, pts, x, wrap_linked=True, flavour=flavour)
+    before = B.wrap_stats()
+    proof = B.prove_reference(replay=blind)
+    after = B.wrap_stats()
+    assert after[0] == before[0] + 1 and after[1] == before[1], "construct_proof() did not take the resident path"
+    assert B.verify() == 1
+    assert proof == proof_cpu, f"wrapped construct_proof(): proof differs from the reference CPU proof (flavour {flavour}, n = {A.n})"
+    # the same prover object again (ProverBase::reset), fresh randomness from the kernel CSPRNG: another valid proof, same cached key
+    keys = B.wrap_cached_keys()
+    again = B.prove_reference(reset=True)
+    assert B.verify() == 1 and again != proof and B.wrap_cached_keys() == keys
+    # opt out: the reference's own body (its MSMs / FFTs through the wrapped entry points)
+    C = RefProver(1 << log2_gates, 21 + flavour, pts, x, wrap_linked=True, flavour=flavour)
+    try:
+        C.wrap_set_enabled(False)
+        stats = C.wrap_stats()
+        link_only = C.prove_reference()
+        assert C.verify() == 1 and C.wrap_stats() == stats and len(link_only) == len(proof)
+    finally:
+        C.wrap_set_enabled(True)
+    for P in (A, B, C):
+        P.free()
+    assert B.wrap_trim() <= keys - 1  # the sessions are gone: their keys' device copies were released
+
+
+def test_wrapped_construct_proof_key_cache(pkg, oracle, bbg):
+    """The key cache of shim/bbg_prover_wrap.cpp: two proving keys alive at once (two provers proving alternately), an entry released when
+    its key's last outside owner is gone, least-recently-used eviction under a byte budget -- never of the key being proved with --, and a
+    re-upload after an eviction giving the same proof bytes."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << 11) + 2)
+    P1 = RefProver(1 << 11, 91, pts, x, wrap_linked=True, flavour=0)
+    P2 = RefProver(1 << 10, 92, pts, x, wrap_linked=True, flavour=1)
+    P1.wrap_clear()
+    assert P1.wrap_cached_keys() == 0 and P1.wrap_bytes() == 0
+    blind = pkg.synthetic_scalars(4711, 15)
+    try:
+        a1 = P1.prove_reference(replay=blind)
+        assert P1.wrap_cached_keys() == 1 and P1.verify() == 1
+        one_key = P1.wrap_bytes()
+        assert one_key > 21 * 4 * (1 << 11) * 32  # at least the 4n coset forms of the key's polynomials
+        b1 = P2.prove_reference(replay=blind[:12])
+        assert P2.wrap_cached_keys() == 2 and P2.verify() == 1 and P2.wrap_bytes() > one_key
+        a2 = P1.prove_reference(replay=blind, reset=True)  # alternating between the two keys: no re-upload, same bytes
+        b2 = P2.prove_reference(replay=blind[:12], reset=True)
+        assert a2 == a1 and b2 == b1 and P1.wrap_cached_keys() == 2
+        ev0 = P1.wrap_stats()[2]
+        P1.wrap_set_budget(one_key)  # room for ONE Turbo key: applied at once, the least recently used entry (P1's: P2 proved last) goes
+        assert P1.wrap_cached_keys() == 1 and P1.wrap_stats()[2] == ev0 + 1
+        a3 = P1.prove_reference(replay=blind, reset=True)  # re-uploaded after its eviction: same proof bytes; now P2's key has to go
+        assert a3 == a1 and P1.wrap_cached_keys() == 1 and P1.wrap_stats()[2] == ev0 + 2
+        P1.wrap_set_budget(1)  # below any key: the key in use survives its own proof, everything else goes
+        b3 = P2.prove_reference(replay=blind[:12], reset=True)
+        assert b3 == b1 and P2.wrap_cached_keys() == 1 and P2.wrap_stats()[1] == 0
+        P1.wrap_set_budget(0)  # 0 = the default budget again (half of the device) from the next proof on
+        a4 = P1.prove_reference(replay=blind, reset=True)
+        assert a4 == a1 and P1.wrap_cached_keys() == 2
+        P2.free()
+        P2 = None
+        assert P1.wrap_trim() == 1  # key destroyed -> entry released
+        P1.free()
+        P1 = None
+        ref = RefProver(1 << 9, 93, pts, x, wrap_linked=True, flavour=0)
+        assert ref.wrap_trim() == 0
+        ref.free()
+    finally:
+        for P in (P1, P2):
+            if P is not None:
+                P.wrap_set_budget(0)
+                P.free()
+
+
 def test_turbo_prover_2_20_gates_on_gpu(pkg, oracle, bbg):
     """BASELINE config 4 at its stated size, under the driver-run suite: a 2^20-gate TurboPLONK circuit.
       (a) every MSM / coset-FFT / iFFT work item of the reference prover computed by this library and compared with the reference
@@ -1262,8 +1474,30 @@ def test_turbo_prover_2_20_gates_on_gpu(pkg, oracle, bbg):
     t_shim = time.perf_counter() - t0
     assert len(proof_shim) == 1248 and C.verify() == 1
     C.free()
-    print(f"\n2^20-gate TurboPLONK proof: reference CPU {t_cpu*1e3:.0f} ms ({A.threads} threads), shim-linked {t_shim*1e3:.0f} ms, "
-          f"resident C++ prover {t_gpu*1e3:.1f} ms first / {t_warm*1e3:.1f} ms warm (key registration {t_key*1e3:.0f} ms, once per circuit)")
+    # (d) zero source edits: the CPU build's driver object with construct_proof() itself wrapped -- byte-identical, and fast
+    from oracle.oracle import PROVER_WRAP_SO
+    t_wrap_first = t_wrap = float("nan")
+    if os.path.exists(PROVER_WRAP_SO):
+        D = RefProver(gates, 11, pts, x, wrap_linked=True)
+        t0 = time.perf_counter()
+        proof_wrap = D.prove_reference(replay=blind)  # includes the one-off key upload + derivation of this circuit
+        t_wrap_first = time.perf_counter() - t0
+        assert D.verify() == 1
+        assert proof_wrap == proof_cpu, "2^20 gates: the wrapped construct_proof() differs from the reference CPU proof"
+        ts = []
+        for _ in range(3):
+            D.lib.refp_reset(D.h)
+            t0 = time.perf_counter()
+            D.prove_reference()
+            ts.append(time.perf_counter() - t0)
+        t_wrap = min(ts)
+        assert D.verify() == 1
+        assert t_wrap < 0.060, f"wrapped construct_proof() at 2^20 gates took {t_wrap*1e3:.1f} ms (resident path not taken?)"
+        D.free()
+        D.wrap_trim()
+    print(f"\n2^20-gate TurboPLONK proof: reference CPU {t_cpu*1e3:.0f} ms ({A.threads} threads), shim-linked (MSM / FFT wrapped only) {t_shim*1e3:.0f} ms, "
+          f"resident C++ prover {t_gpu*1e3:.1f} ms first / {t_warm*1e3:.1f} ms warm (key registration {t_key*1e3:.0f} ms, once per circuit); "
+          f"construct_proof() wrapped, zero source edits: {t_wrap_first*1e3:.0f} ms first (key upload included) / {t_wrap*1e3:.1f} ms warm")
 
 
 def test_prover_handle_error_paths(pkg, bbg):
