@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libbbg.so")
+LIB_PATH = os.environ.get("BBG_LIB_PATH") or os.path.join(CSRC, "libbbg.so")  # BBG_LIB_PATH: A/B builds of the same ABI (tests/tools), never a fallback
 
 # op codes of bbg_ntt (include/bbg.h)
 FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3

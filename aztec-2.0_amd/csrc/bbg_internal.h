@@ -123,6 +123,8 @@ struct bbg_ctx {
     int ntt_kernel = 2;      // 2 = k_ntt_pass8 where applicable (n >= 2^11), 1 = k_ntt_pass only
     int ntt_max_logr8 = 10;  // max log-radix per pass for k_ntt_pass8
     int ntt_big_tile = 1;    // option "ntt_big_tile": 1 = 2^21 as TWO passes over 4096-element tiles instead of three over 2048; 2 = 2^22 as well; 0 = never
+    int ntt_lds_planes = 0;  // option "ntt_lds_planes": 2 = the tile stays in LDS between two steps (k_ntt_pass8), 1 = it moves one 16-byte plane at a time (k_ntt_pass8s: half the LDS, three blocks per CU), 0 = automatic (1 from 2^22)
+    bool ntt_attr8s_set = false;
     bool ntt_attr8_set = false, ntt_attr_set = false; // dynamic-LDS attributes of the pass kernels set on this context's device
 };
 

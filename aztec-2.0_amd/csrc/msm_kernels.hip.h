@@ -1063,16 +1063,22 @@ template <int C, int QL> __global__ void __launch_bounds__(4 * QL) k_rowcol_q(co
     cols += (size_t)blockIdx.y * COLS;
     // serial phase: every THREAD sums its own share with one-lane additions (a quad-cooperative addition costs 1.55x the instructions of a
     // one-lane one -- it buys latency, and there is none to buy while all four lanes have items of their own); then the four partial sums of
-    // a quad are added with four-lane operations, then the tree over the QL quads
+    // a quad are added with four-lane operations, then the tree over the QL quads.  A thread's FIRST item is loaded, not added to an
+    // infinity (r4): with 4 QL = 256 threads a row of 2^8 .. 2^9 buckets gives a thread one or two items, so starting from infinity was
+    // half of the serial additions (C = 19: 262 144 -> 65 536 one-lane additions per launch) and 40 % of a small MSM's row / column kernel.
+    constexpr int T = 4 * QL;
     Xyzz s = xyzz_inf();
     if (blockIdx.x < ROWS) {
         const int hi = blockIdx.x;
-        for (int lo = threadIdx.x; lo < COLS; lo += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
+        const Xyzz* src = buckets + (size_t)hi * COLS;
+        if ((int)threadIdx.x < COLS) s = xyzz_load(src + threadIdx.x);
+        for (int lo = T; lo < COLS; lo += T) s = xyzz_add(s, xyzz_load(src + lo + threadIdx.x)); // COLS is a multiple of T beyond the first item
         Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
         if (threadIdx.x == 0) xyzz_store(rows + hi, v);
     } else {
         const int lo = blockIdx.x - ROWS;
-        for (int hi = threadIdx.x; hi < ROWS; hi += 4 * QL) s = xyzz_add(s, xyzz_load(buckets + (size_t)hi * COLS + lo));
+        if ((int)threadIdx.x < ROWS) s = xyzz_load(buckets + (size_t)threadIdx.x * COLS + lo);
+        for (int hi = T; hi < ROWS; hi += T) s = xyzz_add(s, xyzz_load(buckets + (size_t)(hi + threadIdx.x) * COLS + lo));
         Xyzz v = block_reduce_q4(quad_sum4(s, q), sm, QL);
         if (threadIdx.x == 0) xyzz_store(cols + lo, v);
     }

@@ -530,6 +530,35 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
             attr8 = true;
         }
         ProfScope ps(ctx, "ntt_pass", st);
+        // one-plane exchange (ntt_pass8.hip.h: k_ntt_pass8s: half the LDS, three waves per SIMD): automatic from 2^22 (measured there)
+        if (ctx->ntt_lds_planes == 1 || (ctx->ntt_lds_planes == 0 && d.log2n >= 22)) {
+            bool& attr8s = ctx->ntt_attr8s_set;
+            if (!attr8s) {
+                BBG_HIP(p8s_attr<3>()); BBG_HIP(p8s_attr<4>()); BBG_HIP(p8s_attr<5>()); BBG_HIP(p8s_attr<6>()); BBG_HIP(p8s_attr<7>());
+                BBG_HIP(p8s_attr<8>()); BBG_HIP(p8s_attr<9>()); BBG_HIP(p8s_attr<10>()); BBG_HIP(p8s_attr<11>());
+                BBG_HIP((p8s_attr<10, P8_TILE_LOG_BIG>())); BBG_HIP((p8s_attr<11, P8_TILE_LOG_BIG>()));
+                attr8s = true;
+            }
+            if (d.tile_log8 == P8_TILE_LOG_BIG) {
+                if (p.logR == 11) p8s_launch<11, P8_TILE_LOG_BIG>(p, tiles, st);
+                else if (p.logR == 10) p8s_launch<10, P8_TILE_LOG_BIG>(p, tiles, st);
+                else { set_error("ntt: bad pass8 radix for the 4096-element tile"); return BBG_E_INVALID; }
+                return BBG_OK;
+            }
+            switch (p.logR) {
+            case 3: p8s_launch<3>(p, tiles, st); break;
+            case 4: p8s_launch<4>(p, tiles, st); break;
+            case 5: p8s_launch<5>(p, tiles, st); break;
+            case 6: p8s_launch<6>(p, tiles, st); break;
+            case 7: p8s_launch<7>(p, tiles, st); break;
+            case 8: p8s_launch<8>(p, tiles, st); break;
+            case 9: p8s_launch<9>(p, tiles, st); break;
+            case 10: p8s_launch<10>(p, tiles, st); break;
+            case 11: p8s_launch<11>(p, tiles, st); break;
+            default: set_error("ntt: bad pass8 radix"); return BBG_E_INVALID;
+            }
+            return BBG_OK;
+        }
         if (d.tile_log8 == P8_TILE_LOG_BIG) {
             if (p.logR == 11) p8_launch<11, P8_TILE_LOG_BIG>(p, tiles, st);
             else if (p.logR == 10) p8_launch<10, P8_TILE_LOG_BIG>(p, tiles, st);

@@ -256,6 +256,247 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
     }
 }
 
+// ------------------------------------------------------------------------------------ one-plane exchange (r4)
+// k_ntt_pass8 keeps the whole tile in LDS between two steps: two 16-byte planes, 73 728 B per 256-thread block -> two blocks per CU, two
+// waves per SIMD, although its 104-116 VGPRs would allow four (profiles/r03_kernel_stats_v4.txt).  k_ntt_pass8s moves the tile between two
+// steps ONE PLANE AT A TIME through a single plane-sized buffer (36 864 B -> four blocks per CU): low halves out, barrier, low halves of the
+// next step's elements in, barrier, high halves out, barrier, high halves in.  No more registers than before (a thread holds the high
+// halves of its old elements beside the low halves of its new ones: 8 x 8 words, what x[8] takes anyway); three barriers per exchange
+// instead of one, covered by the other blocks of the CU.  Same arithmetic, same positions, same outputs -- bit-identical by construction,
+// and checked against the reference digests at every size (tests/test_gpu_parity.py).
+template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p8s_coords(int tid, int& c, int& pbase, int& qlo)
+{
+    constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    constexpr int LOGW = TL - LOGR, W = 1 << LOGW;
+    constexpr int QBITS = LOGR - 3;
+    int q;
+    if (ROW && T == 0) { // lanes run along the row (k) so that the global loads coalesce
+        q = tid & ((1 << QBITS) - 1);
+        c = tid >> QBITS;
+    } else {
+        c = tid & (W - 1);
+        q = tid >> LOGW;
+    }
+    qlo = q & ((1 << F) - 1);
+    pbase = ((q >> F) << (F + 3)) | qlo; // field bits zero
+}
+// butterfly on the top S bits of step T's field + the step twiddles (the arithmetic of p8_step, nothing else)
+template <int LOGR, int T> __device__ __forceinline__ void p8s_compute(Fr (&x)[8], const Fr* __restrict__ tw, int qlo)
+{
+    constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
+    constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    Fr w1, w2, w3;
+    if constexpr (S == 3) {
+        w1 = fe_load<FrP>(tw + (1 << (LOGR - 3)));
+        w3 = fe_load<FrP>(tw + (3 << (LOGR - 3)));
+    }
+    if constexpr (S >= 2) w2 = fe_load<FrP>(tw + (1 << (LOGR - 2)));
+    else w2 = Fr::zero();
+    if constexpr (S != 3) {
+        w1 = Fr::zero();
+        w3 = Fr::zero();
+    }
+    p8_butterfly<S>(x, w1, w2, w3);
+    if constexpr (S == 3 && F > 0) {
+        constexpr int DONE = LOGR - 3 - F;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            const int e = (p8_brev3(j) * qlo) << DONE;
+            x[j] = fe_mul(x[j], fe_load<FrP>(tw + e));
+        }
+    }
+}
+// x: the 8 elements of step T (in place) -> the 8 elements of step T + 1, one plane at a time through `buf`
+template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p8s_exchange(Fr (&x)[8], uint4* buf)
+{
+    constexpr int LOGW = TL - LOGR;
+    constexpr int F0 = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    constexpr int F1 = (LOGR - 3 * (T + 1) >= 3) ? (LOGR - 3 * (T + 2)) : 0;
+    int c0, pb0, ql0, c1, pb1, ql1;
+    p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
+    p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+    if (T > 0) __syncthreads(); // everybody has taken the high halves of the previous exchange out of the buffer
+#pragma unroll
+    for (int j = 0; j < 8; j++) buf[p8_addr(pb0 | (j << F0), c0, LOGW)] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
+    __syncthreads();
+    uint4 lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) lo[j] = buf[p8_addr(pb1 | (j << F1), c1, LOGW)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) buf[p8_addr(pb0 | (j << F0), c0, LOGW)] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint4 h = buf[p8_addr(pb1 | (j << F1), c1, LOGW)];
+        x[j].v[0] = lo[j].x; x[j].v[1] = lo[j].y; x[j].v[2] = lo[j].z; x[j].v[3] = lo[j].w;
+        x[j].v[4] = h.x; x[j].v[5] = h.y; x[j].v[6] = h.z; x[j].v[7] = h.w;
+    }
+}
+
+// The exchange in front of a LAST step that transforms ONE bit (log-radix = 1 mod 3: 2^10, 2^7): the thread holds the elements whose
+// in-tile position p differs in bits [3:1] and needs those that differ in bits [2:0] -- a swap of p's bit 3 (a register-index bit) with
+// p's bit 0 (a thread-index bit), i.e. half of the registers change places with ONE partner lane (tid ^ W).  Done with lane shuffles: no
+// LDS buffer, no barrier -- an exchange less per 2^10 pass (three barriers and a tile's round trip through LDS).
+template <int LOGR, int TL> __device__ __forceinline__ void p8s_exchange_last1(Fr (&x)[8])
+{
+    constexpr int LOGW = TL - LOGR;
+    const uint32_t ql = (threadIdx.x >> LOGW) & 1u; // p's bit 0 of what this thread holds; p's bit 3 of what it is going to hold
+    Fr y[8];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { // m = (b2 b1) of the new position's low bits
+        const int b1 = m & 1, b2 = m >> 1;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            // to the partner: my register with j2 = 1 - ql (the partner's ql), low bits m; from it: its register with j2 = my ql, low bits m
+            const uint32_t send = ql ? x[m].v[w] : x[4 + m].v[w];
+            const uint32_t recv = (uint32_t)__shfl_xor((int)send, 1 << LOGW);
+            const uint32_t own = ql ? x[4 + m].v[w] : x[m].v[w]; // my register with j2 = ql, low bits m
+            // new register j' = (b2 b1 b0): b0 = ql -> own, b0 = 1 - ql -> received
+            y[(b2 << 2) | (b1 << 1) | 0].v[w] = ql ? recv : own;
+            y[(b2 << 2) | (b1 << 1) | 1].v[w] = ql ? own : recv;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = y[j];
+}
+
+template <int TL> constexpr size_t p8s_lds_bytes() { return (size_t)p8_plane<TL>() * 16; }
+
+// BBG_NTT_OCC = minimum waves per SIMD the compiler must fit the kernel into (3 -> <= 168 VGPRs, 4 -> <= 128); BBG_NTT_LATE_OUTMUL = 1
+// fetches the outputs' multipliers in front of the LAST step instead of behind the first loads (their 64 registers are then free for most
+// of the kernel -- what makes 168 fit without spills).  Measured, isolated, fft (profiles/r04_ntt_planes_ab.txt; two-plane kernel = 1.00):
+//   OCC 2, early: 2^20 1.05, 2^22 1.00, 2^24 1.00      OCC 3, early: 2^20 1.17, 2^22 1.03, 2^24 1.00
+//   OCC 2, late : 2^20 1.02, 2^22 0.99, 2^24 0.99      OCC 3, late : 2^20 1.04, 2^22 0.94, 2^24 0.96   <- the defaults
+//   OCC 4 (128 VGPRs, spills): 1.13 - 1.23 at 2^20.
+// So the one-plane kernel is the automatic choice from 2^22 (radix 2^7 / 2^8 passes, three per transform), the two-plane kernel below
+// (2^20 = two radix-2^10 passes of four steps: the two extra barriers per exchange cost more than the third wave per SIMD hides).
+#ifndef BBG_NTT_OCC
+#define BBG_NTT_OCC 3
+#endif
+#ifndef BBG_NTT_LATE_OUTMUL
+#define BBG_NTT_LATE_OUTMUL 1
+#endif
+#ifndef BBG_NTT_SHFL_LAST
+#define BBG_NTT_SHFL_LAST 1 // a one-bit last step takes its elements by lane shuffles (p8s_exchange_last1) instead of through LDS
+#endif
+template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), BBG_NTT_OCC) k_ntt_pass8s(PassParams p)
+{
+    extern __shared__ uint4 lds[];
+    constexpr int NSTEPS = (LOGR + 2) / 3;
+    constexpr int LOGW = TL - LOGR;
+    const size_t tile = blockIdx.x;
+    size_t base = 0, lo0 = 0, d1_0 = 0, rest = 0;
+    int logRestCount = 0;
+    if (!ROW) {
+        const int tiles_per_hi_log = p.logS - LOGW;
+        const size_t hi = tile >> tiles_per_hi_log;
+        lo0 = (tile & (((size_t)1 << tiles_per_hi_log) - 1)) << LOGW;
+        base = (hi << (LOGR + p.logS)) + lo0;
+    } else {
+        const int logRows = p.log2n - LOGR;
+        logRestCount = logRows - p.logR1;
+        rest = tile & (((size_t)1 << logRestCount) - 1);
+        d1_0 = (tile >> logRestCount) << LOGW;
+    }
+    const Fr* tw = p.tw_radix;
+    Fr x[8], outmul[8];
+    const Fr* mul_table = ROW ? p.post : p.tw_inter;
+    const bool have_outmul = mul_table != nullptr;
+    // ---- step 0: the tile from global memory (same addressing as p8_step<.., 0, ..>)
+    {
+        int c, pbase, qlo;
+        p8s_coords<LOGR, ROW, 0, TL>(threadIdx.x, c, pbase, qlo);
+        constexpr int F = (LOGR >= 3) ? (LOGR - 3) : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int pj = pbase | (j << F);
+            size_t g;
+            if (!ROW) {
+                g = base + ((size_t)pj << p.logS) + c;
+                if (g >= p.in_count) {
+                    x[j] = Fr::zero();
+                    continue;
+                }
+                x[j] = fe_load<FrP>(p.in + g);
+                if (p.pre && g < p.pre_count) x[j] = fe_mul(x[j], fe_load<FrP>(p.pre + g));
+                continue;
+            }
+            g = (((((d1_0 + c) << logRestCount) + rest)) << LOGR) + pj;
+            x[j] = fe_load<FrP>(p.in + g);
+        }
+        // the multipliers of the outputs: behind the data loads, ahead of all the arithmetic (see k_ntt_pass8)
+        if (have_outmul && (!BBG_NTT_LATE_OUTMUL || NSTEPS == 1)) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int pj, cc;
+                p8_last_coords<LOGR, TL>(threadIdx.x, j, pj, cc);
+                outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, cc, base, lo0, d1_0, rest, true));
+            }
+        }
+        p8s_compute<LOGR, 0>(x, tw, qlo);
+    }
+    auto late_outmul = [&](bool last) { // in front of the last step's arithmetic: 12+ products cover the latency, the registers are free until then
+        if (BBG_NTT_LATE_OUTMUL && last && have_outmul) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int pj, cc;
+                p8_last_coords<LOGR, TL>(threadIdx.x, j, pj, cc);
+                outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, cc, base, lo0, d1_0, rest, true));
+            }
+        }
+    };
+    if constexpr (NSTEPS > 1) {
+        p8s_exchange<LOGR, ROW, 0, TL>(x, lds);
+        late_outmul(NSTEPS == 2);
+        int c, pbase, qlo;
+        p8s_coords<LOGR, ROW, 1, TL>(threadIdx.x, c, pbase, qlo);
+        p8s_compute<LOGR, 1>(x, tw, qlo);
+    }
+    if constexpr (NSTEPS > 2) {
+        if constexpr (NSTEPS == 3 && LOGR - 3 * 2 == 1 && (TL - LOGR) <= 5 && BBG_NTT_SHFL_LAST) p8s_exchange_last1<LOGR, TL>(x);
+        else p8s_exchange<LOGR, ROW, 1, TL>(x, lds);
+        late_outmul(NSTEPS == 3);
+        int c, pbase, qlo;
+        p8s_coords<LOGR, ROW, 2, TL>(threadIdx.x, c, pbase, qlo);
+        p8s_compute<LOGR, 2>(x, tw, qlo);
+    }
+    if constexpr (NSTEPS > 3) {
+        if constexpr (NSTEPS == 4 && LOGR - 3 * 3 == 1 && (TL - LOGR) <= 5 && BBG_NTT_SHFL_LAST) p8s_exchange_last1<LOGR, TL>(x);
+        else p8s_exchange<LOGR, ROW, 2, TL>(x, lds);
+        late_outmul(NSTEPS == 4);
+        int c, pbase, qlo;
+        p8s_coords<LOGR, ROW, 3, TL>(threadIdx.x, c, pbase, qlo);
+        p8s_compute<LOGR, 3>(x, tw, qlo);
+    }
+    // ---- the last step's elements leave for global memory (bit reversal folded into the index)
+    {
+        constexpr int T = NSTEPS - 1;
+        constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+        int c, pbase, qlo;
+        p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c, pbase, qlo);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int pj = pbase | (j << F);
+            Fr v = x[j];
+            if (have_outmul) v = fe_mul(v, outmul[j]);
+            fe_store<FrP>(p.out + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false), v);
+        }
+    }
+}
+
+template <int LOGR, int TL = P8_TILE_LOG> static void p8s_launch(const PassParams& p, size_t tiles, hipStream_t st)
+{
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8s<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8s_lds_bytes<TL>(), st, p);
+    else hipLaunchKernelGGL((k_ntt_pass8s<LOGR, false, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8s_lds_bytes<TL>(), st, p);
+}
+template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p8s_attr()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)k_ntt_pass8s<LOGR, true, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p8s_lds_bytes<TL>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_ntt_pass8s<LOGR, false, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p8s_lds_bytes<TL>());
+}
+
 template <int LOGR, int TL = P8_TILE_LOG> static void p8_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {
     if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);

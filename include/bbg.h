@@ -371,7 +371,10 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
  * "msm_acc_waves" (0 = automatic; N > 0 = lane segments per SIMD lane of the bucket accumulation, A/B), "msm_reduce_priority" (1 = low-priority reduce streams, default), "msm_upload_pieces" (1..4, default 1: pieces the host scalars of bbg_msm travel in),
  * "quotient_fuse" (1 = arithmetic + range + logic widgets of a chain in one pass, default),
  * "ntt_kernel" (2 = register-resident radix-8 passes, default; 1 = radix-2 in LDS),
- * "ntt_max_logr8" (6..11, max log-radix per radix-8 pass, default 10), "ntt_big_tile" (0 / 1 / 2: 4096-element tiles for 2^21 [default] / also 2^22).
+ * "ntt_max_logr8" (6..11, max log-radix per radix-8 pass, default 10), "ntt_big_tile" (0 / 1 / 2: 4096-element tiles for 2^21 [default] / also 2^22),
+ * "ntt_lds_planes" (2 = a pass keeps its tile in LDS between two radix-8 steps, 1 = the tile moves one 16-byte plane at a time through half the LDS with
+ * three waves per SIMD, 0 = automatic [default]: 1 from 2^22), "prover_msm_batch" (0 .. BBG_MSM_BATCH_MAX, default 4: commitments of a bbg_prover round per
+ * launch set; 0 / 1 = one launch set each).
  * Every value of every option gives bit-identical results; they exist for A/B measurements. */
 int bbg_set_option(bbg_ctx* ctx, const char* key, long value);
 /* Per-kernel timing with HIP events recorded on the launch stream.  Names: "msm_recode", "msm_sort", "msm_offsets",

@@ -132,12 +132,17 @@ def test_ntt_pass8_plans(pkg, oracle, bbg, maxr8):
     bbg.set_option("ntt_kernel", 2)
     bbg.set_option("ntt_max_logr8", maxr8)
     try:
-        for lg in (11, 12, 13, 14, 16, 17, 19):
-            c = pkg.synthetic_scalars(8000 + lg, 1 << lg)
-            assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), (maxr8, lg)
-            assert np.array_equal(oracle.canon(0, bbg.ntt(c, COSET_IFFT)), oracle.ntt(c, 3)), (maxr8, lg)
+        for planes in (2, 1):  # k_ntt_pass8 (tile resident in LDS) and k_ntt_pass8s (one plane at a time; one-bit last steps by lane shuffles)
+            bbg.set_option("ntt_lds_planes", planes)
+            for lg in (11, 12, 13, 14, 16, 17, 19):
+                c = pkg.synthetic_scalars(8000 + lg, 1 << lg)
+                assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), (maxr8, planes, lg)
+                assert np.array_equal(oracle.canon(0, bbg.ntt(c, COSET_IFFT)), oracle.ntt(c, 3)), (maxr8, planes, lg)
+                gs = (1 << lg) // 4  # the prover's zero-extended input (generator_size = n on the 4n domain): fused into the first pass's load
+                assert np.array_equal(oracle.canon(0, bbg.ntt(c, COSET_FFT, gs)), oracle.ntt(c, 2, gs)), (maxr8, planes, lg)
     finally:
         bbg.set_option("ntt_max_logr8", 10)
+        bbg.set_option("ntt_lds_planes", 0)
 
 
 def test_ntt_kernel_v1_still_matches(pkg, oracle, bbg):
@@ -187,21 +192,29 @@ def test_ntt_full_size_properties(pkg, oracle, bbg, golden, lg):
     if recs:
         assert sorted(r["op"] for r in recs) == [0, 1, 2, 3]
         for big in ((0, 2) if lg in (21, 22) else (1,)):
-            bbg.set_option("ntt_big_tile", big)
-            try:
-                for rec in recs:
-                    out = run(rec["op"])
-                    for i, want in rec["spots"].items():
-                        assert np.array_equal(out[int(i)], unhex(want)[0]), (lg, rec["op"], big, "spot", i)
-                    assert sha(out) == rec["sha256"], (lg, rec["op"], big)
-            finally:
-                bbg.set_option("ntt_big_tile", 1)
+            for planes in (2, 1):  # both pass kernels (option ntt_lds_planes; automatic = 1 from 2^22)
+                bbg.set_option("ntt_big_tile", big)
+                bbg.set_option("ntt_lds_planes", planes)
+                try:
+                    for rec in recs:
+                        out = run(rec["op"])
+                        for i, want in rec["spots"].items():
+                            assert np.array_equal(out[int(i)], unhex(want)[0]), (lg, rec["op"], big, planes, "spot", i)
+                        assert sha(out) == rec["sha256"], (lg, rec["op"], big, planes)
+                finally:
+                    bbg.set_option("ntt_big_tile", 1)
+                    bbg.set_option("ntt_lds_planes", 0)
     else:  # 2^18 / 2^20: the reference digests live in golden.json, recorded over its own seeds
         grecs = [r for r in golden["ntt"] if r["log2n"] == lg and r["op"] < 4 and r["generator_size"] == 0]
         assert sorted(r["op"] for r in grecs) == [0, 1, 2, 3]
-        for rec in grecs:
-            c = torch.from_numpy(pkg.synthetic_scalars(rec["seed"], n).view(np.int64)).cuda()
-            assert sha(run(rec["op"], c)) == rec["sha256"], (lg, rec["op"])
+        for planes in (2, 1):
+            bbg.set_option("ntt_lds_planes", planes)
+            try:
+                for rec in grecs:
+                    c = torch.from_numpy(pkg.synthetic_scalars(rec["seed"], n).view(np.int64)).cuda()
+                    assert sha(run(rec["op"], c)) == rec["sha256"], (lg, rec["op"], planes)
+            finally:
+                bbg.set_option("ntt_lds_planes", 0)
     work = ta.clone()
     bbg.ntt_device(work.data_ptr(), lg, FFT)
     bbg.ntt_device(work.data_ptr(), lg, IFFT)
