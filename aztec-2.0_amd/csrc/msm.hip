@@ -350,7 +350,7 @@ int msm_run_batch(bbg_ctx* ctx, Srs& srs, int sets, const void* const* d_scalars
         return BBG_E_INVALID;
     }
     if (srs.n > ((size_t)1 << MSM_IDX_BITS)) {
-        set_error("bbg_msm: SRS larger than 2^26 points per device is not supported (shard it across devices)");
+        set_error("bbg_msm: SRS larger than 2^27 points per device is not supported (shard it by point range across devices: bbg_multi_*)");
         return BBG_E_INVALID;
     }
     size_t max_n = 0;

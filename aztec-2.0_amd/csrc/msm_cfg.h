@@ -21,6 +21,7 @@ template <int C> struct MsmCfg {
     static constexpr int windows = (254 + C) / C;           // C * windows >= 255
     static constexpr int nwide = 255 - windows * (C - 1);   // windows [0, nwide) have C bits, the rest C - 1
     static_assert(nwide >= 1 && nwide <= windows, "use the narrower configuration with the same number of windows");
+    static_assert(windows <= 16, "the window field of a sorted value has four bits");
     static constexpr int width(int w) { return w < nwide ? C : C - 1; }
     static constexpr int offset(int w) { return w * (C - 1) + (w < nwide ? w : nwide); } // first scalar bit of window w; offset(windows) = 255
     // A narrow window's digits d fill only the lower half of the bucket range; filed under bucket d they would double the load of the lower
@@ -36,7 +37,11 @@ template <int C> struct MsmCfg {
     static constexpr int planes = C - 1;               // bit planes of the weight idx + 1 <= 2^(C-1)
 };
 constexpr int MSM_MAX_WINDOWS = 16;
-constexpr int MSM_IDX_BITS = 26;     // point index bits in an entry value (n <= 2^26 per call)
+// A sorted value = sign (bit 31) | window (4 bits) | point index (27 bits): up to 16 windows (every compiled width) over up to 2^27 points per
+// device -- the whole 100.8 M-point Ignition SRS (2^26.6) fits one device's format, as it fits its HBM (12 windows x 64 B x 2^27 = 103 GB).
+// The reference's schedule word carries a 32-bit index (scalar_multiplication.hpp:24-29); beyond 2^27 points an SRS is sharded by point
+// range across devices (bbg_multi_*).  (Round 3: 26 bits -- a bit was left unused between the window field and the sign.)
+constexpr int MSM_IDX_BITS = 27;
 constexpr int MSM_MAX_PLANES = 32;
 
 // every width with a translation unit msm_wNN.hip (X-macro: dispatch tables in msm.hip, option parsing, table slots in Srs)

@@ -20,8 +20,24 @@
 // all three call the same kernels.
 #include "bbg_internal.h"
 
-#include <rccl/rccl.h> // types and prototypes only: the entry points are resolved with dlsym
 #include <dlfcn.h>
+
+// The few RCCL declarations this file needs -- the stable public NCCL ABI (nccl.h: opaque communicator, result / data-type enums, the
+// eight entry points below), declared here so that libbbg.so builds on a ROCm install without the RCCL development headers; the entry
+// points themselves are resolved with dlsym on first use of the RCCL exchange.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;         // every other value is an error (ncclGetErrorString names it)
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t; // byte transport only
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char* ncclGetErrorString(ncclResult_t result);
+}
 
 #include <cstring>
 #include <thread>
@@ -106,6 +122,20 @@ int rccl_fail(ncclResult_t r, const char* what)
 } // namespace
 
 namespace {
+
+// Every enqueue on a context's stream holds that context's mutex (a caller may drive bbg_multi_ctx(k) from another thread at the same
+// time); a grouped RCCL operation enqueues on ALL streams of the group, so it takes all of them -- in index order, the only order used.
+struct LockAllContexts {
+    bbg_multi* m;
+    explicit LockAllContexts(bbg_multi* mm) : m(mm)
+    {
+        for (int g = 0; g < m->G; g++) m->ctx[(size_t)g]->mu.lock();
+    }
+    ~LockAllContexts()
+    {
+        for (int g = m->G - 1; g >= 0; g--) m->ctx[(size_t)g]->mu.unlock();
+    }
+};
 
 int set_dev(bbg_ctx* c)
 {
@@ -219,6 +249,7 @@ int multi_ntt_core(bbg_multi* m, void* const* d_shards, unsigned log2n, int op)
         // the all-to-all as ONE group of point-to-point operations (xGMI is point-to-point: every pair has its own links): rank g sends
         // chunk r of its shard to rank r and receives rank r's chunk g into slot r.  Enqueued on the contexts' streams: behind the
         // local transform, ahead of the cross DFT -- and behind the previous transform's cross DFT, which read the same receive buffer.
+        LockAllContexts all(m);
         BBG_RCCL(g_rccl.GroupStart());
         for (int g = 0; g < G; g++) {
             hipStream_t st = m->ctx[(size_t)g]->stream;
@@ -481,10 +512,13 @@ int bbg_multi_msm(bbg_multi* m, const uint64_t* scalars, size_t from, size_t n, 
     if (rc) return rc;
     if (m->use_rccl) {
         // "reduce" = all-gather + local group sum (RCCL has no elliptic-curve reduction operator): every context receives the G partials
-        BBG_RCCL(g_rccl.GroupStart());
-        for (int g = 0; g < m->G; g++)
-            BBG_RCCL(g_rccl.AllGather(m->d_part[(size_t)g], m->d_gather[(size_t)g], 96, ncclUint8, m->comm[(size_t)g], m->ctx[(size_t)g]->stream));
-        BBG_RCCL(g_rccl.GroupEnd());
+        {
+            LockAllContexts all(m);
+            BBG_RCCL(g_rccl.GroupStart());
+            for (int g = 0; g < m->G; g++)
+                BBG_RCCL(g_rccl.AllGather(m->d_part[(size_t)g], m->d_gather[(size_t)g], 96, ncclUint8, m->comm[(size_t)g], m->ctx[(size_t)g]->stream));
+            BBG_RCCL(g_rccl.GroupEnd());
+        }
         bbg_ctx* c0 = m->ctx[0];
         rc = set_dev(c0);
         if (rc) return rc;

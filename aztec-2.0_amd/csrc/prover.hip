@@ -378,18 +378,19 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     const size_t n = p->n;
     for (int k = 0; k < p->width; k++)
         if (!wires_lagrange[k]) { set_error("bbg_prover_round1: null wire"); return BBG_E_INVALID; }
-    // The wires travel on the copy stream; the commitments go in groups through one launch set each (commit()).  A group starts as soon as
-    // ITS wires have landed and been transformed: small circuits (upload negligible) commit all wires at once, large ones in pairs so
-    // that the second pair travels while the first is committed (4 x 32 MiB is 2.6 ms of PCIe at 2^20 gates).
+    // The wires travel on the copy stream (pageable host memory: each copy call returns when its data has been staged), the commitments go
+    // in groups through one launch set each (commit()).  Small circuits (upload negligible) commit all wires at once.  Large ones keep one
+    // wire per group: wire k+1 travels (0.65 ms at 2^20 gates) while wire k is transformed and committed (1.5 ms) -- a group of two would
+    // start 0.65 ms later to save 0.15 ms of launch-set overhead (measured: profiles/r04_batch_ab.txt).
     const int max_batch = std::max(1, std::min(p->ctx->prover_msm_batch, BBG_MSM_BATCH_MAX));
-    const int group = max_batch == 1 ? 1 : (p->log2n <= 17 ? std::min(max_batch, p->width) : std::min(max_batch, 2));
+    const int group = (max_batch == 1 || p->log2n > 17) ? 1 : std::min(max_batch, p->width);
     const size_t lens[4] = { n, n, n, n };
-    for (int k = 0; k < p->width; k++) {
-        BBG_HIP(hipMemcpyAsync(p->wire_lagrange[k], wires_lagrange[k], n * 32, hipMemcpyHostToDevice, p->copy_stream));
-        BBG_HIP(hipEventRecord(p->ev_up[k], p->copy_stream));
-    }
     for (int k0 = 0; k0 < p->width; k0 += group) {
         const int cnt = std::min(group, p->width - k0);
+        for (int k = k0; k < k0 + cnt; k++) {
+            BBG_HIP(hipMemcpyAsync(p->wire_lagrange[k], wires_lagrange[k], n * 32, hipMemcpyHostToDevice, p->copy_stream));
+            BBG_HIP(hipEventRecord(p->ev_up[k], p->copy_stream));
+        }
         for (int k = k0; k < k0 + cnt; k++) {
             BBG_HIP(hipStreamWaitEvent(st, p->ev_up[k], 0));
             BBG_HIP(hipMemcpyAsync(p->wire_coeff[k], p->wire_lagrange[k], n * 32, hipMemcpyDeviceToDevice, st));

@@ -143,8 +143,8 @@ def main():
         problem = "the residue-class NTT split needs a power-of-two world <= 8 (got %d)" % world
     elif not args.no_config5 and ((1 << args.config5_log2n) // world) % world:
         problem = "config 5: G^2 must divide n (G = %d, n = 2^%d)" % (world, args.config5_log2n)
-    elif args.log2n < 1 or args.log2n > 26:
-        problem = "--log2n must be 1 .. 26 (2^26 points per device is the entry format's cap)"
+    elif args.log2n < 1 or args.log2n > 27:
+        problem = "--log2n must be 1 .. 27 (2^27 points per device is the entry format's cap)"
     if problem:
         if rank == 0:
             os.write(REAL_STDOUT, (json.dumps({"metric": "BN254 G1 MSM Mscalar-mults/s (+ Fr NTT Gfield-ops/s in extra) at n=2^%d" % args.log2n, "value": None,

@@ -481,7 +481,7 @@ PROVER_SO = os.path.join(_HERE, "_ref", "libbbprover.so")
 # entry points wrapped onto the GPU library at link time.  Needs the HIP runtime: import torch first.
 PROVER_GPU_SO = os.path.join(_HERE, "_ref", "libbbprover_gpu.so")
 # the CPU build's own driver object linked with BOTH shim TUs: construct_proof() itself is wrapped (oracle/Makefile prover_wrap)
-PROVER_WRAP_SO = os.path.join(_HERE, "_ref", "libbbprover_wrap.so")
+PROVER_WRAP_SO = os.environ.get("BBG_PROVER_WRAP_SO") or os.path.join(_HERE, "_ref", "libbbprover_wrap.so")  # env: the sanitizer build (scripts/sanitize_run.sh)
 
 
 def prover_available():

@@ -112,7 +112,7 @@ def test_bench_refuses_impossible_shapes_before_any_process_group():
         (["--gpus", "8", "--config5-log2n", "5"], {"WORLD_SIZE": "8", "RANK": "0"}, "G^2"),
         (["--gpus", "3"], {"WORLD_SIZE": "3", "RANK": "0"}, "power-of-two"),
         (["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0"}, "WORLD_SIZE"),
-        (["--gpus", "1", "--log2n", "27"], {"WORLD_SIZE": "1", "RANK": "0"}, "2^26"),
+        (["--gpus", "1", "--log2n", "28"], {"WORLD_SIZE": "1", "RANK": "0"}, "2^27"),
     ]
     for argv, envx, needle in cases:
         r = subprocess.run([sys.executable, bench] + argv, env=dict(os.environ, **envx), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)

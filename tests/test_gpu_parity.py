@@ -765,6 +765,108 @@ def test_msm_2_22_properties_wide_windows(pkg, oracle, bbg, golden):
     srs.free()
 
 
+def test_msm_srs_above_2_26_points(pkg, oracle, bbg):
+    """The sorted value carries a 27-bit point index (msm_cfg.h; round 3: 26): an SRS of 2^26 + 2^16 points on ONE device -- more than one
+    Ignition transcript file set of 2^26 would need, the reference's schedule word has 32 index bits (scalar_multiplication.hpp:24-29).
+      (a) the synthetic points above index 2^26 are the oracle's (index-based generator);
+      (b) an MSM over the 2^16 points that straddle index 2^26 (`from` = 2^26 - 2^15) equals the oracle's Pippenger over the same points;
+      (c) the first 2^24 points with the scalars of tests/golden/msm24.json reproduce the compiled REFERENCE's 2^24 result through this
+          SRS's 12-window tables (the msm24.json method: same seeds, the reference's sixteen shards summed);
+      (d) one MSM over ALL 2^26 + 2^16 points (random scalars) equals the group sum of its two parts [0, 2^26) and [2^26, end), and a
+          scalar vector that is zero below 2^26 gives the part above (no entry may lose index bit 26)."""
+    import json
+    import torch
+    top = 1 << 26
+    n = top + (1 << 16)
+    free = bbg.memory_report()["device_free"]
+    if free < (120 << 30):
+        pytest.skip("needs ~100 GB of free HBM (12 windows x 64 B x 2^26 points + the sort arena)")
+    srs = bbg.srs_synth_hashed(0xBB254, n)
+    try:
+        assert bbg.msm_plan(n, srs) == (22, 12)
+        pts_hi = srs.read(top - (1 << 15), 1 << 16)
+        want_pts = oracle.srs_hashed(0xBB254 + top - 8, 16)  # (a) sixteen points around the old cap, oracle-generated
+        assert np.array_equal(pts_hi[(1 << 15) - 8:(1 << 15) + 8], want_pts)
+        sc = pkg.synthetic_scalars(2626, 1 << 16)
+        got = oracle.jac_to_affine(bbg.msm(srs, sc, start=top - (1 << 15)))  # (b)
+        assert np.array_equal(got, oracle.pippenger(sc, pts_hi))
+        g24 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm24.json")))  # (c)
+        sc24 = pkg.synthetic_scalars(0xBB254 + 24, 1 << g24["log2n"])
+        got24 = bbg.g1_normalize(bbg.msm(srs, sc24).reshape(1, 12)).reshape(-1)
+        assert np.array_equal(got24, np.frombuffer(bytes.fromhex(g24["result"]), dtype=np.uint64)), "2^24 golden through the 2^26+ SRS"
+        del sc24
+        dev = torch.device("cuda", 0)  # (d) device-resident: 2.1 GB of scalars
+        d_sc = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        chunk = 1 << 22
+        for lo in range(0, n, chunk):
+            cnt = min(chunk, n - lo)
+            d_sc[lo:lo + cnt] = torch.from_numpy(pkg.synthetic_scalars(2627, cnt, lo).view(np.int64)).to(dev)
+        d_out = torch.zeros(3 * 12, dtype=torch.int64, device=dev)
+        bbg.msm_device(srs, d_sc.data_ptr(), n, d_out.data_ptr())
+        bbg.msm_device(srs, d_sc.data_ptr(), top, d_out.data_ptr() + 96)
+        bbg.msm_device(srs, d_sc.data_ptr() + top * 32, n - top, d_out.data_ptr() + 192, start=top)
+        bbg.join()
+        bbg.sync()
+        res = d_out.cpu().numpy().view(np.uint64).reshape(3, 12)
+        whole = bbg.g1_normalize(res[0:1]).reshape(-1)
+        parts = bbg.g1_normalize(bbg.g1_sum(res[1:3]).reshape(1, 12)).reshape(-1)
+        assert np.array_equal(whole, parts), "MSM over 2^26 + 2^16 points != sum of its parts"
+        d_sc[:top] = 0
+        bbg.msm_device(srs, d_sc.data_ptr(), n, d_out.data_ptr())
+        bbg.sync()
+        only_top = bbg.g1_normalize(d_out.cpu().numpy().view(np.uint64).reshape(3, 12)[0:1]).reshape(-1)
+        assert np.array_equal(only_top, bbg.g1_normalize(res[2:3]).reshape(-1))
+        del d_sc
+    finally:
+        srs.free()
+        bbg.memory_trim(tables=True)
+
+
+def test_memory_report_and_trim(pkg, oracle):
+    """bbg_memory_report / bbg_memory_trim (the HBM budget of a context: window tables, NTT tables, MSM arena, scratch, resident keys) on a
+    context of its own: every class appears when its first user runs, the total is the sum of the parts, trimming releases the rebuildable
+    part and the same calls give the same results afterwards."""
+    import ctypes
+    ctx = pkg.Bbg(0)
+    try:
+        r0 = ctx.memory_report()
+        assert r0["total"] == 0 and r0["live_srs"] == 0 and r0["device_total"] > (200 << 30) and 0 < r0["device_free"] <= r0["device_total"]
+        n = 1 << 14
+        srs = ctx.srs_synth_hashed(0xBB254, n)
+        r1 = ctx.memory_report()
+        assert r1["live_srs"] == 1 and r1["srs_tables"] == n * 16 * 64 and r1["total"] == r1["srs_tables"]
+        sc = pkg.synthetic_scalars(55, n)
+        want = oracle.pippenger(sc, srs.read())
+        assert np.array_equal(oracle.jac_to_affine(ctx.msm(srs, sc)), want)
+        c = pkg.synthetic_scalars(56, n)
+        f0 = ctx.ntt(c, FFT)
+        ctx.set_option("msm_window", 17)
+        assert np.array_equal(oracle.jac_to_affine(ctx.msm(srs, sc)), want)  # a second width: its own table
+        ctx.set_option("msm_window", 0)
+        r2 = ctx.memory_report()
+        assert r2["srs_tables"] == n * (16 + 15) * 64 and r2["msm_arena"] > 0 and r2["ntt_tables"] >= 4 * 32 * n and r2["ntt_domains"] == 1 and r2["scratch"] > 0
+        gens = np.stack([ctx.field_op(0, 5, np.array([[k, 0, 0, 0]], dtype=np.uint64))[0] for k in (5, 5, 6, 7)])
+        h = ctypes.c_void_p()
+        ctx._ck(ctx.lib.bbg_prover_create(ctx.ctx, srs.handle, 12, 4, gens.ctypes.data, ctypes.byref(h)))
+        pb = ctypes.c_size_t()
+        ctx._ck(ctx.lib.bbg_prover_device_bytes(h, ctypes.byref(pb)))
+        r3 = ctx.memory_report()
+        assert r3["live_provers"] == 1 and r3["prover_keys"] == pb.value and pb.value >= (8 * 4096 + 6 * 4 * 4096) * 32
+        assert r3["total"] == sum(r3[k] for k in ("srs_points", "srs_tables", "ntt_tables", "msm_arena", "scratch", "prover_keys"))
+        ctx.lib.bbg_prover_destroy(h)
+        assert ctx.memory_report()["live_provers"] == 0
+        released = ctx.memory_trim(tables=True)
+        r4 = ctx.memory_report()
+        assert released == r3["total"] - pb.value - r4["total"] and r4["srs_tables"] == n * 16 * 64 and r4["ntt_tables"] == 0 and r4["msm_arena"] == 0
+        # everything is rebuilt on demand: same results
+        assert np.array_equal(oracle.jac_to_affine(ctx.msm(srs, sc)), want)
+        assert np.array_equal(ctx.ntt(c, FFT), f0)
+        srs.free()
+        assert ctx.memory_report()["live_srs"] == 0 and ctx.memory_report()["srs_tables"] == 0
+    finally:
+        ctx.close()
+
+
 def test_poly_linear_combination(pkg, oracle, bbg):
     """opening_poly[i] = t[i] + sum_k poly_k[i] * nu_k (kate_commitment_scheme.cpp:216-226) against the oracle's field ops."""
     import torch
