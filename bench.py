@@ -41,6 +41,35 @@ def _latest_pmc_profile():
 PMC_PROFILE = _latest_pmc_profile()
 
 
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        with open(path, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    except OSError:
+        return None
+
+
+def profile_stamp():
+    """The committed profile's build stamp (first line: `# build: libbbg.so sha256 <hex> ...`, scripts/refresh_profiles.sh) against the library
+    this run loads: the numbers bench.py reads from the profile (traffic, SQ_INSTS_VALU -> valu_issue / step_issue_floor) describe the build
+    the profile was taken on."""
+    import re
+    lib = os.path.join(ROOT, "aztec-2.0_amd", "csrc", "libbbg.so")
+    have = _sha256(lib)
+    want = None
+    try:
+        m = re.search(r"libbbg\.so sha256 ([0-9a-f]{64})", open(PMC_PROFILE).readline())
+        want = m.group(1) if m else None
+    except OSError:
+        pass
+    return {"profile": "profiles/" + os.path.basename(PMC_PROFILE), "profile_libbbg_sha256": want, "loaded_libbbg_sha256": have,
+            "profile_matches_build": bool(want and have and want == have)}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/r01_pmc_v2.txt: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command; KiB per dispatch).  MI355X_MICROARCH.md's gfx950
@@ -79,7 +108,8 @@ def valu_issue(acc_ms, ntt_ms):
     """What actually bounds these kernels: VALU instruction issue.  SQ_INSTS_VALU (wave-instructions per launch, committed PMC pass)
     over the launch duration measured in THIS run, against the chip's issue peak."""
     acc, ntt = pmc_counter("k_accumulate", "SQ_INSTS_VALU"), pmc_counter("k_ntt_pass8", "SQ_INSTS_VALU")
-    out = {"unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE) + " SQ_INSTS_VALU"}
+    out = {"unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE) + " SQ_INSTS_VALU",
+           "profile_matches_build": profile_stamp()["profile_matches_build"]}
     if acc:
         out["msm_accumulate"] = {"insts_per_launch": acc, "achieved": round(acc / (acc_ms * 1e-3) / 1e9, 1), "frac": round(acc / (acc_ms * 1e-3) / 1e9 / VALU_PEAK_GWAVE, 3)}
     if ntt:
@@ -171,7 +201,9 @@ def main():
     n = 1 << lg
     bbg = pkg.Bbg(local_rank)
     bbg.set_stream(torch.cuda.current_stream().cuda_stream)
-    bbg.set_option("msm_async_reduce", 1)  # bucket reduction of MSM i overlaps sort/accumulate of step i+1
+    # bucket reduction of MSM i overlaps sort/accumulate of step i+1; BBG_BENCH_INLINE_REDUCE=1 (profiling only: scripts/refresh_profiles.sh)
+    # keeps it on the main stream so that a kernel trace shows every kernel alone on the device
+    bbg.set_option("msm_async_reduce", 0 if os.environ.get("BBG_BENCH_INLINE_REDUCE") == "1" else 1)
     if args.msm_window:
         bbg.set_option("msm_window", args.msm_window)
     if args.reduce_priority >= 0:
@@ -257,8 +289,10 @@ def main():
     acc_ms = avg("msm_accumulate")
     alg_bytes_msm = 96.0 * n                      # 32-B scalar + 64-B base per term, one launch covers all n terms
     achieved = alg_bytes_msm / (acc_ms * 1e-3) / 1e9
+    stamp = profile_stamp()
     roofline = {"kernel": "k_accumulate29 (MSM bucket accumulation, 9 x 29-bit limbs)", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("k_accumulate"),
+                "profile_matches_build": stamp["profile_matches_build"],
                 "traffic_source": "profiles/" + os.path.basename(PMC_PROFILE) + " (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; bytes per launch at n=2^20)",
                 "algorithmic_bytes": alg_bytes_msm, "avg_launch_ms": round(acc_ms, 4),
                 "note": "256-bit modular integer work: the binding resource is v_mad_u64_u32 issue, see extra.alu"}
@@ -280,6 +314,7 @@ def main():
                          "avg_launch_ms": round(pass_ms, 4), "launches_per_ntt": ntt_passes,
                          "whole_ntt_frac": round(ntt_alg / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         "timed_blocks_ms": [round(b[0] * 1e3, 3) for b in blocks], "reported_block": "median",
+        "profile_stamp": stamp,
         "valu_issue": valu_issue(acc_ms, ntt_ms),
         "alu": {"unit": "T v_mad_u64_u32/s", "peak_measured": MAD_PEAK_TOPS,
                 # windows x n mixed additions x 1467 mads (k_accumulate29: 7 products of 162 + 2 squares of 126 + 1 double product of 243 on
@@ -384,7 +419,7 @@ def step_issue_floor():
         lines = open(PMC_PROFILE).read().splitlines()
     except OSError:
         return None
-    m = re.search(r"--steps (\d+) --warmup (\d+)", lines[0]) if lines else None
+    m = next((mm for mm in (re.search(r"--steps (\d+) --warmup (\d+)", ln) for ln in lines[:4]) if mm), None)  # the header names the profiled command
     launches = (int(m.group(1)) + int(m.group(2))) if m else 4
     tot, per_kernel = 0.0, {}
     for line in lines:
@@ -397,7 +432,8 @@ def step_issue_floor():
     if not tot:
         return None
     return {"ms": round(tot / (VALU_PEAK_GWAVE * 1e9) * 1e3, 4), "valu_wave_insts_per_step_M": round(tot / 1e6, 1),
-            "per_kernel_M": per_kernel, "peak_G_per_s": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE)}
+            "per_kernel_M": per_kernel, "peak_G_per_s": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE),
+            "profile_matches_build": profile_stamp()["profile_matches_build"]}
 
 
 def host_path(pkg, bbg, srs, lg, reps=11):

@@ -3,6 +3,7 @@
 
   python scripts/rocpd_summary.py kernels <db>            -> per-kernel calls / total / avg / min / max (us), like --stats
   python scripts/rocpd_summary.py pmc <db> [<db> ...]     -> per-kernel counter averages per dispatch (FETCH_SIZE / WRITE_SIZE are KiB)
+  python scripts/rocpd_summary.py clocks <db>             -> GRBM_GUI_ACTIVE / duration per kernel (a --pmc GRBM_GUI_ACTIVE --kernel-trace pass): effective GHz
 """
 import re
 import sqlite3
@@ -49,8 +50,41 @@ def pmc(dbs):
             print(f"{k:72s} {c:>14s} {a[0]:10d} {a[1]:16.1f}")
 
 
+def clocks(db):
+    """Busy cycles of the dispatch (GRBM_GUI_ACTIVE) over its duration from the same pass's kernel trace: the clock the kernel ran at under
+    the profiler.  The join key is the dispatch id; the schema differs between rocprofv3 releases, so the columns are discovered."""
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    def cols(view):
+        try:
+            return [r[1] for r in cur.execute(f"pragma table_info({view})").fetchall()]
+        except sqlite3.Error:
+            return []
+    cc, kc = cols("counters_collection"), cols("kernels")
+    key = next((k for k in ("dispatch_id", "id", "correlation_id") if k in cc and k in kc), None)
+    if "start" in cc and "end" in cc:  # the counter view carries the dispatch's own timestamps
+        rows = cur.execute("select kernel_name, value, (end - start) from counters_collection where counter_name = 'GRBM_GUI_ACTIVE'").fetchall()
+    elif key:
+        rows = cur.execute(f"select c.kernel_name, c.value, k.duration from counters_collection c join kernels k on c.{key} = k.{key} "
+                           "where c.counter_name = 'GRBM_GUI_ACTIVE'").fetchall()
+    else:
+        print("cannot join counters with durations; counters_collection:", cc, "kernels:", kc)
+        return
+    agg = {}
+    for name, cycles, dur in rows:
+        if not dur:
+            continue
+        a = agg.setdefault(short(name), [0, 0.0, 0.0])
+        a[0] += 1; a[1] += cycles; a[2] += dur
+    print(f"{'kernel':72s} {'dispatches':>10s} {'avg_cycles':>14s} {'avg_us':>10s} {'GHz':>7s}")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+        print(f"{k:72s} {a[0]:10d} {a[1]/a[0]:14.0f} {a[2]/a[0]/1e3:10.2f} {a[1]/a[2]:7.3f}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernels":
         kernels(sys.argv[2])
+    elif sys.argv[1] == "clocks":
+        clocks(sys.argv[2])
     else:
         pmc(sys.argv[2:])
