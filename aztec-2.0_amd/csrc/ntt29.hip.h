@@ -1,0 +1,127 @@
+// The radix-8 NTT step on LAZILY REDUCED 9 x 29-bit limbs (field29.hip.h) -- the arithmetic of k_ntt_pass29 (ntt_pass8.hip.h).
+//
+// Why.  A radix-8 decimation-in-frequency step on 8 x 32-bit limbs (p8_butterfly + the step twiddles) costs 12 Montgomery products of
+// 136 v_mad_u64_u32 + 136 v_addc_co_u32 and 24 butterflies whose add and sub each carry, compare and conditionally correct (8 x u32 with
+// carries: ~24 instructions per operation).  On 29-bit limbs a product is 162 mads and NO carry instruction (field29.hip.h: 168-177 against
+// 139 G products/s), an addition is 9 v_add_u32, a subtraction 9 v_sub + 9 v_add of a constant -- no carries, no comparisons: values are
+// allowed to grow and only the twelve products (which reduce whatever they are given) and one table-driven reduction of the single
+// un-multiplied output bring them back.
+//
+// Representation.  A device array holds x R mod p (R = 2^256), coarsely reduced (< 2p), as 8 x u32.  Re-limbing those 256 bits into
+// 9 x 29-bit limbs WITHOUT the 5-bit shift of the MSM's conversion gives the integer x R = (x / 32) R' with R' = 2^261: the whole transform is
+// carried out on the values x / 32 in R'-Montgomery form -- a uniform scaling that a linear transform hands through, so the outputs are
+// again y R, i.e. already what the array must hold; no conversion multiplication on either side.  Twiddles multiply as w R' mod p: the
+// small per-radix tables exist in that form (NttDomain::tw_radix29, built with one multiplication by 32 per entry), the big per-element
+// tables (inter-pass twiddles, coset factors) are the R-form ones shifted on the fly by 5 bits (w R << 5 = w R' as an integer < 64 p).
+//
+// Bounds (V = value / p; L = largest limb).  Products: (a b + m p) / R' < a b / R' + p, p / R' = 2^-7.4 = 1 / 169, limbs < 2^29 (field29.hip.h).
+// f29_mul needs 9 La Lb + 9 2^58 < 2^64: Lb < 2^29 (a table value) allows La < 2^31 + 2^29.  f29_sub<K> needs b < K p (top-limb margin: V_b + 1 <= K)
+// and b limbs <= 2^30 - 2.  "carried" = after f29_carry: limbs < 2^29 + 8.  Every bound below is asserted on a Python big-integer model
+// of exactly these operations (tests/test_ntt29_model.py).
+#pragma once
+#include "field29.hip.h"
+
+namespace bbg {
+
+using Fr29 = F29<FrP>;
+
+// ---- reduction of a value < 32 p to < 3 p without a multiplication: estimate q = floor(x / p) from the top limb (never too large, at
+// most 1 too small), go one lower (so that the difference keeps a top limb of its own: the row's borrowed limbs need it) and add row
+// q' of a table holding -q' p with every limb below the top raised by 2^30 (the raise borrowed from the limb above: Spread29 with q = 0).
+constexpr int NTT29_RED_ROWS = 32, NTT29_RED_ROW = 12; // 12 words per row: three ds_read_b128
+constexpr uint32_t NTT29_P_TOP = (FrP::MOD[7] >> 8);                            // p >> 232 (22 bits)
+constexpr uint32_t NTT29_INV_TOP = (uint32_t)((1ull << 32) / (NTT29_P_TOP + 1)); // floor(2^32 / (p_top + 1))
+__device__ __forceinline__ void ntt29_fill_reduce_table(uint32_t* tbl, int k) // one row per calling thread, k < 32
+{
+    uint64_t carry = 0;
+    uint32_t w[9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t x = (uint64_t)FrP::MOD[i] * (uint32_t)k + carry;
+        w[i] = (uint32_t)x;
+        carry = x >> 32;
+    }
+    w[8] = (uint32_t)carry;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int b = 29 * j, i = b >> 5, o = b & 31;
+        const uint64_t lo = w[i], hi = i + 1 < 9 ? w[i + 1] : 0;
+        const uint32_t kp = (uint32_t)(((lo | (hi << 32)) >> o) & M29);
+        const uint32_t zero_spread = j == 0 ? (1u << 30) : (j < 8 ? (1u << 30) - 2u : 0u - 2u); // value 0: 2^30 borrowed limb by limb
+        // row 0 is all zeros (x < 2p stays as it is: its top limb may be too small to lend); rows k >= 1 are used for x >= (k + 1) p only,
+        // whose top limb exceeds that of k p by p's own: top limb -2 - kp (mod 2^32) added to a larger one
+        tbl[k * NTT29_RED_ROW + j] = k == 0 ? 0u : zero_spread - kp;
+    }
+}
+// x: carried or not (limbs < 2^32 - 2^30), value < 32 p.  Result: carried, value in [p, 3p) for x >= 2p, x itself below.
+__device__ __forceinline__ Fr29 ntt29_reduce(const Fr29& x, const uint32_t* tbl)
+{
+    const Fr29 c = f29_carry(x);
+    const uint32_t q = __umulhi(c.v[8], NTT29_INV_TOP);
+    const uint32_t k = q > 1u ? q - 1u : 0u;
+    const uint4* row = reinterpret_cast<const uint4*>(tbl + k * NTT29_RED_ROW);
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2];
+    Fr29 t;
+    t.v[0] = c.v[0] + r0.x; t.v[1] = c.v[1] + r0.y; t.v[2] = c.v[2] + r0.z; t.v[3] = c.v[3] + r0.w;
+    t.v[4] = c.v[4] + r1.x; t.v[5] = c.v[5] + r1.y; t.v[6] = c.v[6] + r1.z; t.v[7] = c.v[7] + r1.w;
+    t.v[8] = c.v[8] + r2.x;
+    return f29_carry(t);
+}
+
+// ---- butterflies.  KB = the multiple of p added by the subtraction: must exceed V_b by one.
+template <int KB> __device__ __forceinline__ void n29_bfly(Fr29& a, Fr29& b) // (a, b) <- (a + b, a - b + KB p)
+{
+    const Fr29 u = f29_add(a, b);
+    b = f29_sub<KB>(a, b);
+    a = u;
+}
+__device__ __forceinline__ void n29_carry(Fr29& a) { a = f29_carry(a); }
+
+// S = 3: the radix-8 butterfly of p8_butterfly<3> (same pairs, same twiddle places) followed by the seven step twiddles tw[1..7] (tw[j] is
+// the multiplier of register j; pass nullptr-like `have_tw = false` for a step without them) and the reduction of register 0.
+//   in : x[j] carried, V < 3 (a reduced or freshly loaded value), w1 = w8, w2 = w8^2 = w4, w3 = w8^3 in reduced R'-form (< p, exact limbs)
+//   out: x[0] carried, V < 3; x[1..7] products, V < 1.2 (with step twiddles) or as listed below (without)
+template <bool HAVE_TW>
+__device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const Fr29& w1, const Fr29& w2, const Fr29& w3, const Fr29 (&tw)[8], const uint32_t* red)
+{
+    // level 1: inputs V < 3 carried.  u: V < 6, L < 2^30 + 16.  d = a - b + 4p: V < 7, L < 2^31 + 8.
+    n29_bfly<4>(x[0], x[4]);
+    n29_bfly<4>(x[1], x[5]);
+    n29_bfly<4>(x[2], x[6]);
+    n29_bfly<4>(x[3], x[7]);
+    f29_mul2(x[5], w1, x[6], w2, x[5], x[6]); // V < 7/169 + 1 = 1.05, L < 2^29
+    x[7] = f29_mul(x[7], w3);
+    n29_carry(x[0]); n29_carry(x[1]); n29_carry(x[2]); n29_carry(x[3]); // V < 6
+    n29_carry(x[4]);                                                    // V < 7
+    // level 2.  (0,2), (1,3): a, b carried, V < 6: u V < 12, d = a - b + 7p V < 13.  (4,6): a V < 7 carried, b V < 1.05 exact: u V < 8.05,
+    // d = a - b + 3p V < 10.  (5,7): a, b V < 1.05 exact: u V < 2.1 (L < 2^30), d = a - b + 3p V < 4.05.
+    n29_bfly<7>(x[0], x[2]);
+    n29_bfly<7>(x[1], x[3]);
+    n29_bfly<3>(x[4], x[6]);
+    n29_bfly<3>(x[5], x[7]);
+    f29_mul2(x[3], w2, x[7], w2, x[3], x[7]); // V < 13/169 + 1 = 1.08 ; V < 1.03
+    n29_carry(x[0]); n29_carry(x[1]);         // V < 12
+    n29_carry(x[2]);                          // V < 13
+    n29_carry(x[4]);                          // V < 8.05
+    n29_carry(x[6]);                          // V < 10
+    // (x[5]: V < 2.1, L < 2^30 - 1: a sum of two exact values -- within f29_sub's limb bound as it is)
+    // level 3.  (0,1): V < 12 each: u V < 24, d = a - b + 13p V < 25.  (2,3): a V < 13, b V < 1.08: u V < 14.1, d (+3p) V < 16.
+    // (4,5): a V < 8.05, b V < 2.1: u V < 10.2, d (+4p) V < 12.05.  (6,7): a V < 10, b V < 1.03: u V < 11.03, d (+3p) V < 13.
+    n29_bfly<13>(x[0], x[1]);
+    n29_bfly<3>(x[2], x[3]);
+    n29_bfly<4>(x[4], x[5]);
+    n29_bfly<3>(x[6], x[7]);
+    if constexpr (HAVE_TW) {
+        // the step twiddles: operands V < 25, L < 2^31 + 8 (a difference of carried values) -> products V < 25/169 + 1 = 1.15
+        f29_mul2(x[1], tw[1], x[2], tw[2], x[1], x[2]);
+        f29_mul2(x[3], tw[3], x[4], tw[4], x[3], x[4]);
+        f29_mul2(x[5], tw[5], x[6], tw[6], x[5], x[6]);
+        x[7] = f29_mul(x[7], tw[7]);
+        x[0] = ntt29_reduce(x[0], red); // V < 24 -> < 3
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = ntt29_reduce(x[j], red); // every register leaves below 3p, carried
+    }
+}
+
+} // namespace bbg

@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip extra.config5 (one 2^24 MSM + one 2^24 coset NTT, strong scaling)")
     ap.add_argument("--no-prover-shaped", action="store_true", help="skip extra.prover_shaped (BASELINE config 4 on the resident prover rounds)")
     ap.add_argument("--config5-log2n", type=int, default=24)
+    ap.add_argument("--real-prover-log2", type=int, default=16, help="cpu_baseline.real_prover: gates of the reference TurboPLONK circuit proved on the host "
+                    "cores and through the link-time shim (0 = skip; 2^20 takes ~1 min of circuit construction)")
     ap.add_argument("--no-sweeps", action="store_true", help="skip extra.host_path / extra.ntt_sweep / extra.msm_sweep (SURVEY 8d tables)")
     ap.add_argument("--reduce-priority", type=int, default=-1, help="A/B: 1 = low-priority auxiliary stream for the MSM reduce phase (library default), 0 = normal")
     ap.add_argument("--msm-window", type=int, default=0, help="bucket window width: 0 = library default, or a compiled width (A/B runs)")
@@ -340,6 +342,11 @@ def main():
     # ---- CPU baseline + bit-exact check against it (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, value)
+        if args.real_prover_log2 and out["cpu_baseline"].get("kind") == "reference":
+            try:  # main thread only: the reference's OpenMP state (see reference_prover_sequence below)
+                out["cpu_baseline"]["real_prover"] = real_prover_baseline(args.real_prover_log2)
+            except Exception as e:  # noqa: BLE001 -- reported in the line, never raised
+                out["cpu_baseline"]["real_prover"] = {"error": "%s: %s" % (type(e).__name__, e)}
     # The extras below must never cost the run its line: each runs under a guard (exception -> {"error": ...}; no answer within
     # the limit, e.g. a rank stuck in a collective -> {"error": "timeout"}, the line is printed and the process leaves without
     # waiting for the stuck call).
@@ -384,6 +391,10 @@ def main():
     # ---- the PCIe-inclusive drop-in entry points (host buffers in / out), one GPU
     if rank == 0 and world == 1 and not args.no_sweeps and not stuck:
         extra["host_path"] = guarded("host_path", lambda: host_path(pkg, bbg, srs, lg), 120)
+        rp = out.get("cpu_baseline", {}).get("real_prover", {})
+        if "error" not in extra["host_path"] and "link_only_ms" in rp:  # the unmodified prover through the link-time shim (cpu_baseline.real_prover)
+            extra["host_path"]["shim_linked_proof_ms"] = {"log2_gates": rp["log2_gates"], "msm_fft_wrapped_only": rp["link_only_ms"],
+                                                          "construct_proof_wrapped_too": rp["wrapped_zero_edits_ms"], "reference_cpu": rp["cpu_ms"]}
     # ---- BASELINE config 5: ONE 2^24 MSM + ONE 2^24 coset NTT over the N GPUs (strong scaling: total work fixed as N grows)
     if not args.no_config5 and not stuck:
         srs.free()
@@ -701,6 +712,59 @@ def reference_prover_sequence(srs, scalars, coeffs, lg):
     dom.free()
     return {"total_ms": round((t_msm + t_ifft + t_cfft + t_cifft) * 1e3, 1), "msm_x11_ms": round(t_msm * 1e3, 1), "ifft_x5_ms": round(t_ifft * 1e3, 1),
             "coset_fft_4n_x5_ms": round(t_cfft * 1e3, 1), "coset_ifft_4n_ms": round(t_cifft * 1e3, 1), "threads": ref.num_threads()}
+
+
+def real_prover_baseline(log2_gates):
+    """CPU baseline leg: the reference's REAL TurboPLONK prover (its own composer, prover and verifier compiled from /root/reference into
+    oracle/_ref) on a 2^log2_gates-gate circuit -- on the host cores as shipped, and the SAME driver object linked with the shim
+    (oracle/_ref/libbbprover_wrap.so: MSM / FFT entry points and construct_proof() wrapped at link time, zero source edits), first with the
+    prover wrap switched off (link-only: the round arithmetic stays on the host), then on.  The wrapped proof replays the blinding scalars
+    the CPU proof drew and must equal it byte for byte; every proof is verified by the reference verifier."""
+    from oracle.oracle import Oracle, RefProver, PROVER_WRAP_SO, prover_available
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        return {"error": "oracle/_ref/libbbprover[_wrap].so not shipped"}
+    O = Oracle()
+    x = O.to_mont(0, np.array([[0x1234567890ABCDEF, 0xFEDCBA, 0, 0]], dtype=np.uint64))[0]
+    gates = (1 << log2_gates) - 64
+    pts = O.srs_powers(x, (1 << log2_gates) + 2)
+    A = RefProver(gates, 11, pts, x)
+    t0 = time.perf_counter()
+    cpu, blind = A.prove_recording()
+    t_cpu = time.perf_counter() - t0
+    ok = [A.verify()]
+    threads = A.threads
+    A.free()
+    W = RefProver(gates, 11, pts, x, wrap_linked=True)
+    try:
+        W.wrap_set_enabled(False)
+        W.prove_reference()  # warm-up of the link-only path: window tables, twiddles, scratch
+        W.lib.refp_reset(W.h)
+        t0 = time.perf_counter()
+        W.prove_reference()
+        t_link = time.perf_counter() - t0
+        ok.append(W.verify())
+    finally:
+        W.wrap_set_enabled(True)
+        W.free()
+    W = RefProver(gates, 11, pts, x, wrap_linked=True)
+    t0 = time.perf_counter()
+    got = W.prove_reference(replay=blind)
+    t_first = time.perf_counter() - t0
+    ok.append(W.verify())
+    warm = []
+    for _ in range(5):
+        W.lib.refp_reset(W.h)
+        t0 = time.perf_counter()
+        W.prove_reference()
+        warm.append(time.perf_counter() - t0)
+    ok.append(W.verify())
+    W.free()
+    W.wrap_trim()
+    t_wrap = sorted(warm)[2]
+    return {"prover": "TurboPLONK (TurboComposer::create_prover), reference build, arithmetic circuit", "log2_gates": log2_gates, "host_threads": threads,
+            "cpu_ms": round(t_cpu * 1e3, 1), "link_only_ms": round(t_link * 1e3, 1), "wrapped_zero_edits_first_ms": round(t_first * 1e3, 1),
+            "wrapped_zero_edits_ms": round(t_wrap * 1e3, 2), "byte_identical_to_cpu_proof": got == cpu, "verified": ok,
+            "speedup_wrapped_vs_cpu": round(t_cpu / t_wrap, 1)}
 
 
 def cpu_baseline(pkg, bbg, srs, scalars, coeffs, d_result, d_coeffs, lg, gpu_value):

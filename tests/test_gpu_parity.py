@@ -1178,7 +1178,7 @@ def test_bench_contract_and_dist_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BBG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     env.pop("MASTER_PORT", None)  # bench.py picks a free port for its world of one: two suites on one box cannot collide
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "16", "--config5-log2n", "18"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--log2n", "16", "--config5-log2n", "18", "--real-prover-log2", "10"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
@@ -1190,6 +1190,11 @@ def test_bench_contract_and_dist_path():
     assert out["roofline"]["frac"] > 0 and out["value"] > 0
     assert len(out["extra"]["timed_blocks_ms"]) == 5 and abs(out["ms_per_step"] * 3 - sorted(out["extra"]["timed_blocks_ms"])[2]) < 1e-2
     assert out["extra"]["prover_shaped"]["proof_ms"] > 0 and out["extra"]["config5"]["msm_ms"] > 0 and out["extra"]["config5"]["ntt_ms"] > 0
+    assert "profile_matches_build" in out["roofline"] and "profile_stamp" in out["extra"]
+    rp = out["cpu_baseline"].get("real_prover")
+    if rp is not None and "error" not in rp:  # oracle/_ref prover libraries shipped: the real reference prover, CPU vs link-time shim
+        assert rp["byte_identical_to_cpu_proof"] is True and rp["verified"] == [1, 1, 1, 1] and rp["wrapped_zero_edits_ms"] < rp["link_only_ms"]
+        assert out["extra"]["host_path"]["shim_linked_proof_ms"]["construct_proof_wrapped_too"] == rp["wrapped_zero_edits_ms"]
 
 
 @pytest.mark.parametrize("G,lg,inverse,coset", [(2, 12, False, False), (4, 12, False, True), (8, 13, False, False), (8, 12, True, False),

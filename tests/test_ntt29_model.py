@@ -1,0 +1,222 @@
+"""CPU model of the lazily reduced 29-bit-limb radix-8 NTT step (csrc/ntt29.hip.h) with Python integers, for the FIELD Fr.
+
+Like tests/test_limb29_model.py for the bucket accumulation: random GPU data cannot show that the lazy representation never overflows (a limb
+leaving 32 bits, a column sum leaving 64, a subtraction limb going negative, a value leaving the bound its consumer was sized for, the
+table-driven reduction picking a row whose borrowed top limb goes negative).  The model restates n29_step8 / ntt29_reduce operation by
+operation with assertions on exactly those events and on every bound stated in the header's comments, drives it with random values, with
+inputs pushed to the stated entry bound (every register just below 3p, every limb as large as `carried` allows), and through chains of
+steps, and checks every output against plain modular arithmetic.  Test infrastructure only: the product never runs it."""
+import random
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001  # BN254 Fr (fr.hpp:12-15)
+M29 = (1 << 29) - 1
+R1 = 1 << 261
+INV29 = (-pow(R_MOD, -1, 1 << 29)) % (1 << 29)
+U32, U64 = 1 << 32, 1 << 64
+P = R_MOD
+
+
+def limbs(v):
+    assert 0 <= v < (1 << (29 * 8 + 32))
+    return [(v >> (29 * j)) & M29 for j in range(8)] + [v >> 232]
+
+
+def val(a):
+    return sum(x << (29 * i) for i, x in enumerate(a))
+
+
+P29 = limbs(P)
+P_TOP = P >> 232
+INV_TOP = (1 << 32) // (P_TOP + 1)
+
+
+def carry(a):
+    assert all(0 <= x < U32 for x in a)
+    r = [a[0] & M29] + [(a[i] & M29) + (a[i - 1] >> 29) for i in range(1, 8)] + [a[8] + (a[7] >> 29)]
+    assert all(x < U32 for x in r) and val(r) == val(a)
+    return r
+
+
+def add(a, b):
+    r = [x + y for x, y in zip(a, b)]
+    assert all(x < U32 for x in r), "limb overflow in f29_add"
+    return r
+
+
+def spread(mult, e=30):
+    q = limbs(mult * P)
+    up, down = 1 << e, 1 << (e - 29)
+    s = [q[0] + up] + [q[j] + up - down for j in range(1, 8)] + [q[8] - down]
+    assert val(s) == mult * P and s[8] >= 0
+    return s
+
+
+def sub(a, b, mult):
+    s = spread(mult)
+    r = []
+    for x, y, c in zip(a, b, s):
+        assert c - y >= 0, "subtrahend limb above the spread constant"
+        t = x + (c - y)
+        assert t < U32, "limb overflow in f29_sub"
+        r.append(t)
+    assert val(r) == val(a) - val(b) + mult * P
+    return r
+
+
+def mul(a, b):
+    acc, m, r = 0, [0] * 9, [0] * 9
+    for k in range(17):
+        lo, hi = max(0, k - 8), min(k, 8)
+        for i in range(lo, hi + 1):
+            acc += a[i] * b[k - i]
+            assert acc < U64, "column overflow (a*b)"
+        for i in range(lo, hi + 1 if k > 8 else k):
+            acc += m[i] * P29[k - i]
+            assert acc < U64, "column overflow (m*p)"
+        if k <= 8:
+            m[k] = ((acc & 0xFFFFFFFF) * INV29) & M29
+            acc += m[k] * P29[0]
+            assert acc < U64 and acc & M29 == 0
+        else:
+            r[k - 9] = acc & M29
+        acc >>= 29
+    assert acc < U32
+    r[8] = acc
+    assert (val(r) * R1 - val(a) * val(b)) % P == 0 and val(r) < val(a) * val(b) // R1 + P + 1
+    return r
+
+
+def reduce_table():
+    rows = []
+    for k in range(32):
+        kp = limbs(k * P)
+        zs = [1 << 30] + [(1 << 30) - 2] * 7 + [-2]
+        rows.append([0] * 9 if k == 0 else [(z - x) % U32 for z, x in zip(zs, kp)])
+    return rows
+
+
+RED = reduce_table()
+
+
+def reduce(x):  # ntt29_reduce: value < 32p in, carried value < 3p out
+    assert val(x) < 32 * P
+    c = carry(x)
+    q = (c[8] * INV_TOP) >> 32
+    assert q <= val(x) // P <= q + 1, "quotient estimate off by more than one"
+    k = q - 1 if q > 1 else 0
+    row = RED[k]
+    t = []
+    for i, (a, b) in enumerate(zip(c, row)):
+        s = (a + b) % U32
+        if i < 8:
+            assert a + b < U32, "limb overflow in the reduction"
+        elif k:
+            assert a - 2 - (k * P >> 232) >= 0, "top limb of the reduction went negative"
+        t.append(s)
+    assert val(t) == val(x) - k * P
+    r = carry(t)
+    assert val(r) < 3 * P and max(r[:8]) < (1 << 29) + 8
+    return r
+
+
+def vbound(a, v):  # value < v p (v may be fractional: checked with integers)
+    assert val(a) * 1000 < int(v * 1000) * P + P, ("value bound", val(a) / P, v)
+
+
+def step8(x, w1, w2, w3, tw):  # n29_step8<true>
+    for a in x:
+        vbound(a, 3)
+        assert max(a[:8]) < (1 << 29) + 8
+    x = [list(a) for a in x]
+
+    def bfly(i, j, k):
+        u, d = add(x[i], x[j]), sub(x[i], x[j], k)
+        x[i], x[j] = u, d
+    for i in range(4):
+        bfly(i, i + 4, 4)
+    x[5], x[6], x[7] = mul(x[5], w1), mul(x[6], w2), mul(x[7], w3)
+    for j in (5, 6, 7):
+        vbound(x[j], 1.05)
+    for j in range(5):
+        x[j] = carry(x[j])
+    for j in range(4):
+        vbound(x[j], 6)
+    vbound(x[4], 7)
+    bfly(0, 2, 7); bfly(1, 3, 7); bfly(4, 6, 3); bfly(5, 7, 3)
+    x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
+    vbound(x[3], 1.08); vbound(x[7], 1.03)
+    for j in (0, 1, 2, 4, 6):
+        x[j] = carry(x[j])
+    vbound(x[0], 12); vbound(x[1], 12); vbound(x[2], 13); vbound(x[4], 8.05); vbound(x[6], 10); vbound(x[5], 2.1)
+    bfly(0, 1, 13); bfly(2, 3, 3); bfly(4, 5, 4); bfly(6, 7, 3)
+    for j, v in enumerate((24, 25, 14.1, 16, 10.2, 12.05, 11.03, 13)):
+        vbound(x[j], v)
+    for j in range(1, 8):
+        x[j] = mul(x[j], tw[j])
+        vbound(x[j], 1.15)
+    x[0] = reduce(x[0])
+    return x
+
+
+def step8_mod(x, w1, w2, w3, tw):  # the same butterfly on residues (x R' form: a product with a table value w R' divides by R' again)
+    rinv = pow(R1, -1, P)
+    x = list(x)
+
+    def b(i, j, w=None):
+        u, d = (x[i] + x[j]) % P, (x[i] - x[j]) % P
+        x[i], x[j] = u, d if w is None else d * w * rinv % P
+    b(0, 4); b(1, 5, w1); b(2, 6, w2); b(3, 7, w3)
+    b(0, 2); b(1, 3, w2); b(4, 6); b(5, 7, w2)
+    b(0, 1); b(2, 3); b(4, 5); b(6, 7)
+    for j in range(1, 8):
+        x[j] = x[j] * tw[j] * rinv % P
+    return x
+
+
+def exact(v):  # a table value: exact limbs, < p
+    assert v < P
+    return limbs(v)
+
+
+def test_reduce_table_and_estimate_over_the_whole_range():
+    rng = random.Random(29)
+    for k in range(32):
+        for x in (k * P, k * P + 1, (k + 1) * P - 1, k * P + rng.randrange(P)):
+            if x < 32 * P:
+                r = reduce(limbs(x))
+                assert val(r) % P == x % P
+    # lazily carried inputs: limbs above 29 bits
+    for _ in range(2000):
+        a, b = limbs(rng.randrange(16 * P)), limbs(rng.randrange(16 * P))
+        r = reduce(add(a, b))
+        assert val(r) % P == (val(a) + val(b)) % P
+
+
+def test_step8_random_and_chained():
+    rng = random.Random(2929)
+    for trial in range(60):
+        w = [exact(rng.randrange(P)) for _ in range(3)]
+        tw = [None] + [exact(rng.randrange(P)) for _ in range(7)]
+        x = [limbs(rng.randrange(2 * P)) for _ in range(8)]  # what a device array holds: coarse residues < 2p, re-limbed
+        ref = [val(a) % P for a in x]
+        for _ in range(6):  # six dependent steps: the outputs of one are the inputs of the next
+            x = step8(x, w[0], w[1], w[2], tw)
+            ref = step8_mod(ref, val(w[0]), val(w[1]), val(w[2]), [0] + [val(t) for t in tw[1:]])
+            assert [val(a) % P for a in x] == ref
+
+
+def test_step8_at_the_entry_bounds():
+    """Every register just below 3p with every limb as large as a carried value allows; twiddles p - 1 (the largest table value)."""
+    big = 3 * P - 1
+    fat = limbs(big)
+    # move weight downwards: limb i gives 1 to limb i-1 as 2^29 where that keeps limb i-1 below 2^29 + 8
+    for i in range(8, 0, -1):
+        if fat[i] > 0 and fat[i - 1] + (1 << 29) < (1 << 29) + 8:
+            fat[i] -= 1
+            fat[i - 1] += 1 << 29
+    assert val(fat) == big
+    wmax = exact(P - 1)
+    for x in ([fat] * 8, [limbs(big)] * 8, [limbs(0)] * 8, [limbs(big)] + [limbs(0)] * 7, [limbs(0)] * 7 + [limbs(big)]):
+        out = step8([list(a) for a in x], wmax, wmax, wmax, [None] + [wmax] * 7)
+        ref = step8_mod([val(a) % P for a in x], P - 1, P - 1, P - 1, [0] + [P - 1] * 7)
+        assert [val(a) % P for a in out] == ref
