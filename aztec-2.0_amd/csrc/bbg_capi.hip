@@ -279,6 +279,11 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->msm_sort = (int)value;
         return BBG_OK;
     }
+    if (!strcmp(key, "ntt_limbs29")) { // a launch-time choice between kernels over the same plan and tables
+        if (value < -1 || value > 1) { set_error("ntt_limbs29 must be -1 (automatic), 0 or 1"); return BBG_E_INVALID; }
+        ctx->ntt_limbs29 = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "ntt_lds_planes")) { // a launch-time choice between two kernels over the same plan: no domain is rebuilt
         if (value < 0 || value > 2) { set_error("ntt_lds_planes must be 0 (automatic), 1 or 2"); return BBG_E_INVALID; }
         ctx->ntt_lds_planes = (int)value;

@@ -38,6 +38,7 @@ struct NttDomain {
     void* consts = nullptr;                          // DomainConsts (device)
     void* tw_inter[2][NTT_MAX_PASSES] = {};          // [inverse][pass]: omega_{N_q}^{i*lo}, N_q entries (passes 0..p-2)
     void* tw_radix[2][NTT_MAX_PASSES] = {};          // [inverse][pass]: omega_{R_q}^j, R_q/2 entries
+    void* tw_radix29[2][NTT_MAX_PASSES] = {};        // the same entries times 32 (R'-form, canonical): multipliers of the 29-bit-limb pass kernel
     void* coset_fwd = nullptr;                       // g^j, j < n
     void* coset_inv = nullptr;                       // n^-1 * g^-j, j < n
     size_t bytes = 0;
@@ -124,6 +125,8 @@ struct bbg_ctx {
     int ntt_max_logr8 = 10;  // max log-radix per pass for k_ntt_pass8
     int ntt_big_tile = 1;    // option "ntt_big_tile": 1 = 2^21 as TWO passes over 4096-element tiles instead of three over 2048; 2 = 2^22 as well; 0 = never
     int ntt_lds_planes = 0;  // option "ntt_lds_planes": 2 = the tile stays in LDS between two steps (k_ntt_pass8), 1 = it moves one 16-byte plane at a time (k_ntt_pass8s: half the LDS, three blocks per CU), 0 = automatic (1 from 2^22)
+    int ntt_limbs29 = -1;    // option "ntt_limbs29": 1 = pass arithmetic on lazily reduced 9 x 29-bit limbs (k_ntt_pass29), 0 = 8 x 32-bit (k_ntt_pass8 / 8s), -1 = automatic
+    bool ntt_attr29_set = false;
     bool ntt_attr8s_set = false;
     bool ntt_attr8_set = false, ntt_attr_set = false; // dynamic-LDS attributes of the pass kernels set on this context's device
 };

@@ -204,6 +204,7 @@ struct PassParams {
     Fr* out;
     const Fr* tw_inter; // [R][S] table or nullptr
     const Fr* tw_radix; // R/2 entries
+    const Fr* tw_radix29; // the same R entries as w R' mod p, canonical (k_ntt_pass29: ntt29.hip.h)
     const Fr* post;     // optional per-output-element multiplier table indexed by natural output index (row pass only)
     const Fr* pre;      // first (column) pass of k_ntt_pass8: input element g < pre_count is multiplied by pre[g] as it is loaded
     size_t pre_count;   //   (coset_fft's a_j *= g^j for j < generator_size, polynomial_arithmetic.cpp:395-399, fused into the load)
@@ -338,10 +339,25 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(PassParams p)
 
 } // namespace bbg
 #include "ntt_pass8.hip.h"
+#include "ntt_pass29.hip.h"
 namespace bbg {
+// out[j] = in[j] * 32 (canonical): w R -> w R' for R' = 2^261 = 32 R, the multiplier form of the 29-bit-limb pass kernel
+__global__ void k_to_rprime(Fr* out, const Fr* in, size_t count)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    Fr c = Fr::zero();
+    c.v[0] = 32;
+    fe_store<FrP>(out + idx, fe_canon(fe_mul(fe_load<FrP>(in + idx), fe_to_mont(c))));
+}
 
 // ------------------------------------------------------------------------------------------ host side
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
+
+// sizes at which the 29-bit-limb pass kernel is the automatic choice (option ntt_limbs29 = -1).  Measured, isolated fft, ms
+// (profiles/r04_ntt29_ab.txt; best 32-bit kernel -> k_ntt_pass29): 2^18 0.0629 -> 0.0654 (loses: one pass of a small grid), 2^20 0.1229 -> 0.1187,
+// 2^21 0.2545 -> 0.2441, 2^22 0.4761 -> 0.4548, 2^23 0.9377 -> 0.8963, 2^24 1.8875 -> 1.8761.
+#define NTT_LIMBS29_AUTO(log2n) ((log2n) >= 20)
 
 static void plan_passes(bbg_ctx* ctx, NttDomain& d)
 {
@@ -428,6 +444,7 @@ void ntt_free_domain(NttDomain& d)
         for (int q = 0; q < NTT_MAX_PASSES; q++) {
             if (d.tw_inter[inv][q]) (void)hipFree(d.tw_inter[inv][q]);
             if (d.tw_radix[inv][q]) (void)hipFree(d.tw_radix[inv][q]);
+            if (d.tw_radix29[inv][q]) (void)hipFree(d.tw_radix29[inv][q]);
         }
     if (d.coset_fwd) (void)hipFree(d.coset_fwd);
     if (d.coset_inv) (void)hipFree(d.coset_inv);
@@ -462,6 +479,11 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
             d.bytes += half * sizeof(Fr);
             hipLaunchKernelGGL(k_twiddle_1d, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix[inv][q], pow2, half,
                                (uint64_t)(n >> logR));
+            if (d.use_pass8) { // the same table in R'-form for k_ntt_pass29 (R <= 2048 entries: 64 KB)
+                BBG_HIP(hipMalloc(&d.tw_radix29[inv][q], half * sizeof(Fr)));
+                d.bytes += half * sizeof(Fr);
+                hipLaunchKernelGGL(k_to_rprime, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix29[inv][q], (const Fr*)d.tw_radix[inv][q], half);
+            }
             if (q < d.passes - 1) {
                 // inter-pass twiddles w_{N_q}^(i*lo), N_q = R*S ; w_{N_q} = w_n^(n/N_q): use the pow2 table shifted
                 const int logN = logR + logS;
@@ -508,6 +530,7 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     p.logW = d.logW[q];
     p.log2n = (int)d.log2n;
     p.tw_radix = (const Fr*)d.tw_radix[inverse][q];
+    p.tw_radix29 = (const Fr*)d.tw_radix29[inverse][q];
     p.post = post;
     p.row_pass = (q == d.passes - 1);
     int logS = (int)d.log2n;
@@ -530,6 +553,34 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
             attr8 = true;
         }
         ProfScope ps(ctx, "ntt_pass", st);
+        if (ctx->ntt_limbs29 == 1 || (ctx->ntt_limbs29 == -1 && NTT_LIMBS29_AUTO(d.log2n))) { // the pass on lazily reduced 29-bit limbs (ntt_pass29.hip.h)
+            bool& attr29 = ctx->ntt_attr29_set;
+            if (!attr29) {
+                BBG_HIP(p29_attr<3>()); BBG_HIP(p29_attr<4>()); BBG_HIP(p29_attr<5>()); BBG_HIP(p29_attr<6>()); BBG_HIP(p29_attr<7>());
+                BBG_HIP(p29_attr<8>()); BBG_HIP(p29_attr<9>()); BBG_HIP(p29_attr<10>()); BBG_HIP(p29_attr<11>());
+                BBG_HIP((p29_attr<10, P8_TILE_LOG_BIG>())); BBG_HIP((p29_attr<11, P8_TILE_LOG_BIG>()));
+                attr29 = true;
+            }
+            if (d.tile_log8 == P8_TILE_LOG_BIG) {
+                if (p.logR == 11) p29_launch<11, P8_TILE_LOG_BIG>(p, tiles, st);
+                else if (p.logR == 10) p29_launch<10, P8_TILE_LOG_BIG>(p, tiles, st);
+                else { set_error("ntt: bad pass8 radix for the 4096-element tile"); return BBG_E_INVALID; }
+                return BBG_OK;
+            }
+            switch (p.logR) {
+            case 3: p29_launch<3>(p, tiles, st); break;
+            case 4: p29_launch<4>(p, tiles, st); break;
+            case 5: p29_launch<5>(p, tiles, st); break;
+            case 6: p29_launch<6>(p, tiles, st); break;
+            case 7: p29_launch<7>(p, tiles, st); break;
+            case 8: p29_launch<8>(p, tiles, st); break;
+            case 9: p29_launch<9>(p, tiles, st); break;
+            case 10: p29_launch<10>(p, tiles, st); break;
+            case 11: p29_launch<11>(p, tiles, st); break;
+            default: set_error("ntt: bad pass8 radix"); return BBG_E_INVALID;
+            }
+            return BBG_OK;
+        }
         // one-plane exchange (ntt_pass8.hip.h: k_ntt_pass8s: half the LDS, three waves per SIMD): automatic from 2^22 (measured there)
         if (ctx->ntt_lds_planes == 1 || (ctx->ntt_lds_planes == 0 && d.log2n >= 22)) {
             bool& attr8s = ctx->ntt_attr8s_set;

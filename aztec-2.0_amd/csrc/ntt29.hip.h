@@ -81,8 +81,10 @@ __device__ __forceinline__ void n29_carry(Fr29& a) { a = f29_carry(a); }
 // the multiplier of register j; pass nullptr-like `have_tw = false` for a step without them) and the reduction of register 0.
 //   in : x[j] carried, V < 3 (a reduced or freshly loaded value), w1 = w8, w2 = w8^2 = w4, w3 = w8^3 in reduced R'-form (< p, exact limbs)
 //   out: x[0] carried, V < 3; x[1..7] products, V < 1.2 (with step twiddles) or as listed below (without)
-template <bool HAVE_TW>
-__device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const Fr29& w1, const Fr29& w2, const Fr29& w3, const Fr29 (&tw)[8], const uint32_t* red)
+// `tw(j)` delivers the step twiddle of register j when the product is about to use it (a table load for the pass kernel: seven multipliers
+// held at once are 63 registers the kernel does not have at three waves per SIMD)
+template <bool HAVE_TW, class TW>
+__device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const Fr29& w1, const Fr29& w2, const Fr29& w3, TW tw, const uint32_t* red)
 {
     // level 1: inputs V < 3 carried.  u: V < 6, L < 2^30 + 16.  d = a - b + 4p: V < 7, L < 2^31 + 8.
     n29_bfly<4>(x[0], x[4]);
@@ -113,15 +115,90 @@ __device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const Fr29& w1, const Fr
     n29_bfly<3>(x[6], x[7]);
     if constexpr (HAVE_TW) {
         // the step twiddles: operands V < 25, L < 2^31 + 8 (a difference of carried values) -> products V < 25/169 + 1 = 1.15
-        f29_mul2(x[1], tw[1], x[2], tw[2], x[1], x[2]);
-        f29_mul2(x[3], tw[3], x[4], tw[4], x[3], x[4]);
-        f29_mul2(x[5], tw[5], x[6], tw[6], x[5], x[6]);
-        x[7] = f29_mul(x[7], tw[7]);
+        {
+            const Fr29 t1 = tw(1), t2 = tw(2);
+            f29_mul2(x[1], t1, x[2], t2, x[1], x[2]);
+        }
+        {
+            const Fr29 t3 = tw(3), t4 = tw(4);
+            f29_mul2(x[3], t3, x[4], t4, x[3], x[4]);
+        }
+        {
+            const Fr29 t5 = tw(5), t6 = tw(6);
+            f29_mul2(x[5], t5, x[6], t6, x[5], x[6]);
+        }
+        x[7] = f29_mul(x[7], tw(7));
         x[0] = ntt29_reduce(x[0], red); // V < 24 -> < 3
     } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = ntt29_reduce(x[j], red); // every register leaves below 3p, carried
     }
+}
+
+// The LAST step of a pass whose log-radix is not a multiple of 3 transforms two bits or one (p8_butterfly<2> / <1>): no step twiddles, the
+// outputs leave for the pass's final multiplication / conversion.  in: x[j] carried, V < 3.
+//   S = 2: radix-4 on (b1 b0) -- pairs (0,2), (1,3) w4, (4,6), (5,7) w4, then (0,1), (2,3), (4,5), (6,7).  out: V < 13, L < 2^31 + 8.
+//   S = 1: pairs (0,1), (2,3), (4,5), (6,7).                                                              out: V < 7,  L < 2^31 + 8.
+__device__ __forceinline__ void n29_step4(Fr29 (&x)[8], const Fr29& w2)
+{
+    // level A: u V < 6, d = a - b + 4p V < 7
+    n29_bfly<4>(x[0], x[2]);
+    n29_bfly<4>(x[1], x[3]);
+    n29_bfly<4>(x[4], x[6]);
+    n29_bfly<4>(x[5], x[7]);
+    f29_mul2(x[3], w2, x[7], w2, x[3], x[7]); // V < 7/169 + 1 = 1.05
+    n29_carry(x[0]); n29_carry(x[1]); n29_carry(x[4]); n29_carry(x[5]); // V < 6
+    n29_carry(x[2]); n29_carry(x[6]);                                   // V < 7
+    // level B: (0,1), (4,5): a, b V < 6: u V < 12, d (+7p) V < 13.  (2,3), (6,7): a V < 7, b V < 1.05 exact: u V < 8.05, d (+3p) V < 10.
+    n29_bfly<7>(x[0], x[1]);
+    n29_bfly<3>(x[2], x[3]);
+    n29_bfly<7>(x[4], x[5]);
+    n29_bfly<3>(x[6], x[7]);
+}
+__device__ __forceinline__ void n29_step2(Fr29 (&x)[8])
+{
+    n29_bfly<4>(x[0], x[1]);
+    n29_bfly<4>(x[2], x[3]);
+    n29_bfly<4>(x[4], x[5]);
+    n29_bfly<4>(x[6], x[7]);
+}
+// A radix-8 step WITHOUT step twiddles (the last step of a pass whose log-radix is a multiple of 3): n29_step8<false> reduces every register;
+// when a final multiplication follows, the reduction can wait for it: out V < 25, L < 2^31 + 8 (see n29_step8's level 3).
+__device__ __forceinline__ void n29_step8_raw(Fr29 (&x)[8], const Fr29& w1, const Fr29& w2, const Fr29& w3)
+{
+    n29_bfly<4>(x[0], x[4]);
+    n29_bfly<4>(x[1], x[5]);
+    n29_bfly<4>(x[2], x[6]);
+    n29_bfly<4>(x[3], x[7]);
+    f29_mul2(x[5], w1, x[6], w2, x[5], x[6]);
+    x[7] = f29_mul(x[7], w3);
+    n29_carry(x[0]); n29_carry(x[1]); n29_carry(x[2]); n29_carry(x[3]);
+    n29_carry(x[4]);
+    n29_bfly<7>(x[0], x[2]);
+    n29_bfly<7>(x[1], x[3]);
+    n29_bfly<3>(x[4], x[6]);
+    n29_bfly<3>(x[5], x[7]);
+    f29_mul2(x[3], w2, x[7], w2, x[3], x[7]);
+    n29_carry(x[0]); n29_carry(x[1]);
+    n29_carry(x[2]);
+    n29_carry(x[4]);
+    n29_carry(x[6]);
+    n29_bfly<13>(x[0], x[1]);
+    n29_bfly<3>(x[2], x[3]);
+    n29_bfly<4>(x[4], x[5]);
+    n29_bfly<3>(x[6], x[7]);
+}
+
+// ---- the way out of a pass.  x: V < 25, L < 2^31 + 8 (any output of the last step).  With a multiplier (inter-pass twiddle / post-scale table
+// entry, the R-form words of the table shifted by 5 bits: w R' as an integer < 64 p, exact limbs): product V < 25 * 64 / 169 + 1 = 10.5, then the
+// table reduction (V < 3), exact limbs, the 8 words, one conditional subtraction -> the coarse [0, 2p) residue the device arrays hold.
+__device__ __forceinline__ Fr n29_finish(const Fr29& x, const uint32_t* red)
+{
+    return fe_reduce_once(f29_to_fe(ntt29_reduce(x, red)));
+}
+__device__ __forceinline__ Fr n29_finish_mul(const Fr29& x, const Fr& mult_rform, const uint32_t* red)
+{
+    return n29_finish(f29_mul(x, f29_from_fe<FrP, 5>(mult_rform)), red);
 }
 
 } // namespace bbg

@@ -1,0 +1,196 @@
+// k_ntt_pass29: the NTT pass of k_ntt_pass8s (ntt_pass8.hip.h: 2048- / 4096-element tiles, 8 elements per thread in registers, radix-8 steps,
+// one-plane-at-a-time exchange, three waves per SIMD) with every step's arithmetic on LAZILY REDUCED 9 x 29-bit limbs (ntt29.hip.h).
+//
+// Same contract, same positions, same global addressing as k_ntt_pass8 / k_ntt_pass8s; what differs is what a register holds between the
+// load and the store: F29<FrP> values of (x / 32) in R'-Montgomery form (the 256 stored bits re-limbed -- ntt29.hip.h), 9 words each.  An
+// exchange therefore moves 36 bytes per element: the low four limbs through the plane buffer, limb 8 through a buffer of its own IN THE SAME
+// ROUND (separate LDS arrays, no extra barrier), then limbs 4..7 through the plane buffer.  LDS: 36 864 + 9 216 B of buffers + 1 536 B of
+// reduction table = 47.6 KB per 256-thread block, three blocks per CU.
+//
+// Results are the same residues as the 32-bit kernels give (the representative may differ: both are coarse, < 2p); the parity tests compare
+// canonical values against the oracle and the reference digests with this kernel selected (option "ntt_limbs29").
+#pragma once
+#include "ntt29.hip.h"
+
+namespace bbg {
+
+template <int TL> constexpr size_t p29_lds_bytes() { return (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_RED_ROWS * NTT29_RED_ROW * 4; }
+
+__device__ __forceinline__ Fr29 p29_load_tw(const Fr* __restrict__ tw29, int idx) { return f29_from_fe<FrP, 0>(fe_load<FrP>(tw29 + idx)); } // < p: exact limbs
+
+// butterfly of step T + its step twiddles (p8s_compute's structure on F29 values).  `raw_last`: a LAST step with S = 3 leaves its outputs
+// un-reduced for the pass's final multiplication / reduction (n29_step8_raw)
+template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)[8], const Fr* __restrict__ tw29, int qlo, const uint32_t* red)
+{
+    constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
+    constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    if constexpr (S == 3) {
+        const Fr29 w1 = p29_load_tw(tw29, 1 << (LOGR - 3)), w2 = p29_load_tw(tw29, 1 << (LOGR - 2)), w3 = p29_load_tw(tw29, 3 << (LOGR - 3));
+        if constexpr (F > 0) {
+            constexpr int DONE = LOGR - 3 - F;
+            n29_step8<true>(x, w1, w2, w3, [&](int j) { return p29_load_tw(tw29, (p8_brev3(j) * qlo) << DONE); }, red);
+        } else {
+            n29_step8_raw(x, w1, w2, w3);
+        }
+    } else if constexpr (S == 2) {
+        n29_step4(x, p29_load_tw(tw29, 1 << (LOGR - 2)));
+    } else {
+        n29_step2(x);
+    }
+}
+
+// x: the 8 elements of step T (in place) -> the 8 elements of step T + 1.  Every value that crosses is a valid step input (V < 3, limbs below
+// 2^29 + 8): a product, or a reduced register 0.
+template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29_exchange(Fr29 (&x)[8], uint4* buf, uint32_t* buf8)
+{
+    constexpr int LOGW = TL - LOGR;
+    constexpr int F0 = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    constexpr int F1 = (LOGR - 3 * (T + 1) >= 3) ? (LOGR - 3 * (T + 2)) : 0;
+    int c0, pb0, ql0, c1, pb1, ql1;
+    p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
+    p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+    if (T > 0) __syncthreads(); // everybody has taken limbs 4..7 of the previous exchange out of the buffer
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int a = p8_addr(pb0 | (j << F0), c0, LOGW);
+        buf[a] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
+        buf8[a] = x[j].v[8];
+    }
+    __syncthreads();
+    uint4 lo[8];
+    uint32_t top[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int a = p8_addr(pb1 | (j << F1), c1, LOGW);
+        lo[j] = buf[a];
+        top[j] = buf8[a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) buf[p8_addr(pb0 | (j << F0), c0, LOGW)] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint4 h = buf[p8_addr(pb1 | (j << F1), c1, LOGW)];
+        x[j].v[0] = lo[j].x; x[j].v[1] = lo[j].y; x[j].v[2] = lo[j].z; x[j].v[3] = lo[j].w;
+        x[j].v[4] = h.x; x[j].v[5] = h.y; x[j].v[6] = h.z; x[j].v[7] = h.w;
+        x[j].v[8] = top[j];
+    }
+}
+
+// Two waves per SIMD (no register cap); the eight output multipliers are fetched where they are used.  Measured (profiles/r04_ntt29_ab.txt,
+// isolated fft, ms): capping the kernel at 168 VGPRs for three waves gives the same times with 23-46 spills (2^20 0.1193 vs 0.1190); fetching
+// the multipliers behind the data loads as k_ntt_pass8 does -- 64 registers held through the whole pass -- is SLOWER (2^20 0.1236 vs 0.1187,
+// 2^22 0.508 vs 0.455): with 9-word elements the registers are worth more than the latency they would hide.
+#ifndef BBG_NTT29_OCC
+#define BBG_NTT29_OCC 2
+#endif
+#ifndef BBG_NTT29_PREFETCH
+#define BBG_NTT29_PREFETCH 0 // 1 = multipliers fetched at the start (64 registers held through the pass), 0 = fetched where they are used
+#endif
+template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), BBG_NTT29_OCC) k_ntt_pass29(PassParams p)
+{
+    extern __shared__ uint4 lds[];
+    uint4* buf = lds;
+    uint32_t* buf8 = reinterpret_cast<uint32_t*>(lds + p8_plane<TL>());
+    uint32_t* red = buf8 + p8_plane<TL>(); // 16-byte aligned: p8_plane is a multiple of 4
+    constexpr int NSTEPS = (LOGR + 2) / 3;
+    constexpr int LOGW = TL - LOGR;
+    if (threadIdx.x < NTT29_RED_ROWS) ntt29_fill_reduce_table(red, threadIdx.x);
+    const size_t tile = blockIdx.x;
+    size_t base = 0, lo0 = 0, d1_0 = 0, rest = 0;
+    int logRestCount = 0;
+    if (!ROW) {
+        const int tiles_per_hi_log = p.logS - LOGW;
+        const size_t hi = tile >> tiles_per_hi_log;
+        lo0 = (tile & (((size_t)1 << tiles_per_hi_log) - 1)) << LOGW;
+        base = (hi << (LOGR + p.logS)) + lo0;
+    } else {
+        const int logRows = p.log2n - LOGR;
+        logRestCount = logRows - p.logR1;
+        rest = tile & (((size_t)1 << logRestCount) - 1);
+        d1_0 = (tile >> logRestCount) << LOGW;
+    }
+    const Fr* tw29 = p.tw_radix29; // w_R^x R' mod p, x < R
+    Fr29 x[8];
+    const Fr* mul_table = ROW ? p.post : p.tw_inter;
+    const bool have_outmul = mul_table != nullptr;
+    // ---- step 0: the tile from global memory (the addressing of k_ntt_pass8), re-limbed; the first pass's coset factor as a product
+    int c, pbase, qlo;
+    p8s_coords<LOGR, ROW, 0, TL>(threadIdx.x, c, pbase, qlo);
+    {
+        constexpr int F = (LOGR >= 3) ? (LOGR - 3) : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int pj = pbase | (j << F);
+            size_t g;
+            if (!ROW) {
+                g = base + ((size_t)pj << p.logS) + c;
+                if (g >= p.in_count) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) x[j].v[i] = 0;
+                    continue;
+                }
+                x[j] = f29_from_fe<FrP, 0>(fe_load<FrP>(p.in + g));
+                if (p.pre && g < p.pre_count) x[j] = f29_mul(x[j], f29_from_fe<FrP, 5>(fe_load<FrP>(p.pre + g))); // V < 2 * 64 / 169 + 1
+                continue;
+            }
+            g = (((((d1_0 + c) << logRestCount) + rest)) << LOGR) + pj;
+            x[j] = f29_from_fe<FrP, 0>(fe_load<FrP>(p.in + g));
+        }
+    }
+    Fr outmul[8];
+    if (BBG_NTT29_PREFETCH && have_outmul) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int pj, cc;
+            p8_last_coords<LOGR, TL>(threadIdx.x, j, pj, cc);
+            outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, cc, base, lo0, d1_0, rest, true));
+        }
+    }
+    __syncthreads(); // the reduction table is complete
+    p29_compute<LOGR, 0>(x, tw29, qlo, red);
+    if constexpr (NSTEPS > 1) {
+        p29_exchange<LOGR, ROW, 0, TL>(x, buf, buf8);
+        p8s_coords<LOGR, ROW, 1, TL>(threadIdx.x, c, pbase, qlo);
+        p29_compute<LOGR, 1>(x, tw29, qlo, red);
+    }
+    if constexpr (NSTEPS > 2) {
+        p29_exchange<LOGR, ROW, 1, TL>(x, buf, buf8);
+        p8s_coords<LOGR, ROW, 2, TL>(threadIdx.x, c, pbase, qlo);
+        p29_compute<LOGR, 2>(x, tw29, qlo, red);
+    }
+    if constexpr (NSTEPS > 3) {
+        p29_exchange<LOGR, ROW, 2, TL>(x, buf, buf8);
+        p8s_coords<LOGR, ROW, 3, TL>(threadIdx.x, c, pbase, qlo);
+        p29_compute<LOGR, 3>(x, tw29, qlo, red);
+    }
+    // ---- the last step's elements: final multiplier (inter-pass twiddle / post table), reduction, back to 8 words, out (bit reversal in the index)
+    {
+        constexpr int T = NSTEPS - 1;
+        constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int pj = pbase | (j << F);
+            Fr v;
+            if (have_outmul)
+                v = n29_finish_mul(x[j], BBG_NTT29_PREFETCH ? outmul[j] : fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, true)), red);
+            else v = n29_finish(x[j], red);
+            fe_store<FrP>(p.out + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false), v);
+        }
+    }
+}
+
+template <int LOGR, int TL = P8_TILE_LOG> static void p29_launch(const PassParams& p, size_t tiles, hipStream_t st)
+{
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass29<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
+    else hipLaunchKernelGGL((k_ntt_pass29<LOGR, false, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
+}
+template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p29_attr()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)k_ntt_pass29<LOGR, true, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p29_lds_bytes<TL>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_ntt_pass29<LOGR, false, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p29_lds_bytes<TL>());
+}
+
+} // namespace bbg

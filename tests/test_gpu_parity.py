@@ -132,8 +132,11 @@ def test_ntt_pass8_plans(pkg, oracle, bbg, maxr8):
     bbg.set_option("ntt_kernel", 2)
     bbg.set_option("ntt_max_logr8", maxr8)
     try:
-        for planes in (2, 1):  # k_ntt_pass8 (tile resident in LDS) and k_ntt_pass8s (one plane at a time; one-bit last steps by lane shuffles)
-            bbg.set_option("ntt_lds_planes", planes)
+        # k_ntt_pass8 (tile resident in LDS), k_ntt_pass8s (one plane at a time; one-bit last steps by lane shuffles), and k_ntt_pass29 (the
+        # same pass on lazily reduced 9 x 29-bit limbs: planes = 29 here)
+        for planes in (2, 1, 29):
+            bbg.set_option("ntt_lds_planes", planes if planes != 29 else 0)
+            bbg.set_option("ntt_limbs29", 1 if planes == 29 else 0)
             for lg in (11, 12, 13, 14, 16, 17, 19):
                 c = pkg.synthetic_scalars(8000 + lg, 1 << lg)
                 assert np.array_equal(oracle.canon(0, bbg.ntt(c, FFT)), oracle.ntt(c, 0)), (maxr8, planes, lg)
@@ -143,6 +146,7 @@ def test_ntt_pass8_plans(pkg, oracle, bbg, maxr8):
     finally:
         bbg.set_option("ntt_max_logr8", 10)
         bbg.set_option("ntt_lds_planes", 0)
+        bbg.set_option("ntt_limbs29", -1)
 
 
 def test_ntt_kernel_v1_still_matches(pkg, oracle, bbg):
@@ -192,9 +196,10 @@ def test_ntt_full_size_properties(pkg, oracle, bbg, golden, lg):
     if recs:
         assert sorted(r["op"] for r in recs) == [0, 1, 2, 3]
         for big in ((0, 2) if lg in (21, 22) else (1,)):
-            for planes in (2, 1):  # both pass kernels (option ntt_lds_planes; automatic = 1 from 2^22)
+            for planes in (2, 1, 29):  # every pass kernel (ntt_lds_planes: automatic = 1 from 2^22; 29 = ntt_limbs29, the 29-bit-limb kernel)
                 bbg.set_option("ntt_big_tile", big)
-                bbg.set_option("ntt_lds_planes", planes)
+                bbg.set_option("ntt_lds_planes", planes if planes != 29 else 0)
+                bbg.set_option("ntt_limbs29", 1 if planes == 29 else 0)
                 try:
                     for rec in recs:
                         out = run(rec["op"])
@@ -204,17 +209,20 @@ def test_ntt_full_size_properties(pkg, oracle, bbg, golden, lg):
                 finally:
                     bbg.set_option("ntt_big_tile", 1)
                     bbg.set_option("ntt_lds_planes", 0)
+                    bbg.set_option("ntt_limbs29", -1)
     else:  # 2^18 / 2^20: the reference digests live in golden.json, recorded over its own seeds
         grecs = [r for r in golden["ntt"] if r["log2n"] == lg and r["op"] < 4 and r["generator_size"] == 0]
         assert sorted(r["op"] for r in grecs) == [0, 1, 2, 3]
-        for planes in (2, 1):
-            bbg.set_option("ntt_lds_planes", planes)
+        for planes in (2, 1, 29):
+            bbg.set_option("ntt_lds_planes", planes if planes != 29 else 0)
+            bbg.set_option("ntt_limbs29", 1 if planes == 29 else 0)
             try:
                 for rec in grecs:
                     c = torch.from_numpy(pkg.synthetic_scalars(rec["seed"], n).view(np.int64)).cuda()
                     assert sha(run(rec["op"], c)) == rec["sha256"], (lg, rec["op"], planes)
             finally:
                 bbg.set_option("ntt_lds_planes", 0)
+                bbg.set_option("ntt_limbs29", -1)
     work = ta.clone()
     bbg.ntt_device(work.data_ptr(), lg, FFT)
     bbg.ntt_device(work.data_ptr(), lg, IFFT)

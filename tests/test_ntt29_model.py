@@ -173,6 +173,76 @@ def step8_mod(x, w1, w2, w3, tw):  # the same butterfly on residues (x R' form: 
     return x
 
 
+def check_lazy(a, v, lbound):  # what a consumer was sized for
+    vbound(a, v)
+    assert max(a) < lbound, ("limb bound", max(a), lbound)
+
+
+def step4(x, w2):  # n29_step4
+    x = [list(a) for a in x]
+    for a in x:
+        vbound(a, 3)
+
+    def bfly(i, j, k):
+        u, d = add(x[i], x[j]), sub(x[i], x[j], k)
+        x[i], x[j] = u, d
+    bfly(0, 2, 4); bfly(1, 3, 4); bfly(4, 6, 4); bfly(5, 7, 4)
+    x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
+    for j in (0, 1, 4, 5, 2, 6):
+        x[j] = carry(x[j])
+    bfly(0, 1, 7); bfly(2, 3, 3); bfly(4, 5, 7); bfly(6, 7, 3)
+    for a in x:
+        check_lazy(a, 13, (1 << 31) + 8)
+    return x
+
+
+def step2(x):  # n29_step2
+    x = [list(a) for a in x]
+    for i in (0, 2, 4, 6):
+        u, d = add(x[i], x[i + 1]), sub(x[i], x[i + 1], 4)
+        x[i], x[i + 1] = u, d
+    for a in x:
+        check_lazy(a, 7, (1 << 31) + 8)
+    return x
+
+
+def step8_raw(x, w1, w2, w3):  # n29_step8_raw: the radix-8 butterfly without step twiddles and without reductions
+    x = [list(a) for a in x]
+
+    def bfly(i, j, k):
+        u, d = add(x[i], x[j]), sub(x[i], x[j], k)
+        x[i], x[j] = u, d
+    for i in range(4):
+        bfly(i, i + 4, 4)
+    x[5], x[6], x[7] = mul(x[5], w1), mul(x[6], w2), mul(x[7], w3)
+    for j in range(5):
+        x[j] = carry(x[j])
+    bfly(0, 2, 7); bfly(1, 3, 7); bfly(4, 6, 3); bfly(5, 7, 3)
+    x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
+    for j in (0, 1, 2, 4, 6):
+        x[j] = carry(x[j])
+    bfly(0, 1, 13); bfly(2, 3, 3); bfly(4, 5, 4); bfly(6, 7, 3)
+    for a in x:
+        check_lazy(a, 25, (1 << 31) + 8)
+    return x
+
+
+def finish(x, mult_rform=None):  # n29_finish / n29_finish_mul: -> the 8 words a device array holds (< 2p)
+    check_lazy(x, 25, (1 << 31) + 8)
+    if mult_rform is not None:
+        assert mult_rform < 2 * P
+        m = limbs(mult_rform << 5)  # f29_from_fe<5>: exact limbs, value < 64p
+        x = mul(x, m)
+        vbound(x, 10.5)
+    r = reduce(x)
+    v = val(r)
+    assert v < 3 * P and v < (1 << 256)
+    if v >= P:  # fe_reduce_once
+        v -= P
+    assert v < 2 * P
+    return v
+
+
 def exact(v):  # a table value: exact limbs, < p
     assert v < P
     return limbs(v)
@@ -220,3 +290,53 @@ def test_step8_at_the_entry_bounds():
         out = step8([list(a) for a in x], wmax, wmax, wmax, [None] + [wmax] * 7)
         ref = step8_mod([val(a) % P for a in x], P - 1, P - 1, P - 1, [0] + [P - 1] * 7)
         assert [val(a) % P for a in out] == ref
+
+
+def test_partial_last_steps_and_the_way_out():
+    """n29_step4 / n29_step2 / n29_step8_raw on inputs at the bound, followed by n29_finish with and without a multiplier: the words written
+    back are the residues plain modular arithmetic gives, below 2p."""
+    rng = random.Random(404)
+    rinv = pow(R1, -1, P)
+    big = limbs(3 * P - 1)
+    for trial in range(40):
+        x = [big] * 8 if trial == 0 else [limbs(rng.randrange(3 * P)) for _ in range(8)]
+        xm = [val(a) % P for a in x]
+        w = [rng.randrange(P) for _ in range(3)] if trial else [P - 1] * 3
+        # S = 2
+        out = step4(x, exact(w[1]))
+        ref = list(xm)
+
+        def b(i, j, ww=None):
+            u, d = (ref[i] + ref[j]) % P, (ref[i] - ref[j]) % P
+            ref[i], ref[j] = u, d if ww is None else d * ww * rinv % P
+        b(0, 2); b(1, 3, w[1]); b(4, 6); b(5, 7, w[1]); b(0, 1); b(2, 3); b(4, 5); b(6, 7)
+        assert [val(a) % P for a in out] == ref
+        mult = rng.randrange(2 * P) if trial else 2 * P - 1
+        for a, r in zip(out, ref):
+            assert finish(a) % P == r
+            # a multiplier stored as w R (R-form): x (= X R') * (w R << 5 = w R') / R' = X w R'
+            assert finish(a, mult) % P == r * (mult << 5) * rinv % P
+        # S = 1
+        out = step2(x)
+        ref = list(xm)
+        b(0, 1); b(2, 3); b(4, 5); b(6, 7)
+        assert [val(a) % P for a in out] == ref
+        for a, r in zip(out, ref):
+            assert finish(a, mult) % P == r * (mult << 5) * rinv % P
+        # S = 3 without step twiddles
+        out = step8_raw(x, exact(w[0]), exact(w[1]), exact(w[2]))
+        ref = list(xm)
+        b(0, 4); b(1, 5, w[0]); b(2, 6, w[1]); b(3, 7, w[2]); b(0, 2); b(1, 3, w[1]); b(4, 6); b(5, 7, w[1]); b(0, 1); b(2, 3); b(4, 5); b(6, 7)
+        assert [val(a) % P for a in out] == ref
+        for a, r in zip(out, ref):
+            assert finish(a) % P == r and finish(a, mult) % P == r * (mult << 5) * rinv % P
+
+
+def test_premultiplied_load():
+    """The first pass's fused coset factor: x (re-limbed R-form, < 2p) times pre (R-form << 5, < 64p) is a valid step input (V < 3, exact limbs)."""
+    rng = random.Random(7)
+    for _ in range(200):
+        x, pre = rng.randrange(2 * P), rng.randrange(2 * P)
+        r = mul(limbs(x), limbs(pre << 5))
+        vbound(r, 1.76 + 0.01)
+        assert max(r[:8]) < (1 << 29)
