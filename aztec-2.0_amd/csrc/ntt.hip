@@ -204,7 +204,7 @@ struct PassParams {
     Fr* out;
     const Fr* tw_inter; // [R][S] table or nullptr
     const Fr* tw_radix; // R/2 entries
-    const Fr* tw_radix29; // the same R entries as w R' mod p, canonical (k_ntt_pass29: ntt29.hip.h)
+    const uint32_t* tw_radix29; // the same R entries as w R' mod p, canonical, 9 x 29-bit limbs in 12-word rows (k_ntt_pass29: ntt29.hip.h)
     const Fr* post;     // optional per-output-element multiplier table indexed by natural output index (row pass only)
     const Fr* pre;      // first (column) pass of k_ntt_pass8: input element g < pre_count is multiplied by pre[g] as it is loaded
     size_t pre_count;   //   (coset_fft's a_j *= g^j for j < generator_size, polynomial_arithmetic.cpp:395-399, fused into the load)
@@ -341,23 +341,27 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(PassParams p)
 #include "ntt_pass8.hip.h"
 #include "ntt_pass29.hip.h"
 namespace bbg {
-// out[j] = in[j] * 32 (canonical): w R -> w R' for R' = 2^261 = 32 R, the multiplier form of the 29-bit-limb pass kernel
-__global__ void k_to_rprime(Fr* out, const Fr* in, size_t count)
+// out row j = in[j] * 32 (canonical) as 9 x 29-bit limbs in a 12-word row: w R -> w R' for R' = 2^261 = 32 R, the multiplier form of the
+// 29-bit-limb pass kernel, already in the limbs its products take (three 16-byte loads, no split)
+__global__ void k_to_rprime(uint32_t* out, const Fr* in, size_t count)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     Fr c = Fr::zero();
     c.v[0] = 32;
-    fe_store<FrP>(out + idx, fe_canon(fe_mul(fe_load<FrP>(in + idx), fe_to_mont(c))));
+    const Fr29 l = f29_from_fe<FrP, 0>(fe_canon(fe_mul(fe_load<FrP>(in + idx), fe_to_mont(c))));
+    uint32_t* row = out + idx * NTT29_TW_ROW;
+#pragma unroll
+    for (int i = 0; i < NTT29_TW_ROW; i++) row[i] = i < 9 ? l.v[i] : 0u;
 }
 
 // ------------------------------------------------------------------------------------------ host side
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
 // sizes at which the 29-bit-limb pass kernel is the automatic choice (option ntt_limbs29 = -1).  Measured, isolated fft, ms
-// (profiles/r04_ntt29_ab.txt; best 32-bit kernel -> k_ntt_pass29): 2^18 0.0629 -> 0.0654 (loses: one pass of a small grid), 2^20 0.1229 -> 0.1187,
-// 2^21 0.2545 -> 0.2441, 2^22 0.4761 -> 0.4548, 2^23 0.9377 -> 0.8963, 2^24 1.8875 -> 1.8761.
-#define NTT_LIMBS29_AUTO(log2n) ((log2n) >= 20)
+// (profiles/r04_ntt29_ab.txt, last series; best 32-bit kernel -> k_ntt_pass29): 2^16 0.0524 -> 0.0512, 2^18 0.0629 -> 0.0633, 2^19 0.0779 -> 0.0766,
+// 2^20 0.1235 -> 0.1136, 2^21 0.2560 -> 0.2335, 2^22 0.4772 -> 0.4382, 2^23 0.9386 -> 0.8710, 2^24 1.9069 -> 1.8216.
+#define NTT_LIMBS29_AUTO(log2n) ((log2n) >= 19)
 
 static void plan_passes(bbg_ctx* ctx, NttDomain& d)
 {
@@ -479,10 +483,10 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
             d.bytes += half * sizeof(Fr);
             hipLaunchKernelGGL(k_twiddle_1d, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix[inv][q], pow2, half,
                                (uint64_t)(n >> logR));
-            if (d.use_pass8) { // the same table in R'-form for k_ntt_pass29 (R <= 2048 entries: 64 KB)
-                BBG_HIP(hipMalloc(&d.tw_radix29[inv][q], half * sizeof(Fr)));
-                d.bytes += half * sizeof(Fr);
-                hipLaunchKernelGGL(k_to_rprime, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix29[inv][q], (const Fr*)d.tw_radix[inv][q], half);
+            if (d.use_pass8) { // the same table in R'-form, as 9-limb rows, for k_ntt_pass29 (R <= 2048 entries of 48 bytes: 96 KB)
+                BBG_HIP(hipMalloc(&d.tw_radix29[inv][q], half * NTT29_TW_ROW * 4));
+                d.bytes += half * NTT29_TW_ROW * 4;
+                hipLaunchKernelGGL(k_to_rprime, dim3(grid_for(half, 256)), dim3(256), 0, st, (uint32_t*)d.tw_radix29[inv][q], (const Fr*)d.tw_radix[inv][q], half);
             }
             if (q < d.passes - 1) {
                 // inter-pass twiddles w_{N_q}^(i*lo), N_q = R*S ; w_{N_q} = w_n^(n/N_q): use the pow2 table shifted
@@ -530,7 +534,7 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     p.logW = d.logW[q];
     p.log2n = (int)d.log2n;
     p.tw_radix = (const Fr*)d.tw_radix[inverse][q];
-    p.tw_radix29 = (const Fr*)d.tw_radix29[inverse][q];
+    p.tw_radix29 = (const uint32_t*)d.tw_radix29[inverse][q];
     p.post = post;
     p.row_pass = (q == d.passes - 1);
     int logS = (int)d.log2n;

@@ -29,6 +29,8 @@ using Fr29 = F29<FrP>;
 // most 1 too small), go one lower (so that the difference keeps a top limb of its own: the row's borrowed limbs need it) and add row
 // q' of a table holding -q' p with every limb below the top raised by 2^30 (the raise borrowed from the limb above: Spread29 with q = 0).
 constexpr int NTT29_RED_ROWS = 32, NTT29_RED_ROW = 12; // 12 words per row: three ds_read_b128
+constexpr int NTT29_TW_ROW = 12; // a twiddle of the per-radix tables: 9 limbs in a 48-byte row
+constexpr int NTT29_TABLE_WORDS = 2 * NTT29_RED_ROWS * NTT29_RED_ROW; // the borrowed rows (ntt29_reduce), then the plain rows q p (n29_finish)
 constexpr uint32_t NTT29_P_TOP = (FrP::MOD[7] >> 8);                            // p >> 232 (22 bits)
 constexpr uint32_t NTT29_INV_TOP = (uint32_t)((1ull << 32) / (NTT29_P_TOP + 1)); // floor(2^32 / (p_top + 1))
 __device__ __forceinline__ void ntt29_fill_reduce_table(uint32_t* tbl, int k) // one row per calling thread, k < 32
@@ -51,6 +53,7 @@ __device__ __forceinline__ void ntt29_fill_reduce_table(uint32_t* tbl, int k) //
         // row 0 is all zeros (x < 2p stays as it is: its top limb may be too small to lend); rows k >= 1 are used for x >= (k + 1) p only,
         // whose top limb exceeds that of k p by p's own: top limb -2 - kp (mod 2^32) added to a larger one
         tbl[k * NTT29_RED_ROW + j] = k == 0 ? 0u : zero_spread - kp;
+        tbl[(NTT29_RED_ROWS + k) * NTT29_RED_ROW + j] = kp; // plain k p, exact limbs: the way out of a pass subtracts it with signed limbs
     }
 }
 // x: carried or not (limbs < 2^32 - 2^30), value < 32 p.  Result: carried, value in [p, 3p) for x >= 2p, x itself below.
@@ -192,9 +195,35 @@ __device__ __forceinline__ void n29_step8_raw(Fr29 (&x)[8], const Fr29& w1, cons
 // ---- the way out of a pass.  x: V < 25, L < 2^31 + 8 (any output of the last step).  With a multiplier (inter-pass twiddle / post-scale table
 // entry, the R-form words of the table shifted by 5 bits: w R' as an integer < 64 p, exact limbs): product V < 25 * 64 / 169 + 1 = 10.5, then the
 // table reduction (V < 3), exact limbs, the 8 words, one conditional subtraction -> the coarse [0, 2p) residue the device arrays hold.
+// x - q p with q = the quotient estimate itself (x / p - 1 < q <= x / p): the result is in [0, 2p) -- what a device array holds -- and is produced
+// with EXACT limbs by one sequential pass over signed limb differences (a limb of x - q p may be negative; the value is not), so neither a
+// second carry pass nor a conditional subtraction follows; the 8 words are a join of the limbs.
 __device__ __forceinline__ Fr n29_finish(const Fr29& x, const uint32_t* red)
 {
-    return fe_reduce_once(f29_to_fe(ntt29_reduce(x, red)));
+    const Fr29 c = f29_carry(x);
+    const uint32_t q = __umulhi(c.v[8], NTT29_INV_TOP);
+    const uint4* row = reinterpret_cast<const uint4*>(red + (NTT29_RED_ROWS + q) * NTT29_RED_ROW);
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2];
+    const uint32_t qp[9] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x };
+    Fr29 t;
+    int32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int32_t v = (int32_t)(c.v[i] - qp[i]) + carry; // |difference| < 2^30: no wrap
+        t.v[i] = (uint32_t)v & M29;
+        carry = v >> 29; // arithmetic shift: borrows travel upwards as -1
+    }
+    t.v[8] = (uint32_t)((int32_t)(c.v[8] - qp[8]) + carry);
+    Fr r;
+    r.v[0] = f29_join_word<0>(t.v);
+    r.v[1] = f29_join_word<1>(t.v);
+    r.v[2] = f29_join_word<2>(t.v);
+    r.v[3] = f29_join_word<3>(t.v);
+    r.v[4] = f29_join_word<4>(t.v);
+    r.v[5] = f29_join_word<5>(t.v);
+    r.v[6] = f29_join_word<6>(t.v);
+    r.v[7] = f29_join_word<7>(t.v);
+    return r;
 }
 __device__ __forceinline__ Fr n29_finish_mul(const Fr29& x, const Fr& mult_rform, const uint32_t* red)
 {

@@ -4,8 +4,8 @@
 // Same contract, same positions, same global addressing as k_ntt_pass8 / k_ntt_pass8s; what differs is what a register holds between the
 // load and the store: F29<FrP> values of (x / 32) in R'-Montgomery form (the 256 stored bits re-limbed -- ntt29.hip.h), 9 words each.  An
 // exchange therefore moves 36 bytes per element: the low four limbs through the plane buffer, limb 8 through a buffer of its own IN THE SAME
-// ROUND (separate LDS arrays, no extra barrier), then limbs 4..7 through the plane buffer.  LDS: 36 864 + 9 216 B of buffers + 1 536 B of
-// reduction table = 47.6 KB per 256-thread block, three blocks per CU.
+// ROUND (separate LDS arrays, no extra barrier), then limbs 4..7 through the plane buffer.  LDS: 36 864 + 9 216 B of buffers + 3 072 B of
+// reduction tables = 49.2 KB per 256-thread block, three blocks per CU.
 //
 // Results are the same residues as the 32-bit kernels give (the representative may differ: both are coarse, < 2p); the parity tests compare
 // canonical values against the oracle and the reference digests with this kernel selected (option "ntt_limbs29").
@@ -14,13 +14,22 @@
 
 namespace bbg {
 
-template <int TL> constexpr size_t p29_lds_bytes() { return (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_RED_ROWS * NTT29_RED_ROW * 4; }
+template <int TL> constexpr size_t p29_lds_bytes() { return (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_TABLE_WORDS * 4; }
 
-__device__ __forceinline__ Fr29 p29_load_tw(const Fr* __restrict__ tw29, int idx) { return f29_from_fe<FrP, 0>(fe_load<FrP>(tw29 + idx)); } // < p: exact limbs
+__device__ __forceinline__ Fr29 p29_load_tw(const uint32_t* __restrict__ tw29, int idx) // a table row: 9 exact limbs of a value < p
+{
+    const uint4* row = reinterpret_cast<const uint4*>(tw29 + (size_t)idx * NTT29_TW_ROW);
+    const uint4 a = row[0], b = row[1];
+    Fr29 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = tw29[(size_t)idx * NTT29_TW_ROW + 8];
+    return r;
+}
 
 // butterfly of step T + its step twiddles (p8s_compute's structure on F29 values).  `raw_last`: a LAST step with S = 3 leaves its outputs
 // un-reduced for the pass's final multiplication / reduction (n29_step8_raw)
-template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)[8], const Fr* __restrict__ tw29, int qlo, const uint32_t* red)
+template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)[8], const uint32_t* __restrict__ tw29, int qlo, const uint32_t* red)
 {
     constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
     constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
@@ -111,7 +120,7 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
         rest = tile & (((size_t)1 << logRestCount) - 1);
         d1_0 = (tile >> logRestCount) << LOGW;
     }
-    const Fr* tw29 = p.tw_radix29; // w_R^x R' mod p, x < R
+    const uint32_t* tw29 = p.tw_radix29; // w_R^x R' mod p, x < R: rows of 9 limbs
     Fr29 x[8];
     const Fr* mul_table = ROW ? p.post : p.tw_inter;
     const bool have_outmul = mul_table != nullptr;

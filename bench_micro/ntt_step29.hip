@@ -31,7 +31,7 @@ __device__ __forceinline__ Fr to_rprime(const Fr& w)
 
 template <int V> __global__ void __launch_bounds__(256) k_step(uint32_t* out, const uint32_t* in, int* bad)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t red[NTT29_RED_ROWS * NTT29_RED_ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t red[NTT29_TABLE_WORDS];
     if (threadIdx.x < NTT29_RED_ROWS) ntt29_fill_reduce_table(red, threadIdx.x);
     __syncthreads();
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -234,12 +234,24 @@ def finish(x, mult_rform=None):  # n29_finish / n29_finish_mul: -> the 8 words a
         m = limbs(mult_rform << 5)  # f29_from_fe<5>: exact limbs, value < 64p
         x = mul(x, m)
         vbound(x, 10.5)
-    r = reduce(x)
-    v = val(r)
-    assert v < 3 * P and v < (1 << 256)
-    if v >= P:  # fe_reduce_once
-        v -= P
-    assert v < 2 * P
+    assert val(x) < 32 * P
+    c = carry(x)
+    q = (c[8] * INV_TOP) >> 32
+    assert q <= val(x) // P <= q + 1 and q < 32
+    qp = limbs(q * P)
+    t, cy = [], 0
+    for i in range(8):
+        d = c[i] - qp[i]
+        assert -(1 << 31) <= d < (1 << 31), "signed limb difference leaves 32 bits"
+        v = d + cy
+        assert -(1 << 31) <= v < (1 << 31)
+        t.append(v & M29)
+        cy = v >> 29  # Python's >> on negative integers is the arithmetic shift
+    top = c[8] - qp[8] + cy
+    assert 0 <= top < U32, "top limb of the exact difference"
+    t.append(top)
+    v = val(t)
+    assert v == val(x) - q * P and 0 <= v < 2 * P and v < (1 << 256) and all(limb <= M29 for limb in t[:8])
     return v
 
 
