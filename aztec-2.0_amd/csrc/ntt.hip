@@ -359,8 +359,8 @@ __global__ void k_to_rprime(uint32_t* out, const Fr* in, size_t count)
 static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
 // sizes at which the 29-bit-limb pass kernel is the automatic choice (option ntt_limbs29 = -1).  Measured, isolated fft, ms
-// (profiles/r04_ntt29_ab.txt, last series; best 32-bit kernel -> k_ntt_pass29): 2^16 0.0524 -> 0.0512, 2^18 0.0629 -> 0.0633, 2^19 0.0779 -> 0.0766,
-// 2^20 0.1235 -> 0.1136, 2^21 0.2560 -> 0.2335, 2^22 0.4772 -> 0.4382, 2^23 0.9386 -> 0.8710, 2^24 1.9069 -> 1.8216.
+// (profiles/r04_ntt29_ab.txt, last series; best 32-bit kernel -> k_ntt_pass29): 2^16 0.0523 -> 0.0507, 2^19 0.0773 -> 0.0748,
+// 2^20 0.1225 -> 0.1107, 2^21 0.2540 -> 0.2329, 2^22 0.4788 -> 0.4447, 2^23 0.9477 -> 0.8851, 2^24 1.9194 -> 1.7706.
 #define NTT_LIMBS29_AUTO(log2n) ((log2n) >= 19)
 
 static void plan_passes(bbg_ctx* ctx, NttDomain& d)

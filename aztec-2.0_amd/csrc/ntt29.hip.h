@@ -72,10 +72,10 @@ __device__ __forceinline__ Fr29 ntt29_reduce(const Fr29& x, const uint32_t* tbl)
 }
 
 // ---- butterflies.  KB = the multiple of p added by the subtraction: must exceed V_b by one.
-template <int KB> __device__ __forceinline__ void n29_bfly(Fr29& a, Fr29& b) // (a, b) <- (a + b, a - b + KB p)
+template <int KB, int E = 30> __device__ __forceinline__ void n29_bfly(Fr29& a, Fr29& b) // (a, b) <- (a + b, a - b + KB p); b limbs <= 2^E - 2
 {
     const Fr29 u = f29_add(a, b);
-    b = f29_sub<KB>(a, b);
+    b = f29_sub<KB, E>(a, b);
     a = u;
 }
 __device__ __forceinline__ void n29_carry(Fr29& a) { a = f29_carry(a); }
@@ -89,21 +89,22 @@ __device__ __forceinline__ void n29_carry(Fr29& a) { a = f29_carry(a); }
 template <bool HAVE_TW, class TW>
 __device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const Fr29& w1, const Fr29& w2, const Fr29& w3, TW tw, const uint32_t* red)
 {
-    // level 1: inputs V < 3 carried.  u: V < 6, L < 2^30 + 16.  d = a - b + 4p: V < 7, L < 2^31 + 8.
+    // level 1: inputs V < 3 carried.  u: V < 6, L < 2^30 + 16.  d = a - b + 4p: V < 7, L < 2^31 + 8.  NOTHING is carried here (r4b): the
+    // sums go into level 2 as they are (its subtractions take subtrahend limbs up to 2^31 - 2: E = 31), x[4] = d04 likewise.
     n29_bfly<4>(x[0], x[4]);
     n29_bfly<4>(x[1], x[5]);
     n29_bfly<4>(x[2], x[6]);
     n29_bfly<4>(x[3], x[7]);
     f29_mul2(x[5], w1, x[6], w2, x[5], x[6]); // V < 7/169 + 1 = 1.05, L < 2^29
     x[7] = f29_mul(x[7], w3);
-    n29_carry(x[0]); n29_carry(x[1]); n29_carry(x[2]); n29_carry(x[3]); // V < 6
-    n29_carry(x[4]);                                                    // V < 7
-    // level 2.  (0,2), (1,3): a, b carried, V < 6: u V < 12, d = a - b + 7p V < 13.  (4,6): a V < 7 carried, b V < 1.05 exact: u V < 8.05,
-    // d = a - b + 3p V < 10.  (5,7): a, b V < 1.05 exact: u V < 2.1 (L < 2^30), d = a - b + 3p V < 4.05.
-    n29_bfly<7>(x[0], x[2]);
-    n29_bfly<7>(x[1], x[3]);
+    // level 2.  (0,2), (1,3): a, b V < 6, L < 2^30 + 16: u V < 12, L < 2^31 + 32; d = a - b + 7p (E = 31) V < 13, L < 2^30 + 16 + 2^31 + 2^29.
+    // (4,6): a V < 7, L < 2^31 + 8, b V < 1.05 exact: u V < 8.05, L < 2^31 + 2^29 + 8; d = a - b + 3p V < 10, L < 2^31 + 8 + 2^30 + 2^29.
+    // (5,7): a, b V < 1.05 exact: u V < 2.1 (L < 2^30), d = a - b + 3p V < 4.05.
+    n29_bfly<7, 31>(x[0], x[2]);
+    n29_bfly<7, 31>(x[1], x[3]);
     n29_bfly<3>(x[4], x[6]);
     n29_bfly<3>(x[5], x[7]);
+    n29_carry(x[3]);                          // a multiplication's operand: limbs back below 2^29 + 8
     f29_mul2(x[3], w2, x[7], w2, x[3], x[7]); // V < 13/169 + 1 = 1.08 ; V < 1.03
     n29_carry(x[0]); n29_carry(x[1]);         // V < 12
     n29_carry(x[2]);                          // V < 13
@@ -175,12 +176,11 @@ __device__ __forceinline__ void n29_step8_raw(Fr29 (&x)[8], const Fr29& w1, cons
     n29_bfly<4>(x[3], x[7]);
     f29_mul2(x[5], w1, x[6], w2, x[5], x[6]);
     x[7] = f29_mul(x[7], w3);
-    n29_carry(x[0]); n29_carry(x[1]); n29_carry(x[2]); n29_carry(x[3]);
-    n29_carry(x[4]);
-    n29_bfly<7>(x[0], x[2]);
-    n29_bfly<7>(x[1], x[3]);
+    n29_bfly<7, 31>(x[0], x[2]);
+    n29_bfly<7, 31>(x[1], x[3]);
     n29_bfly<3>(x[4], x[6]);
     n29_bfly<3>(x[5], x[7]);
+    n29_carry(x[3]);
     f29_mul2(x[3], w2, x[7], w2, x[3], x[7]);
     n29_carry(x[0]); n29_carry(x[1]);
     n29_carry(x[2]);

@@ -43,7 +43,7 @@ def add(a, b):
     return r
 
 
-def spread(mult, e=30):
+def spread(mult, e):
     q = limbs(mult * P)
     up, down = 1 << e, 1 << (e - 29)
     s = [q[0] + up] + [q[j] + up - down for j in range(1, 8)] + [q[8] - down]
@@ -51,8 +51,8 @@ def spread(mult, e=30):
     return s
 
 
-def sub(a, b, mult):
-    s = spread(mult)
+def sub(a, b, mult, e=30):
+    s = spread(mult, e)
     r = []
     for x, y, c in zip(a, b, s):
         assert c - y >= 0, "subtrahend limb above the spread constant"
@@ -129,20 +129,19 @@ def step8(x, w1, w2, w3, tw):  # n29_step8<true>
         assert max(a[:8]) < (1 << 29) + 8
     x = [list(a) for a in x]
 
-    def bfly(i, j, k):
-        u, d = add(x[i], x[j]), sub(x[i], x[j], k)
+    def bfly(i, j, k, e=30):
+        u, d = add(x[i], x[j]), sub(x[i], x[j], k, e)
         x[i], x[j] = u, d
     for i in range(4):
         bfly(i, i + 4, 4)
     x[5], x[6], x[7] = mul(x[5], w1), mul(x[6], w2), mul(x[7], w3)
     for j in (5, 6, 7):
         vbound(x[j], 1.05)
-    for j in range(5):
-        x[j] = carry(x[j])
     for j in range(4):
         vbound(x[j], 6)
     vbound(x[4], 7)
-    bfly(0, 2, 7); bfly(1, 3, 7); bfly(4, 6, 3); bfly(5, 7, 3)
+    bfly(0, 2, 7, 31); bfly(1, 3, 7, 31); bfly(4, 6, 3); bfly(5, 7, 3)
+    x[3] = carry(x[3])
     x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
     vbound(x[3], 1.08); vbound(x[7], 1.03)
     for j in (0, 1, 2, 4, 6):
@@ -209,15 +208,14 @@ def step2(x):  # n29_step2
 def step8_raw(x, w1, w2, w3):  # n29_step8_raw: the radix-8 butterfly without step twiddles and without reductions
     x = [list(a) for a in x]
 
-    def bfly(i, j, k):
-        u, d = add(x[i], x[j]), sub(x[i], x[j], k)
+    def bfly(i, j, k, e=30):
+        u, d = add(x[i], x[j]), sub(x[i], x[j], k, e)
         x[i], x[j] = u, d
     for i in range(4):
         bfly(i, i + 4, 4)
     x[5], x[6], x[7] = mul(x[5], w1), mul(x[6], w2), mul(x[7], w3)
-    for j in range(5):
-        x[j] = carry(x[j])
-    bfly(0, 2, 7); bfly(1, 3, 7); bfly(4, 6, 3); bfly(5, 7, 3)
+    bfly(0, 2, 7, 31); bfly(1, 3, 7, 31); bfly(4, 6, 3); bfly(5, 7, 3)
+    x[3] = carry(x[3])
     x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
     for j in (0, 1, 2, 4, 6):
         x[j] = carry(x[j])
