@@ -107,7 +107,7 @@ VALU_PEAK_GWAVE = 1024 * 2.4 / 4  # 256 CUs x 4 SIMDs, one wave-instruction per 
 def valu_issue(acc_ms, ntt_ms):
     """What actually bounds these kernels: VALU instruction issue.  SQ_INSTS_VALU (wave-instructions per launch, committed PMC pass)
     over the launch duration measured in THIS run, against the chip's issue peak."""
-    acc, ntt = pmc_counter("k_accumulate", "SQ_INSTS_VALU"), pmc_counter("k_ntt_pass8", "SQ_INSTS_VALU")
+    acc, ntt = pmc_counter("k_accumulate", "SQ_INSTS_VALU"), pmc_counter("k_ntt_pass", "SQ_INSTS_VALU")  # whichever pass kernels the profiled build ran (k_ntt_pass8 / 8s / 29)
     out = {"unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GWAVE, 1), "source": "profiles/" + os.path.basename(PMC_PROFILE) + " SQ_INSTS_VALU",
            "profile_matches_build": profile_stamp()["profile_matches_build"]}
     if acc:
@@ -120,7 +120,7 @@ def valu_issue(acc_ms, ntt_ms):
 def pmc_traffic_ntt():
     """HBM bytes of ONE whole NTT (both pass kernels, one launch each) from the committed PMC passes.  The passes stream wide
     coalesced rows, the case for which MI355X_MICROARCH.md prescribes FETCH_SIZE x 2 on gfx950; WRITE_SIZE is taken as reported."""
-    fetch, write = pmc_counter("k_ntt_pass8", "FETCH_SIZE"), pmc_counter("k_ntt_pass8", "WRITE_SIZE")
+    fetch, write = pmc_counter("k_ntt_pass", "FETCH_SIZE"), pmc_counter("k_ntt_pass", "WRITE_SIZE")
     if fetch is None or write is None:
         return None
     return round((2.0 * fetch + write) * 1024.0)
@@ -307,7 +307,7 @@ def main():
         "msm_ms": round(msm_ms, 4), "msm_mscalar_per_s_per_gpu": round(n / msm_ms / 1e3, 2),
         "ntt_ms": round(ntt_ms, 4), "ntt_gfield_ops_per_s_per_gpu": round(1.5 * n * lg / ntt_ms / 1e6, 2),
         "msm_phase_ms": {k: round(prof[k][0] / args.steps, 4) for k in prof if k.startswith("msm_")},
-        "roofline_ntt": {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": round(ntt_alg / (pass_ms * 1e-3) / 1e9, 2),
+        "roofline_ntt": {"kernel": "k_ntt_pass29 (NTT pass on lazily reduced 9 x 29-bit limbs; two launches per 2^20 transform)", "bound": "hbm", "achieved": round(ntt_alg / (pass_ms * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ntt_alg / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "traffic": (pmc_traffic_ntt() / max(1.0, ntt_passes)) if pmc_traffic_ntt() else None,
                          "traffic_whole_ntt": pmc_traffic_ntt(),
