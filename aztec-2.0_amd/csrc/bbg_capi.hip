@@ -369,6 +369,9 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
         drop(&ctx->quot_setup, &ctx->quot_setup_bytes);
         drop(&ctx->msm.buf, &ctx->msm.bytes);
         ctx->msm_layout_n = 0; // the arena's counters are re-initialised with the next layout
+        ctx->msm_zero_buf = nullptr;
+        ctx->msm_zero_c = 0;
+        ctx->msm_zero_sets = 0;
         for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) ctx->ev_done_valid[k] = false;
         if (tables) {
             std::lock_guard<std::mutex> lk2(g_srs_mu);

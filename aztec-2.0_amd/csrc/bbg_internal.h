@@ -39,6 +39,7 @@ struct NttDomain {
     void* tw_inter[2][NTT_MAX_PASSES] = {};          // [inverse][pass]: omega_{N_q}^{i*lo}, N_q entries (passes 0..p-2)
     void* tw_radix[2][NTT_MAX_PASSES] = {};          // [inverse][pass]: omega_{R_q}^j, R_q/2 entries
     void* tw_radix29[2][NTT_MAX_PASSES] = {};        // the same entries times 32 (R'-form, canonical): multipliers of the 29-bit-limb pass kernel
+    uint64_t root_host[4] = { 0, 0, 0, 0 };          // host copy of the domain's root of unity (Montgomery form, canonical): poly.hip builds evaluation-point tables on the host
     void* coset_fwd = nullptr;                       // g^j, j < n
     void* coset_inv = nullptr;                       // n^-1 * g^-j, j < n
     size_t bytes = 0;
@@ -103,6 +104,9 @@ struct bbg_ctx {
     size_t msm_layout_n = 0; // (scalars of the batch, MSMs in it, window width) of the layout the scratch arena currently holds: a change of any
     int msm_layout_sets = 0; // moves every region, so pending reduce phases are joined first (msm_run_c)
     int msm_layout_c = 0;
+    void* msm_zero_buf = nullptr; // the arena whose leading zero-initialised regions (partition counters, redo flags) were cleared ...
+    int msm_zero_c = 0;           // ... for this window width ...
+    int msm_zero_sets = 0;        // ... and this many bucket sets (msm_layout's cap_sets)
     int msm_layout_sort = 1; // (the sort path is part of the layout: the library-sort path reserves rocPRIM's temporary storage)
     bool msm_async_reduce = false;
     int msm_reduce_quad = 14;   // reduce stages with four lanes per EC operation (curve_quad.hip.h): bit 0 combine (a THROUGHPUT kernel over all buckets: one lane per operation is cheaper, measured), 1 row/col, 2 planes, 3 sum
@@ -168,6 +172,7 @@ int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, u
 int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n);
 int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
+int ntt_domain_root_host(bbg_ctx* ctx, unsigned log2n, uint64_t out[4]);
 int poly_binop(int op, const void* a, const void* b, void* r, size_t n, hipStream_t st);
 int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* z, uint64_t* out, hipStream_t st);
 int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st);

@@ -1115,6 +1115,7 @@ struct MsmLayout {
     size_t off_offsets[bbg_ctx::MSM_SLOTS], off_head[bbg_ctx::MSM_SLOTS], off_tail[bbg_ctx::MSM_SLOTS], off_buckets[bbg_ctx::MSM_SLOTS], off_rows[bbg_ctx::MSM_SLOTS],
         off_cols[bbg_ctx::MSM_SLOTS], off_long[bbg_ctx::MSM_SLOTS], off_redo[bbg_ctx::MSM_SLOTS];
     size_t sort_bytes;
+    size_t zero_bytes; // the leading part of the arena that holds the zero-initialised regions
     size_t total;
 };
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -1145,8 +1146,11 @@ static uint32_t msm_seg_len(size_t entries, size_t buckets, int waves_override)
     return (uint32_t)seg;
 }
 
-// total_n = scalars of all `sets` MSMs of the batch together
-template <int C> static int msm_layout(size_t total_n, int sets, bool library_sort, MsmLayout& L, int acc_waves = 0)
+// total_n = scalars of all `sets` MSMs of the batch together.  The two regions that must be ZERO when an MSM starts -- the sort's partition
+// counters and the redo queues' per-bucket flags -- come first and are sized for `cap_sets` (the largest batch this context has run at this
+// width): they keep their place when n or the batch size change, so a prover's rounds (batches of 4, 1, 4, 2 over the same n) neither move
+// nor clear them (round 4: twelve memsets per proof).
+template <int C> static int msm_layout(size_t total_n, int sets, int cap_sets, bool library_sort, MsmLayout& L, int acc_waves = 0)
 {
     using K = MsmCfg<C>;
     const size_t nbuckets = (size_t)sets * K::buckets;
@@ -1166,6 +1170,9 @@ template <int C> static int msm_layout(size_t total_n, int sets, bool library_so
     L.sort_bytes = tmp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.off_parts = take((size_t)3 * cap_sets * SORT_PAD * 4); // per set: partition counts | bases | cursors (strides of cap_sets tables)
+    for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) L.off_redo[k] = take((size_t)2 * cap_sets * K::buckets * 4); // RedoQueue: flags (zero between MSMs), then the list
+    L.zero_bytes = o;
     L.off_keys0 = take(L.entries * 4);
     L.off_keys1 = take(L.entries * 4);
     // sorted values, one copy per slot: a bucket queued for k_redo (reduce phase, auxiliary stream) is recomputed from its entries while the
@@ -1173,7 +1180,6 @@ template <int C> static int msm_layout(size_t total_n, int sets, bool library_so
     for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) L.off_vals0[k] = take(L.entries * 4);
     L.off_vals1 = take(library_sort ? L.entries * 4 : 0); // second value buffer of the library sort's double buffer (A/B build only)
     L.off_sort = take(L.sort_bytes);
-    L.off_parts = take((size_t)3 * sets * SORT_PAD * 4); // per set: partition counts | bases | cursors
     for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
         L.off_offsets[k] = take((nbuckets + 2) * 4);
         L.off_head[k] = take(L.lanes * sizeof(Xyzz));
@@ -1181,8 +1187,7 @@ template <int C> static int msm_layout(size_t total_n, int sets, bool library_so
         L.off_buckets[k] = take(nbuckets * sizeof(Xyzz));
         L.off_rows[k] = take((size_t)sets * ((size_t)(1 << K::log_rows) + MSM_MAX_PLANES) * sizeof(Xyzz)); // row sums of every set, then their bit planes
         L.off_cols[k] = take((size_t)sets * (size_t)(1 << K::log_cols) * sizeof(Xyzz));
-        L.off_long[k] = take((nbuckets + 2) * 4);
-        L.off_redo[k] = take((2 * nbuckets) * 4); // RedoQueue: list, flags (the count lives beside the long-bucket count)
+        L.off_long[k] = take((nbuckets + 2) * 4); // long-bucket count, redo count, long-bucket list
     }
     L.total = o;
     return BBG_OK;
@@ -1214,7 +1219,8 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
     const size_t n = max_n; // grid extent of the per-scalar kernels (blockIdx.y = MSM of the batch; shorter ones leave early)
     const uint32_t nbuckets = (uint32_t)sets * K::buckets;
     MsmLayout L;
-    int rc = msm_layout<C>(total_n, sets, ctx->msm_sort == 0, L, ctx->msm_acc_waves);
+    const int cap_sets = (ctx->msm_zero_c == C && ctx->msm_zero_sets > sets) ? ctx->msm_zero_sets : sets;
+    int rc = msm_layout<C>(total_n, sets, cap_sets, ctx->msm_sort == 0, L, ctx->msm_acc_waves);
     if (rc) return rc;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
@@ -1239,10 +1245,16 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
         ctx->msm_layout_sets = sets;
         ctx->msm_layout_c = C;
         ctx->msm_layout_sort = ctx->msm_sort;
-        // the partition counters moved with the layout: cleared once here, then kept clear by k_sortA_scan
-        BBG_HIP(hipMemsetAsync(base_of(ctx) + L.off_parts, 0, (size_t)sets * SORT_PAD * 4, st));
-        // the redo queues likewise: count and per-bucket flags are zero between MSMs (k_redo clears what it was given)
-        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) BBG_HIP(hipMemsetAsync(base_of(ctx) + L.off_redo[k], 0, ((size_t)2 * nbuckets) * 4, st));
+    }
+    if (ctx->msm_zero_buf != ctx->msm.buf || ctx->msm_zero_c != C || ctx->msm_zero_sets != cap_sets) {
+        // the zero-initialised regions are new (fresh arena), belong to another width, or grew: cleared once here -- then the partition
+        // counters are kept clear by k_sortA_scan and the redo flags by k_redo, whatever n and batch size the following calls have
+        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++)
+            if (ctx->ev_done_valid[k]) BBG_HIP(hipStreamWaitEvent(st, ctx->ev_done[k], 0));
+        BBG_HIP(hipMemsetAsync(base_of(ctx), 0, L.zero_bytes, st));
+        ctx->msm_zero_buf = ctx->msm.buf;
+        ctx->msm_zero_c = C;
+        ctx->msm_zero_sets = cap_sets;
     }
     const int slot = (int)(ctx->msm_seq++ % bbg_ctx::MSM_SLOTS);
     char* base = (char*)ctx->msm.buf;
@@ -1275,8 +1287,8 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
         // fused recode + MSD partition sort (keys0 area = 64-bit entries, vals0 = final values, keys1 head = partition tables)
         uint64_t* entries = (uint64_t*)keys0; // keys0 and keys1 are adjacent: 2 x 4 x 16n bytes = 8 x 16n
         uint32_t* part_count = (uint32_t*)(base + L.off_parts);
-        uint32_t* part_base = part_count + (size_t)sets * SORT_PAD;
-        uint32_t* cursor = part_count + (size_t)2 * sets * SORT_PAD;
+        uint32_t* part_base = part_count + (size_t)cap_sets * SORT_PAD;
+        uint32_t* cursor = part_count + (size_t)2 * cap_sets * SORT_PAD;
         const int nblk = grid_for(n, SORT_BLOCK);
         {
             ProfScope ps(ctx, "msm_recode", st);
@@ -1356,7 +1368,7 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
     }
     bool redo_pending = false; // k_accumulate29 ran: buckets it could not sum are queued
     uint32_t* redo_words = reinterpret_cast<uint32_t*>(base + L.off_redo[slot]);
-    const RedoQueue redo{ long_count + 1, redo_words, redo_words + nbuckets };
+    const RedoQueue redo{ long_count + 1, redo_words + (size_t)cap_sets * K::buckets, redo_words }; // flags first: their place does not depend on the batch
     {
         ProfScope ps(ctx, "msm_accumulate", st);
         if (ctx->msm_sort != 1) BBG_HIP(hipMemsetAsync(long_count, 0, 8, st)); // the partition sort's scan kernel clears both counts

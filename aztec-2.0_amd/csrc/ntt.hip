@@ -515,7 +515,12 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
     hipLaunchKernelGGL(k_powers, dim3(grid_for((n + POW_E - 1) / POW_E, 256)), dim3(256), 0, st, (Fr*)d.coset_inv,
                        dc->pow2_tmp, d.inv_scaled ? (const Fr*)nullptr : (const Fr*)&dc->n_inv, n);
     BBG_HIP(hipGetLastError());
-    BBG_HIP(hipStreamSynchronize(st));
+    {
+        Fr root;
+        BBG_HIP(hipMemcpyAsync(&root, &dc->root, sizeof(Fr), hipMemcpyDeviceToHost, st));
+        BBG_HIP(hipStreamSynchronize(st));
+        memcpy(d.root_host, &root, 32);
+    }
     auto ins = ctx->domains.emplace(log2n, d);
     *out = &ins.first->second;
     return BBG_OK;
@@ -968,6 +973,16 @@ int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts)
     int rc = build_domain(ctx, log2n, &d);
     if (rc) return rc;
     *consts = d->consts;
+    return BBG_OK;
+}
+
+int ntt_domain_root_host(bbg_ctx* ctx, unsigned log2n, uint64_t out[4])
+{
+    if (log2n > 28) { set_error("domain: log2n > 28"); return BBG_E_INVALID; }
+    NttDomain* d = nullptr;
+    int rc = build_domain(ctx, log2n, &d);
+    if (rc) return rc;
+    memcpy(out, d->root_host, 32);
     return BBG_OK;
 }
 

@@ -108,22 +108,98 @@ static int poly_scratch(bbg_ctx* ctx, size_t partials, PolyHeader** hdr, Fr** pa
     return BBG_OK;
 }
 
-// z arrives BY VALUE (kernel argument): no pageable-memory copy whose source the caller could reuse before it ran.
-// mul_root != null: the point is z * (*mul_root) (the shifted evaluations at zeta * w of round 5).
-__global__ void __launch_bounds__(256) k_poly_pow2(PolyScratch* s, Fr z, const Fr* mul_root)
+// ---- the evaluation point's powers z^(2^b): a chain of dependent squarings.  On the device that chain is ONE lane's latency -- 45 us per
+// evaluation point, six points per proof (round 5's zeta and zeta w, r(zeta), two Kate quotients): 0.27 ms of a proof that takes 3-5 ms at
+// 2^12 .. 2^16 gates (profile of round 4).  On a host core it is 48 Montgomery squarings of 4 x u64 limbs: a few microseconds.  So the host
+// computes the table (hostfr below: CIOS with unsigned __int128, field_impl_generic.hpp:392-442 restated for this one purpose) and hands
+// it to the kernel BY VALUE (1.5 KB of kernel arguments: no pageable-memory copy whose source the caller could reuse before it ran).
+namespace hostfr {
+struct H {
+    uint64_t v[4];
+};
+static const uint64_t MOD[4] = { ((uint64_t)FrP::MOD[1] << 32) | FrP::MOD[0], ((uint64_t)FrP::MOD[3] << 32) | FrP::MOD[2],
+                                 ((uint64_t)FrP::MOD[5] << 32) | FrP::MOD[4], ((uint64_t)FrP::MOD[7] << 32) | FrP::MOD[6] };
+static const uint64_t INV64 = 0xc2e1f593efffffffULL; // -p^-1 mod 2^64 (fr.hpp:42)
+static_assert((uint32_t)INV64 == FrP::INV, "the 64-bit Montgomery constant extends the 32-bit one the device uses");
+static bool geq_mod(const H& a)
 {
-    if (threadIdx.x == 0) {
-        Fr a = fe_reduce_once(fe_reduce_once(z));
-        if (mul_root) a = fe_reduce_once(fe_mul(a, *mul_root));
-        s->z = a;
-        for (int i = 0; i < 48; i++) {
-            s->pow2z[i] = a;
-            a = fe_reduce_once(fe_sqr(a));
-        }
+    for (int i = 3; i >= 0; i--)
+        if (a.v[i] != MOD[i]) return a.v[i] > MOD[i];
+    return true;
+}
+static H sub_mod(const H& a)
+{
+    H r;
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned __int128 d = (unsigned __int128)a.v[i] - MOD[i] - borrow;
+        r.v[i] = (uint64_t)d;
+        borrow = (d >> 64) & 1;
     }
-    __threadfence_block();
-    __syncthreads();
-    s->ztid[threadIdx.x] = fe_reduce_once(pow_from_table(s->pow2z, (uint64_t)threadIdx.x));
+    return r;
+}
+static H canon(H a) // any 256-bit representative -> [0, p)
+{
+    while (geq_mod(a)) a = sub_mod(a);
+    return a;
+}
+static H mul(const H& a, const H& b) // a b / 2^256 mod p, canonical; a, b < 2^256 with a b < 2^256 p (one canonical operand suffices)
+{
+    uint64_t t[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (unsigned __int128)a.v[j] * b.v[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * INV64;
+        c = ((unsigned __int128)m * MOD[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (unsigned __int128)m * MOD[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    H r = { { t[0], t[1], t[2], t[3] } };
+    if (t[4] || geq_mod(r)) r = sub_mod(r); // t < 2p
+    return canon(r);
+}
+} // namespace hostfr
+
+struct Pow2Arg {
+    Fr z;
+    Fr pow2z[48];
+};
+static Pow2Arg host_pow2(const uint64_t* z_limbs, const uint64_t* mul_root) // mul_root (canonical, Montgomery form) or null
+{
+    hostfr::H a;
+    memcpy(&a, z_limbs, 32);
+    a = hostfr::canon(a);
+    if (mul_root) {
+        hostfr::H r;
+        memcpy(&r, mul_root, 32);
+        a = hostfr::mul(a, hostfr::canon(r));
+    }
+    Pow2Arg t;
+    memcpy(&t.z, &a, 32);
+    for (int i = 0; i < 48; i++) {
+        memcpy(&t.pow2z[i], &a, 32);
+        a = hostfr::mul(a, a);
+    }
+    return t;
+}
+__global__ void __launch_bounds__(256) k_poly_pow2(PolyScratch* s, const Pow2Arg t)
+{
+    if (threadIdx.x == 0) s->z = t.z;
+    if (threadIdx.x < 48) s->pow2z[threadIdx.x] = t.pow2z[threadIdx.x];
+    s->ztid[threadIdx.x] = fe_reduce_once(pow_from_table(t.pow2z, (uint64_t)threadIdx.x));
 }
 // LDS tree sum of one field element per thread (256 threads); result valid in thread 0
 __device__ Fr block_sum(Fr v, Fr* sm)
@@ -224,7 +300,7 @@ static int poly_setup(bbg_ctx* ctx, size_t n, const uint64_t* z, PolyHeader** hd
     *nblocks = ((n + PV_E - 1) / PV_E + 255) / 256;
     int rc = poly_scratch(ctx, 2 * (*nblocks + 1), hdr, partials);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &(*hdr)->ps[0], fr_from_host(z), (const Fr*)nullptr);
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &(*hdr)->ps[0], host_pow2(z, nullptr));
     return BBG_OK;
 }
 
@@ -277,9 +353,11 @@ int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* 
     Fr* partials;
     rc = poly_scratch(ctx, a.stride * count, &hdr, &partials);
     if (rc) return rc;
-    const Fr z = fr_from_host(zeta);
-    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[0], z, (const Fr*)nullptr);
-    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[1], z, (const Fr*)&((const DomainConsts*)dc)->root);
+    uint64_t root[4];
+    rc = ntt_domain_root_host(ctx, log2n, root); // the small domain's generator w (host copy kept with the domain)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[0], host_pow2(zeta, nullptr));
+    hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[1], host_pow2(zeta, root));
     hipLaunchKernelGGL(k_multi_eval_partial, dim3((unsigned)a.stride, (unsigned)count), dim3(256), 0, st, a, (const PolyScratch*)hdr->ps, partials);
     hipLaunchKernelGGL(k_multi_eval_final, dim3((unsigned)count), dim3(256), 0, st, (const Fr*)partials, a.stride, hdr->results);
     BBG_HIP(hipGetLastError());

@@ -61,10 +61,9 @@ __device__ __forceinline__ Fr fr_small(uint32_t k)
 struct QuotientChallenges {
     Fr v[9]; // alpha_base, alpha, beta, gamma, delta, g, k1, k2, k3
 };
-__global__ void k_quotient_setup(QuotientSetup* s, QuotientChallenges in, const Fr* alpha_base_dev)
+__device__ __forceinline__ void quotient_setup_one(QuotientSetup* s, const QuotientChallenges& in, const Fr& alpha_base)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const Fr alpha_base = alpha_base_dev ? fe_load<FrP>(alpha_base_dev) : in.v[0], alpha = in.v[1];
+    const Fr alpha = in.v[1];
     s->alpha = alpha;
     s->beta = in.v[2];
     s->gamma = in.v[3];
@@ -96,6 +95,26 @@ __global__ void k_quotient_setup(QuotientSetup* s, QuotientChallenges in, const 
     s->alpha_out[5] = s->alpha_out[0];               // permutation, 3 wires
     s->alpha_out[6] = s->ap[1];                      // standard arithmetic: 1 relation
     s->alpha_out[7] = s->ap[2];                      // MiMC: 2 relations
+}
+__global__ void k_quotient_setup(QuotientSetup* s, QuotientChallenges in, const Fr* alpha_base_dev)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    quotient_setup_one(s, in, alpha_base_dev ? fe_load<FrP>(alpha_base_dev) : in.v[0]);
+}
+// The set-up blocks of a whole widget chain in ONE launch: block w starts from the alpha_out block w - 1 produced for its widget (r4: a
+// launch per widget was a chain of five 31-us single-lane kernels, 0.16 ms of every proof).
+struct WidgetChain {
+    int count;
+    int widget[8];
+};
+__global__ void k_quotient_setup_chain(QuotientSetup* setups, QuotientChallenges in, WidgetChain chain)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fr alpha_base = in.v[0];
+    for (int w = 0; w < chain.count; w++) {
+        quotient_setup_one(setups + w, in, alpha_base);
+        alpha_base = setups[w].alpha_out[chain.widget[w]];
+    }
 }
 
 #define QLOAD(id, idx) fe_load<FrP>(a.p[id] + (idx))
@@ -745,9 +764,13 @@ int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const vo
     // the alpha_base chain runs over the set-up kernels alone (block w reads the alpha_out of block w - 1), so the widget kernels behind
     // them may run in any order and share passes: arithmetic + range + logic of a TurboPLONK chain go through the data once
     int pos_arith = -1, pos_range = -1, pos_logic = -1;
+    {
+        WidgetChain chain;
+        chain.count = count;
+        for (int w = 0; w < 8; w++) chain.widget[w] = w < count ? widgets[w] : 0;
+        hipLaunchKernelGGL(k_quotient_setup_chain, dim3(1), dim3(64), 0, st, setups, ch, chain);
+    }
     for (int w = 0; w < count; w++) {
-        const Fr* prev = w ? &setups[w - 1].alpha_out[widgets[w - 1]] : nullptr;
-        hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, setups + w, ch, prev);
         if (widgets[w] == 1 && pos_arith < 0) pos_arith = w;
         if (widgets[w] == 3 && pos_range < 0) pos_range = w;
         if (widgets[w] == 4 && pos_logic < 0) pos_logic = w;
