@@ -760,7 +760,7 @@ def real_prover_baseline(log2_gates):
         t0 = time.perf_counter()
         W.prove_reference()
         warm.append(time.perf_counter() - t0)
-    ok.append(W.verify())
+    ok.append(W.verify())  # after the loop: the proofs run back to back
     W.free()
     W.wrap_trim()
     t_wrap = sorted(warm)[2]
