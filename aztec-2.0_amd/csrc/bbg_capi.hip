@@ -266,7 +266,7 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         return BBG_OK;
     }
     if (!strcmp(key, "msm_window")) {
-        if (value != 0 && msm_width_slot((int)value) < 0) { set_error("msm_window must be 0 (automatic) or a compiled width: 16, 17, 19, 20, 22"); return BBG_E_INVALID; }
+        if (value != 0 && msm_width_slot((int)value) < 0) { set_error("msm_window must be 0 (automatic) or a compiled width: 13, 16, 17, 19, 20, 22"); return BBG_E_INVALID; }
         ctx->msm_window = (int)value;
         return BBG_OK;
     }

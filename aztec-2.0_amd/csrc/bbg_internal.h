@@ -49,7 +49,7 @@ struct NttDomain {
 struct Srs {
     size_t n = 0;          // number of (plain) points
     void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical (= window 0 of a table below)
-    static constexpr int MAX_WIDTHS = 5;
+    static constexpr int MAX_WIDTHS = 6;
     void* tables[MAX_WIDTHS] = {}; // window tables T[w][i] = 2^(MsmCfg<C>::table_offset(w)) P_i (balanced windows, halved weight for the narrow ones: msm_cfg.h) per compiled width C (slot = msm_width_slot(C), msm.hip); built on first use
     int home_slot = -1;    // the table built at registration: its window 0 IS `points`, so it is never released before the handle
     int device = 0;

@@ -271,13 +271,18 @@ int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipSt
 // full additions per bucket) that grows with 2^(C-1) and runs beside the NEXT call's sort -- the reference widens its buckets with n
 // for the same reason (get_optimal_bucket_width, runtime_states.hpp:9-63).  The thresholds are measured (profiles/r03_window_sweep.txt,
 // tests/tools/msm_window_sweep.py: pipelined MSMs, every compiled width, interleaved); msm_window = 0 selects them, a compiled width forces one.
+#ifndef MSM_SMALL_WINDOW_MAX_LOG2N
+#define MSM_SMALL_WINDOW_MAX_LOG2N 14 // the 13-bit configuration is the automatic choice up to 2^14 terms (profiles/r04_window13_sweep.txt: it wins by 4-10 % there, ties at 2^13-2^14, loses from 2^15 -- its four-bin second sort level serialises on LDS counters once partitions hold a thousand entries)
+#endif
 int msm_auto_window(size_t n)
 {
     if (n >= ((size_t)1 << 23)) return 22; // 2^23: 9.8 vs 10.1 ms, 2^24: 18.3 vs 19.1 ms (22 vs 20 bits, pipelined); 2^22: 5.25 vs 4.94
     if (n >= ((size_t)1 << 21)) return 20; // 2^21: 2.72 (20) / 2.73 (19) / 2.79 (17); 2^22: 5.13 (20) / 5.56 (19)
     if (n >= ((size_t)1 << 20)) return 19; // 2^20: MSM + NTT step 1.48 (19) / 1.49 (17) / 1.54 (20) / 1.53 (16): the 29-bit-limb accumulation made
                                            // an entry cheaper, so one more window and half the buckets pay (20 bits won with the 32-bit limbs)
-    return 16;                             // 2^19: 0.80 (16) / 0.85 (19); 2^18: 0.51 vs 0.55 (17); 2^16: 0.233 vs 0.235 (17)
+    // (+ 1024: StandardPLONK commits to n + 1 coefficients over an SRS of n + 1 points -- the same configuration as its n-term MSMs)
+    if (n > ((size_t)1 << MSM_SMALL_WINDOW_MAX_LOG2N) + 1024) return 16; // 2^19: 0.80 (16) / 0.85 (19); 2^18: 0.51 vs 0.55 (17); 2^16: 0.233 vs 0.235 (17)
+    return 13;                             // small circuits: 2^12 buckets instead of 2^15 (r4; profiles/r04_window13_sweep.txt)
 }
 int msm_pick_window(const bbg_ctx* ctx, size_t n)
 {
@@ -314,6 +319,13 @@ static int msm_choose(bbg_ctx* ctx, Srs& srs, size_t max_n, bool build, hipStrea
         for (int k = 0; k < MSM_NUM_WIDTHS; k++)
             if (srs.tables[k] && (best < 0 || abs(MSM_WIDTHS[k] - c) < abs(MSM_WIDTHS[best] - c))) best = k;
         if (best >= 0) c = MSM_WIDTHS[best];
+    }
+    if (msm_windows_for(c) > 16 && srs.n > ((size_t)1 << 26)) { // the 20-window configuration indexes 2^26 points (msm_cfg.h)
+        if (ctx->msm_window == c) {
+            set_error("bbg_msm: msm_window = 13 indexes at most 2^26 points per device");
+            return BBG_E_INVALID;
+        }
+        c = 16;
     }
     *c_out = c;
     if (!build) return BBG_OK;

@@ -14,6 +14,8 @@ namespace bbg {
 // 15 x 17).  Cutting W windows of C bits from the bottom instead leaves a top window with a handful of bits (C = 19: 7, C = 22: 12) whose n
 // digits all land in the first few buckets -- one partition of the sort then holds n entries and its single block runs for a millisecond
 // (measured, profiles/r03_window_sweep_a.txt).  Widths whose W equals a narrower width's (18 -> 17, 21 -> 20) are pointless and not compiled.
+// C = 13 (r4: 20 windows, 2^12 buckets) is the small-circuit configuration: at n = 2^12 .. 2^16 the 2^15 buckets of C = 16 hold one to thirty
+// entries each and the bucket reduction (two additions per bucket, per MSM of a batch) costs as much as the accumulation.
 // Each configuration has its own window tables T[w][i] = 2^(table_offset(w)) P_i, built the first time it is used on an SRS, and its own
 // translation unit (msm_wNN.hip) so that the configurations compile side by side.
 template <int C> struct MsmCfg {
@@ -21,7 +23,12 @@ template <int C> struct MsmCfg {
     static constexpr int windows = (254 + C) / C;           // C * windows >= 255
     static constexpr int nwide = 255 - windows * (C - 1);   // windows [0, nwide) have C bits, the rest C - 1
     static_assert(nwide >= 1 && nwide <= windows, "use the narrower configuration with the same number of windows");
-    static_assert(windows <= 16, "the window field of a sorted value has four bits");
+    // A sorted value = sign (bit 31) | window | point index.  Up to 16 windows the window field has 4 bits and the index 27 (2^27 points per device);
+    // narrower configurations (C = 13: 20 windows -- the small-circuit end, where 2^(C-1) buckets must not outnumber the entries) take a 5-bit
+    // window field and a 26-bit index.  The reference's schedule word: 32 index bits (scalar_multiplication.hpp:24-29).
+    static_assert(windows <= 32, "the window field of a sorted value has at most five bits");
+    static constexpr int win_bits = windows > 16 ? 5 : 4;
+    static constexpr int idx_bits = 31 - win_bits;
     static constexpr int width(int w) { return w < nwide ? C : C - 1; }
     static constexpr int offset(int w) { return w * (C - 1) + (w < nwide ? w : nwide); } // first scalar bit of window w; offset(windows) = 255
     // A narrow window's digits d fill only the lower half of the bucket range; filed under bucket d they would double the load of the lower
@@ -36,16 +43,16 @@ template <int C> struct MsmCfg {
     static constexpr int log_rows = C - 1 - log_cols;
     static constexpr int planes = C - 1;               // bit planes of the weight idx + 1 <= 2^(C-1)
 };
-constexpr int MSM_MAX_WINDOWS = 16;
-// A sorted value = sign (bit 31) | window (4 bits) | point index (27 bits): up to 16 windows (every compiled width) over up to 2^27 points per
+constexpr int MSM_MAX_WINDOWS = 20;
+// The widest point index a sorted value carries (MsmCfg<C>::idx_bits of the configurations with up to 16 windows): up to 2^27 points per
 // device -- the whole 100.8 M-point Ignition SRS (2^26.6) fits one device's format, as it fits its HBM (12 windows x 64 B x 2^27 = 103 GB).
-// The reference's schedule word carries a 32-bit index (scalar_multiplication.hpp:24-29); beyond 2^27 points an SRS is sharded by point
-// range across devices (bbg_multi_*).  (Round 3: 26 bits -- a bit was left unused between the window field and the sign.)
+// Beyond 2^27 points an SRS is sharded by point range across devices (bbg_multi_*).  (Round 3: 26 bits -- a bit was left unused between the
+// window field and the sign.)  The 20-window configuration C = 13 indexes 2^26 points; it is chosen for small MSMs only.
 constexpr int MSM_IDX_BITS = 27;
 constexpr int MSM_MAX_PLANES = 32;
 
 // every width with a translation unit msm_wNN.hip (X-macro: dispatch tables in msm.hip, option parsing, table slots in Srs)
-#define BBG_MSM_WIDTHS(X) X(16) X(17) X(19) X(20) X(22)
+#define BBG_MSM_WIDTHS(X) X(13) X(16) X(17) X(19) X(20) X(22)
 
 // a batch of `sets` MSMs (1 .. BBG_MSM_BATCH_MAX; MSM k: n[k] terms from point from[k], result at d_out_jac + 96 k) with C-bit windows over
 // `table` (window tables of this width) through one launch set; defined in msm_kernels.hip.h, instantiated in msm_wNN.hip

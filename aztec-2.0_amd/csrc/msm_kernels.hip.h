@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #ifdef BBG_ROCPRIM_SORT // A/B build only (make ROCPRIM_SORT=1): k_recode + rocPRIM radix sort + k_offsets instead of the partition sort
 #include <rocprim/device/device_radix_sort.hpp>
 #endif
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) k_recode(const Fr* __restrict__ scalars, 
 #pragma unroll
     for (int w = 0; w < MsmCfg<C>::windows; w++) {
         keys[(size_t)w * n + i] = mag[w];
-        vals[(size_t)w * n + i] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
+        vals[(size_t)w * n + i] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MsmCfg<C>::idx_bits) | (uint32_t)(from + i);
     }
 }
 
@@ -262,7 +263,11 @@ k_sortA_scatter(const MsmBatch batch, uint32_t* cursor, uint64_t* entries)
     __shared__ uint32_t gbase[SORT_PAD];  // this block's first global slot in each partition, minus lstart
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t st_val[CAP];
-    __shared__ uint32_t st_mag[CAP];
+    // bucket ids fit 16 bits where there are more than 16 windows (C <= 15: ids <= 2^14), and must: 20 windows x 1024 scalars x 8 bytes would be
+    // the whole LDS of a CU
+    using StMag = typename std::conditional<(MSM_WINDOWS > 16), uint16_t, uint32_t>::type;
+    static_assert(MSM_WINDOWS <= 16 || MsmCfg<C>::buckets < 65536, "16-bit staging of bucket ids");
+    __shared__ StMag st_mag[CAP];
     const int tid = threadIdx.x;
     hist[tid] = 0;
     hist[tid + 1024] = 0;
@@ -296,8 +301,8 @@ k_sortA_scatter(const MsmBatch batch, uint32_t* cursor, uint64_t* entries)
         const uint32_t rank = lds_take(hist, h, on);
         if (on) {
             const uint32_t slot = lstart[h] + rank;
-            st_val[slot] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MSM_IDX_BITS) | (uint32_t)(from + i);
-            st_mag[slot] = mag[w];
+            st_val[slot] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MsmCfg<C>::idx_bits) | (uint32_t)(from + i);
+            st_mag[slot] = (StMag)mag[w];
         }
     }
     __syncthreads();
@@ -500,9 +505,10 @@ constexpr uint32_t MSM_SEG_MIN = 8, MSM_SEG_DEFAULT = 64; // segment length is c
 constexpr size_t MSM_QUAD_ACC_MAX_LANES = 32768; // k_accumulate_q4 up to this many lane segments (two waves per SIMD of quads)
 constexpr int MSM_LONG_SPAN = 48; // buckets spanning more lanes than this are summed by a whole block
 
-__device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ table, size_t n_srs, uint32_t v)
+template <int C> __device__ __forceinline__ Affine load_entry_point(const Affine* __restrict__ table, size_t n_srs, uint32_t v)
 {
-    return aff_load(table + (size_t)((v >> MSM_IDX_BITS) & 15u) * n_srs + (v & ((1u << MSM_IDX_BITS) - 1)));
+    using K = MsmCfg<C>;
+    return aff_load(table + (size_t)((v >> K::idx_bits) & ((1u << K::win_bits) - 1)) * n_srs + (v & ((1u << K::idx_bits) - 1)));
 }
 
 template <int C> __global__ void __launch_bounds__(256)
@@ -529,7 +535,7 @@ k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off
     bool first_run = true;
     Xyzz acc = xyzz_inf();
     uint32_t v = vals[s];
-    Affine p = load_entry_point(table, n_srs, v);
+    Affine p = load_entry_point<C>(table, n_srs, v);
     for (uint32_t q = s; q < e; q++) {
         if (q == cur_end) { // the run of bucket `cur` ended inside this segment
             if (first_run) xyzz_store(head + lane, acc);
@@ -545,7 +551,7 @@ k_accumulate(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off
         const Affine pc = p;
         if (q + 1 < e) { // software prefetch of the next gather
             v = vals[q + 1];
-            p = load_entry_point(table, n_srs, v);
+            p = load_entry_point<C>(table, n_srs, v);
         }
         acc = xyzz_madd(acc, aff_neg_if(pc, (vc >> 31) != 0));
     }
@@ -580,7 +586,7 @@ k_accumulate_q4(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ 
     bool first_run = true;
     Xyzz acc = xyzz_inf();
     uint32_t v = vals[s];
-    Affine p = load_entry_point(table, n_srs, v);
+    Affine p = load_entry_point<C>(table, n_srs, v);
     for (uint32_t q = s; q < e; q++) {
         if (q == cur_end) {
             if (qd == 0) {
@@ -598,7 +604,7 @@ k_accumulate_q4(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ 
         const Affine pc = p;
         if (q + 1 < e) {
             v = vals[q + 1];
-            p = load_entry_point(table, n_srs, v);
+            p = load_entry_point<C>(table, n_srs, v);
         }
         acc = xyzz_madd_q4(acc, aff_neg_if(pc, (vc >> 31) != 0), qd);
     }
@@ -656,7 +662,7 @@ k_accumulate29(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ o
         xyzz_store(dst, out);
     };
     uint32_t v = vals[s];
-    Affine p = load_entry_point(table, n_srs, v);
+    Affine p = load_entry_point<C>(table, n_srs, v);
     for (uint32_t q = s; q < e; q++) {
         if (q == cur_end) { // the run of bucket `cur` ended inside this segment
             emit(first_run ? head + lane : buckets + (cur - 1));
@@ -671,7 +677,7 @@ k_accumulate29(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ o
         const Affine pc = p;
         if (q + 1 < e) { // software prefetch of the next gather
             v = vals[q + 1];
-            p = load_entry_point(table, n_srs, v);
+            p = load_entry_point<C>(table, n_srs, v);
         }
         if (!aff_is_inf(pc)) {
             const Aff29 pt = aff29_from_table(pc, (vc >> 31) != 0);
@@ -703,7 +709,7 @@ k_redo(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, 
         Xyzz acc = xyzz_inf();
         for (uint32_t q = sb + threadIdx.x; q < eb; q += 256) {
             const uint32_t v = vals[q];
-            acc = xyzz_madd(acc, aff_neg_if(load_entry_point(table, n_srs, v), (v >> 31) != 0));
+            acc = xyzz_madd(acc, aff_neg_if(load_entry_point<C>(table, n_srs, v), (v >> 31) != 0));
         }
         acc = block_reduce(acc, sm, 256);
         if (threadIdx.x == 0) {
@@ -887,7 +893,7 @@ template <int C> __global__ void __launch_bounds__(256, 1) k_rowcol(const Xyzz* 
     cols += (size_t)blockIdx.y * COLS;
     if (blockIdx.x < ROWS) {
         const int hi = blockIdx.x;
-        Xyzz v = xyzz_load(buckets + (size_t)hi * COLS + tid);
+        Xyzz v = tid < COLS ? xyzz_load(buckets + (size_t)hi * COLS + tid) : xyzz_inf(); // (C = 13: 64 columns)
         for (int lo = tid + 256; lo < COLS; lo += 256) v = xyzz_add(v, xyzz_load(buckets + (size_t)hi * COLS + lo));
         v = block_reduce(v, sm, 256);
         if (tid == 0) xyzz_store(rows + hi, v);

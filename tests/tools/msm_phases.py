@@ -22,7 +22,7 @@ out = torch.zeros(12, dtype=torch.int64, device="cuda")
 bbg.set_option("msm_async_reduce", 1)
 for lg in sizes:
     n = 1 << lg
-    for w in (16, 17, 19, 20, 22):
+    for w in (13, 16, 17, 19, 20, 22):
         bbg.set_option("msm_window", w)
         for _ in range(3):
             bbg.msm_device(srs, d_sc.data_ptr(), n, out.data_ptr())

@@ -85,7 +85,7 @@ int main()
         EXPECT(bbg_msm_batch(ctx, srs, 5, ptrs, bad, lens, batch) == BBG_E_INVALID);
         int c = 0, w = 0;
         CK(bbg_msm_plan(ctx, srs, N, &c, &w));
-        EXPECT(c == 16 && w == 16);
+        EXPECT(c == 13 && w == 20); // the small-circuit configuration
     }
     // ---- NTT family, sizes up and down (domain cache, scratch regrowth)
     for (unsigned lg : { 10u, 13u, 4u, 12u, 1u, 11u }) {
