@@ -152,6 +152,33 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* ctr, uint32_t key, bool a
     return r;
 }
 
+// The same for a counter array of a FEW bins (the second sort level of the 13-bit configuration: 4 bins per partition): with a thousand
+// entries on four counters the per-lane atomics of lds_take serialise (measured: a 2^16-term MSM 0.81 ms against 0.34 with 16-bit windows).
+// Here every bin is counted with one ballot per wave and reserved with ONE atomic per wave and bin; the lane's rank is its position among
+// the wave's lanes of the same bin.
+template <int BINS> __device__ __forceinline__ uint32_t lds_take_few(uint32_t* ctr, uint32_t key, bool active)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t below_mask = (1ull << lane) - 1;
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < BINS; b++) {
+        const uint64_t m = __ballot(active && key == (uint32_t)b);
+        if (m) { // wave-uniform
+            uint32_t base = 0;
+            if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&ctr[b], (uint32_t)__popcll(m));
+            base = __shfl(base, (int)__builtin_ctzll(m));
+            if (active && key == (uint32_t)b) r = base + (uint32_t)__popcll(m & below_mask);
+        }
+    }
+    return r;
+}
+template <int BINS> __device__ __forceinline__ uint32_t lds_take_bins(uint32_t* ctr, uint32_t key, bool active)
+{
+    if constexpr (BINS <= 8) return lds_take_few<BINS>(ctr, key, active);
+    else return lds_take(ctr, key, active);
+}
+
 // exclusive scan of tbl[0 .. SORT_PAD) by a 1024-thread block, two adjacent entries per thread; returns the pair's
 // exclusive prefixes.  wsum = 16 words of LDS scratch.
 __device__ __forceinline__ void block_scan_pairs(const uint32_t* tbl, uint32_t* wsum, uint32_t& excl0, uint32_t& c0, uint32_t& c1)
@@ -387,7 +414,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
             e[u] = q < len ? v : ~0ull;
         }
 #pragma unroll
-        for (int u = 0; u < PER; u++) lds_take(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
+        for (int u = 0; u < PER; u++) lds_take_bins<BINS>(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
     } else {
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
             uint32_t key[UNROLL];
@@ -398,7 +425,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
                 key[u] = q < len ? k : 0xffffffffu;
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) lds_take(hist, key[u] & SORT_LO_MASK, key[u] != 0xffffffffu);
+            for (int u = 0; u < UNROLL; u++) lds_take_bins<BINS>(hist, key[u] & SORT_LO_MASK, key[u] != 0xffffffffu);
         }
     }
     __syncthreads();
@@ -415,7 +442,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const bool on = e[u] != ~0ull;
-            const uint32_t pos = lds_take(off, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, on);
+            const uint32_t pos = lds_take_bins<BINS>(off, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, on);
             if (on) stage[pos] = (uint32_t)e[u];
         }
         __syncthreads();
@@ -441,7 +468,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
                 x[u] = q < len ? v : ~0ull;
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) rk[u] = lds_take(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
+            for (int u = 0; u < UNROLL; u++) rk[u] = lds_take_bins<BINS>(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
             __syncthreads();
             block_scan_bins<BINS, TPB>(cnt, cstart, wsum); // exclusive scan of this chunk's counts
             __syncthreads();
