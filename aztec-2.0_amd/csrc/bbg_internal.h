@@ -120,6 +120,7 @@ struct bbg_ctx {
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
     int prover_msm_batch = 4; // option "prover_msm_batch": commitments of a prover round per launch set (0 / 1 = one each; prover.hip commit())
+    bool quotient_limbs29 = true; // option "quotient_limbs29": permutation / fixed-base / fused arithmetic + range + logic widgets on lazily reduced 29-bit limbs (quotient29.hip.h; 0 = the 32-bit kernels, A/B)
     bool quotient_fuse = true; // option "quotient_fuse": arithmetic + range + logic widgets of a chain in one pass over the wires (0 = one kernel each, A/B)
     int msm_window = 0; // 0 = automatic (msm_auto_window), or one of the compiled widths (BBG_MSM_WIDTHS)
     int msm_sort = 1; // 1 = fused recode + MSD partition sort (msm.hip), 0 = k_recode + rocPRIM radix sort + k_offsets

@@ -31,6 +31,7 @@ constexpr int WIDGET_COUNT = 8;
 struct QuotientSetup {
     Fr ap[7];       // alpha_base * alpha^k
     Fr alpha, beta, gamma, delta;
+    Fr alpha2, alpha3x2; // alpha^2, 2 alpha^3: the logic identity's Horner chain written as a sum (quotient29.hip.h)
     Fr alpha_base_sqr;
     Fr beta_g;      // beta * g (g = the small domain's coset generator): beta*g*w^i is the identity-permutation term
     Fr k1, k2, k3;  // coset generators of the wire columns 2..4 (fr::coset_generator(0..2))
@@ -65,6 +66,11 @@ __device__ __forceinline__ void quotient_setup_one(QuotientSetup* s, const Quoti
 {
     const Fr alpha = in.v[1];
     s->alpha = alpha;
+    s->alpha2 = fe_sqr(alpha);
+    {
+        const Fr a3 = fe_mul(s->alpha2, alpha);
+        s->alpha3x2 = fe_add(a3, a3);
+    }
     s->beta = in.v[2];
     s->gamma = in.v[3];
     s->delta = in.v[4];
@@ -430,6 +436,10 @@ __global__ void __launch_bounds__(256) k_quotient_turbo_arith_range_logic(Quotie
     fe_store<FrP>(a.quotient + i, fe_add(q, total));
 }
 
+} // namespace bbg
+#include "quotient29.hip.h"
+namespace bbg {
+
 // ---------------------------------------------------------------------------------------------- permutation grand product
 // z of ProverPermutationWidget<W,false>::compute_round_commitments (permutation_widget_impl.hpp:48-268, steps 1-3; the blinding of
 // the last rows and the ifft stay with the caller):
@@ -708,6 +718,24 @@ static const uint32_t WIDGET_NEEDS[WIDGET_COUNT] = {
 static int launch_widget(bbg_ctx* ctx, int widget, const QuotientArgs& a, size_t m, hipStream_t st)
 {
     ProfScope ps(ctx, "quotient_widget", st);
+    if (ctx->quotient_limbs29) { // the 29-bit-limb kernels of quotient29.hip.h
+        switch (widget) {
+        case 0: hipLaunchKernelGGL(q29::k_quotient29_permutation<4>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL(q29::k_quotient29_permutation<3>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+        case 2:
+            hipLaunchKernelGGL(q29::k_quotient29_turbo_fixed_base_linear, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(q29::k_quotient29_turbo_fixed_base_gate, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+            break;
+        case 1: hipLaunchKernelGGL(q29::k_quotient29_turbo_arith_range_logic<1>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, a.s, a.s); break;
+        case 3: hipLaunchKernelGGL(q29::k_quotient29_turbo_arith_range_logic<2>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, a.s, a.s); break;
+        case 4: hipLaunchKernelGGL(q29::k_quotient29_turbo_arith_range_logic<4>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, a.s, a.s); break;
+        case 6: hipLaunchKernelGGL(q29::k_quotient29_standard_arith, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+        case 7: hipLaunchKernelGGL(q29::k_quotient29_mimc, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a); break;
+        default: set_error("bbg_quotient_widget_device: unknown widget"); return BBG_E_INVALID;
+        }
+        BBG_HIP(hipGetLastError());
+        return BBG_OK;
+    }
     switch (widget) {
     case 0: hipLaunchKernelGGL(k_quotient_permutation<4>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
     case 5: hipLaunchKernelGGL(k_quotient_permutation<3>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
@@ -786,7 +814,10 @@ int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const vo
     if (fuse) {
         ProfScope ps(ctx, "quotient_widget", st);
         a.s = setups + pos_arith;
-        hipLaunchKernelGGL(k_quotient_turbo_arith_range_logic, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, setups + pos_range, setups + pos_logic);
+        if (ctx->quotient_limbs29)
+            hipLaunchKernelGGL(q29::k_quotient29_turbo_arith_range_logic<7>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, setups + pos_range, setups + pos_logic);
+        else
+            hipLaunchKernelGGL(k_quotient_turbo_arith_range_logic, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, setups + pos_range, setups + pos_logic);
         BBG_HIP(hipGetLastError());
     }
     if (alpha_out) {

@@ -1012,22 +1012,42 @@ def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0, widgets=(0, 1, 2,
         yield alpha_base, quot.cpu().numpy().view(np.uint64).reshape(-1, 4)
 
 
+@pytest.mark.parametrize("limbs29,coarse", [(1, False), (1, True), (0, False)])
 @pytest.mark.parametrize("log2_large", [3, 5, 8, 13])
-def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large):
+def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large, limbs29, coarse):
     """All eight widgets against the oracle's restatement (itself pinned by the reference goldens / live reference proofs) on arbitrary
-    challenge values -- public_input_delta, g, k1..k3 are NOT the transcript / field constants here -- and on the smallest legal domain."""
+    challenge values -- public_input_delta, g, k1..k3 are NOT the transcript / field constants here -- and on the smallest legal domain.
+    limbs29: the kernels on lazily reduced 29-bit limbs (quotient29.hip.h, default) or the 32-bit ones.  coarse: every input polynomial is
+    handed over as x + p (the upper half of the [0, 2p) range the prover's coset FFTs fill): the largest values the compile-time bounds of
+    the 29-bit kernels are priced for."""
     m = 1 << log2_large
     polys = [pkg.synthetic_scalars(5000 + 31 * log2_large + k, m) for k in range(23)]
     ch9 = pkg.synthetic_scalars(6000 + log2_large, 9)
     quot = np.zeros((m, 4), dtype=np.uint64)
     alpha_base = ch9[0].copy()
     order = (0, 1, 2, 3, 4, 5, 7, 6)  # after the TurboPLONK five: MiMCComposer's list (5 assigns again; MiMC and arithmetic accumulate)
-    for widget, (alpha_out, q) in zip(order, _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, ch9[0], order)):
-        ch = ch9.copy()
-        ch[0] = alpha_base
-        alpha_base = oracle.quotient_widget(widget, polys, log2_large, ch, quot)
-        assert np.array_equal(oracle.canon(0, alpha_out.reshape(1, 4))[0], alpha_base), widget
-        assert np.array_equal(oracle.canon(0, q), oracle.canon(0, quot)), widget
+    gpu_polys = polys
+    if coarse:
+        P = int("30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", 16)
+        def plus_p(a):
+            out = np.empty_like(a)
+            for r in range(a.shape[0]):
+                v = sum(int(a[r, k]) << (64 * k) for k in range(4)) + P
+                assert v < 2 * P
+                out[r] = [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+            return out
+        gpu_polys = [plus_p(p) for p in polys]
+    bbg.set_option("quotient_limbs29", limbs29)
+    try:
+        for widget, (alpha_out, q) in zip(order, _run_gpu_widgets(pkg, bbg, gpu_polys, log2_large, ch9, ch9[0], order)):
+            ch = ch9.copy()
+            ch[0] = alpha_base
+            alpha_base = oracle.quotient_widget(widget, polys, log2_large, ch, quot)
+            assert np.array_equal(oracle.canon(0, alpha_out.reshape(1, 4))[0], alpha_base), widget
+            assert np.array_equal(oracle.canon(0, q), oracle.canon(0, quot)), widget
+            assert (q[:, 3] <= np.uint64(0x60c89ce5c2634053)).all(), widget  # every stored residue below 2p (top word of 2p = 0x60c89ce5c2634053)
+    finally:
+        bbg.set_option("quotient_limbs29", 1)
 
 
 def test_quotient_widgets_vs_reference_golden(pkg, oracle, bbg):
@@ -1731,9 +1751,15 @@ def test_quotient_fused_widgets_equal_separate(pkg, bbg):
         separate = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
         bbg.set_option("quotient_fuse", 1)
         fused = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
+        bbg.set_option("quotient_limbs29", 0)  # the 32-bit-limb kernels: fused, then one per widget
+        fused32 = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
+        bbg.set_option("quotient_fuse", 0)
+        separate32 = _prover_rounds_1_to_4(pkg, bbg, lib, h, n)
     finally:
         bbg.set_option("quotient_fuse", 1)
+        bbg.set_option("quotient_limbs29", 1)
     assert np.array_equal(separate, fused)
+    assert np.array_equal(fused32, fused) and np.array_equal(separate32, fused)
     lib.bbg_prover_destroy(h)
     srs.free()
 
