@@ -37,23 +37,7 @@ namespace bbg {
 __device__ __constant__ uint32_t FR_PRIMITIVE_ROOT_28[8] = { 0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u,
                                                              0x1eb203d8u, 0x56452ac0u, 0x2963f9e7u, 0x1860ef94u };
 
-__device__ Fr fr_pow_u256(Fr a, const uint32_t* e)
-{
-    Fr acc = Fr::one();
-    for (int i = 255; i >= 0; i--) {
-        acc = fe_sqr(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
-    }
-    return acc;
-}
-__device__ Fr fr_invert(Fr a)
-{
-    uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = FrP::MOD[i];
-    e[0] -= 2; // p - 2 (low limb 0xf0000001, no borrow)
-    return fr_pow_u256(a, e);
-}
+__device__ Fr fr_invert(Fr a) { return fe_inverse_gcd<FrP, true>(a); } // (field.hip.h: binary extended Euclid, a fifth of the a^(p-2) chain)
 
 // evaluation_domain constructor restated on device (polynomials/evaluation_domain.cpp:57-76;
 // get_root_of_unity: ecc/fields/field_impl.hpp:496-503; coset_generator(0) = 5: fr.hpp:44-59).

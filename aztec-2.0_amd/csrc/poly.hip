@@ -484,19 +484,7 @@ int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, c
 }
 
 // ---------------------------------------------------------------------------------------------- divide by Z*_H
-__device__ Fr fr_inv_fermat(Fr a)
-{
-    uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = FrP::MOD[i];
-    e[0] -= 2;
-    Fr acc = Fr::one();
-    for (int i = 255; i >= 0; i--) {
-        acc = fe_sqr(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
-    }
-    return acc;
-}
+__device__ Fr fr_inv_fermat(Fr a) { return fe_inverse_gcd(a); } // (the name is history: field.hip.h's binary extended Euclid since r4)
 // compute_multiplicative_subgroup (:119-138) + the "- 1", invert, numerator constants (:680-697)
 __global__ void k_dpv_setup(DpvConsts* c, const DomainConsts* src, const DomainConsts* ext_dom, int log2_src, int ext, int cut)
 {

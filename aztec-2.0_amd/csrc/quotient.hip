@@ -46,14 +46,11 @@ struct QuotientArgs {
     const DomainConsts* dc; // large (4n) domain: root and its power-of-two table
 };
 
-__device__ __forceinline__ Fr fr_small(uint32_t k)
+__device__ __forceinline__ Fr fr_small(uint32_t k) // the Montgomery residue of a small integer: one product with R^2 (r4: was 32 doublings)
 {
-    Fr one = Fr::one(), acc = Fr::zero();
-    for (int b = 31; b >= 0; b--) {
-        acc = fe_add(acc, acc);
-        if ((k >> b) & 1) acc = fe_add(acc, one);
-    }
-    return acc;
+    Fr v = Fr::zero();
+    v.v[0] = k;
+    return fe_reduce_once(fe_to_mont(v));
 }
 // challenges arrive as Montgomery limbs from the host, BY VALUE as a kernel argument (no pageable-memory copy whose source the
 // caller could reuse before it ran); everything derived from them is computed here (the product has no CPU field arithmetic).
@@ -62,19 +59,25 @@ __device__ __forceinline__ Fr fr_small(uint32_t k)
 struct QuotientChallenges {
     Fr v[9]; // alpha_base, alpha, beta, gamma, delta, g, k1, k2, k3
 };
-__device__ __forceinline__ void quotient_setup_one(QuotientSetup* s, const QuotientChallenges& in, const Fr& alpha_base)
+// consts: a block of the same launch whose challenge-independent constants and alpha powers are already there (the chain kernel fills
+// them once and copies: 17 products per further block instead of 30)
+__device__ __forceinline__ void quotient_setup_one(QuotientSetup* s, const QuotientChallenges& in, const Fr& alpha_base, const QuotientSetup* consts = nullptr)
 {
     const Fr alpha = in.v[1];
     s->alpha = alpha;
-    s->alpha2 = fe_sqr(alpha);
-    {
+    if (consts) {
+        s->alpha2 = consts->alpha2;
+        s->alpha3x2 = consts->alpha3x2;
+        s->beta_g = consts->beta_g;
+    } else {
+        s->alpha2 = fe_sqr(alpha);
         const Fr a3 = fe_mul(s->alpha2, alpha);
         s->alpha3x2 = fe_add(a3, a3);
+        s->beta_g = fe_mul(in.v[2], in.v[5]);
     }
     s->beta = in.v[2];
     s->gamma = in.v[3];
     s->delta = in.v[4];
-    s->beta_g = fe_mul(s->beta, in.v[5]);
     s->k1 = in.v[6];
     s->k2 = in.v[7];
     s->k3 = in.v[8];
@@ -85,13 +88,18 @@ __device__ __forceinline__ void quotient_setup_one(QuotientSetup* s, const Quoti
     }
     s->alpha_base_sqr = fe_sqr(alpha_base);
     s->one = Fr::one();
-    s->c2 = fr_small(2);
-    s->c3 = fr_small(3);
-    s->c6 = fr_small(6);
-    s->c7 = fr_small(7);
-    s->c17 = fr_small(17);
-    s->c81 = fr_small(81);
-    s->c83 = fr_small(83);
+    if (consts) {
+        s->c2 = consts->c2; s->c3 = consts->c3; s->c6 = consts->c6; s->c7 = consts->c7;
+        s->c17 = consts->c17; s->c81 = consts->c81; s->c83 = consts->c83;
+    } else {
+        s->c2 = fr_small(2);
+        s->c3 = fr_small(3);
+        s->c6 = fr_small(6);
+        s->c7 = fr_small(7);
+        s->c17 = fr_small(17);
+        s->c81 = fr_small(81);
+        s->c83 = fr_small(83);
+    }
     // update_alpha (transition_widget.hpp:88-94): alpha_powers[num_independent_relations - 1] * alpha
     s->alpha_out[0] = fe_sqr(s->alpha_base_sqr);     // permutation: alpha_base^4 (permutation_widget_impl.hpp:419)
     s->alpha_out[1] = fe_mul(s->ap[1], alpha);       // arithmetic: 2 relations
@@ -118,7 +126,7 @@ __global__ void k_quotient_setup_chain(QuotientSetup* setups, QuotientChallenges
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fr alpha_base = in.v[0];
     for (int w = 0; w < chain.count; w++) {
-        quotient_setup_one(setups + w, in, alpha_base);
+        quotient_setup_one(setups + w, in, alpha_base, w ? setups : nullptr);
         alpha_base = setups[w].alpha_out[chain.widget[w]];
     }
 }
@@ -450,22 +458,11 @@ namespace bbg {
 //   k_gp_terms  : block = 1024 rows (256 threads x 4): N_i, D_i; in-block inclusive prefix of N -> z[j+1], in-block exclusive suffix of D
 //                 -> sd[j]; block totals of both
 //   k_gp_blocks : one block: exclusive prefix of the N block totals, exclusive suffix of the D block totals, the grand total of D
-//   k_gp_invert : one lane: (prod_all D)^-1  (a 0.25 ms dependency chain: the prover overlaps it with the wires' coset FFTs)
+//   k_gp_invert : one lane: (prod_all D)^-1  (a dependency chain -- 0.32 ms as a^(p-2), r4: binary extended Euclid --: the prover overlaps it with
+//                 the wires' coset FFTs)
 //   k_gp_apply  : z[j+1] *= (prefix of earlier blocks) * sd[j] * (suffix of later blocks) * inverse
 constexpr int GP_E = 4, GP_BLOCK_ROWS = 256 * GP_E;
-__device__ inline Fr fr_inverse(const Fr& a) // a^(r-2)
-{
-    uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = FrP::MOD[i];
-    e[0] -= 2;
-    Fr acc = Fr::one();
-    for (int i = 253; i >= 0; i--) {
-        acc = fe_sqr(acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul(acc, a);
-    }
-    return acc;
-}
+__device__ inline Fr fr_inverse(const Fr& a) { return fe_inverse_gcd<FrP, true>(a); } // field.hip.h: binary extended Euclid on the scalar unit (one lane, one input), canonical result
 struct GpArgs {
     const Fr* w[4];
     const Fr* sigma[4];
@@ -591,7 +588,10 @@ __global__ void __launch_bounds__(256) k_gp_blocks(Fr* bt, size_t B)
 }
 __global__ void k_gp_invert(Fr* bt, size_t B)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) bt[2 * B + 1] = fe_reduce_once(fr_inverse(bt[2 * B])); // a zero D has probability ~2^-230 (random beta, gamma)
+    // every lane of the (single) wave computes the same inverse from the same address: uniform data, no divergent branch around the chain, so it
+    // runs on the scalar unit (fe_inverse_gcd<.., true>); one lane stores.  A zero D has probability ~2^-230 (random beta, gamma).
+    const Fr inv = fr_inverse(fe_load<FrP>(bt + 2 * B));
+    if (threadIdx.x == 0 && blockIdx.x == 0) fe_store<FrP>(bt + 2 * B + 1, inv);
 }
 __global__ void __launch_bounds__(256) k_gp_apply(GpArgs a)
 {
