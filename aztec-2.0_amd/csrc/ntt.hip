@@ -1002,13 +1002,28 @@ template <class P> __global__ void k_field_op(int op, const Fe<P>* a, const Fe<P
     case 5: z = fe_to_mont(x); break;
     case 8: z = fe_mul_sub2(x, x, y, y); break;                       // x^2 - y^2, single reduction
     case 9: z = fe_mul_sub2(fe_neg(x), fe_neg(y), x, fe_neg(y)); break; // extreme operands (2p - x ...): = 2xy
+    case 10: z = fe_inverse_gcd<P, false>(x); break;                  // the Montgomery residue of 1 / x (0 -> 0), one lane per element
     default: z = x; break;
     }
     fe_store<P>(out + i, fe_reduce_once(z));
 }
+// op 11: the same inverse through the scalar-unit variant (every lane of a wave holds the same input): one wave per element
+template <class P> __global__ void k_field_inverse_uniform(const Fe<P>* a, Fe<P>* out)
+{
+    Fe<P> x = fe_load<P>(a + blockIdx.x);
+    for (int k = 0; k < 5; k++) x = fe_reduce_once(x);
+    const Fe<P> z = fe_inverse_gcd<P, true>(x);
+    if (threadIdx.x == 0) fe_store<P>(out + blockIdx.x, z);
+}
 int field_op_device(int which, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st)
 {
     if (n == 0) return BBG_OK;
+    if (op == 11) {
+        if (which == 0) hipLaunchKernelGGL(k_field_inverse_uniform<FrP>, dim3((unsigned)n), dim3(64), 0, st, (const Fr*)a, (Fr*)out);
+        else hipLaunchKernelGGL(k_field_inverse_uniform<FqP>, dim3((unsigned)n), dim3(64), 0, st, (const Fq*)a, (Fq*)out);
+        BBG_HIP(hipGetLastError());
+        return BBG_OK;
+    }
     if (which == 0)
         hipLaunchKernelGGL(k_field_op<FrP>, dim3(grid_for(n, 256)), dim3(256), 0, st, op, (const Fr*)a, (const Fr*)b, (Fr*)out, n);
     else

@@ -384,7 +384,8 @@ int bbg_profile_enable(bbg_ctx* ctx, int on);
 int bbg_profile_get(bbg_ctx* ctx, const char* name, double* total_ms, size_t* launches);
 /* Field-level self test entry used by tests: out[i] = a[i] (op) b[i] computed by the device field code.
  * which: 0 Fr, 1 Fq.  op: 0 mul, 1 add, 2 sub, 3 mul via the CIOS cross-check path, 4 from_montgomery, 5 to_montgomery,
- * 6/7 mul / CIOS mul without pre-reduction, 8 a*a - b*b and 9 (-a)(-b) - a(-b) through the fused two-product multiplier. */
+ * 6/7 mul / CIOS mul without pre-reduction, 8 a*a - b*b and 9 (-a)(-b) - a(-b) through the fused two-product multiplier,
+ * 10 / 11 the inverse of a (0 -> 0) by the binary extended Euclid of the set-up kernels, per lane / on the scalar unit (one wave per element). */
 int bbg_field_op(bbg_ctx* ctx, int which, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 
 #ifdef __cplusplus

@@ -56,6 +56,28 @@ def test_field_ops(pkg, oracle, bbg, which):
     assert np.array_equal(bbg.field_op(which, 9, a, b), oracle.fe_add(which, ab, ab))
 
 
+@pytest.mark.parametrize("which", [0, 1])
+def test_field_inverse_gcd(pkg, oracle, bbg, which):
+    """The single-lane inversion of the set-up kernels (field.hip.h fe_inverse_gcd: Kaliski's binary extended Euclid, then a product with a
+    power of two), per lane (op 10) and on the scalar unit (op 11), against Python's modular inverse: random residues, 0, 1, 2, p - 1,
+    powers of two (the shortest and longest runs of the shift loop), un-reduced representatives."""
+    p = (0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47)[which]
+    R = 1 << 256
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 253, (1 << 253) + 1, (1 << 200) - 1, 5, p + 5, 2 * p - 1, (1 << 256) - 1]
+    rnd = pkg.synthetic_scalars(77 + which, 600)
+    vals += [sum(int(rnd[i, k]) << (64 * k) for k in range(4)) for i in range(rnd.shape[0])]
+    a = np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in vals], dtype=np.uint64)
+    want = []
+    for v in vals:
+        x = v % p  # the residue a R the words stand for
+        std = x * pow(R, -1, p) % p
+        w = 0 if std == 0 else pow(std, -1, p) * R % p
+        want.append([(w >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)])
+    want = np.array(want, dtype=np.uint64)
+    assert np.array_equal(bbg.field_op(which, 10, a), want)
+    assert np.array_equal(bbg.field_op(which, 11, a[:200]), want[:200])
+
+
 def test_field_reference_kats(bbg, oracle, kats):
     for name, which, op in (("fr_mul", 0, 0), ("fr_add", 0, 1), ("fr_sub", 0, 2), ("fq_mul", 1, 0), ("fq_mul_short", 1, 0),
                             ("fq_add", 1, 1), ("fq_sub", 1, 2), ("fr_sqr", 0, 0), ("fq_sqr", 1, 0)):
