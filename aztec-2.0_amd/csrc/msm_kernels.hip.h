@@ -302,10 +302,13 @@ k_sortA_scatter(const MsmBatch batch, uint32_t* cursor, uint64_t* entries)
     const size_t i = (size_t)blockIdx.x * SORT_BLOCK + tid;
     uint32_t mag[MSM_MAX_WINDOWS], signs = 0;
     if (i < n) recode_digits<C>(scalars, i, mag, signs);
+    // ONE round of LDS atomics (r4): the value a counting atomic returns IS the entry's rank inside its partition; it waits in a register while
+    // the counts are scanned (a second, ranking round of 14 atomics per scalar cost a quarter of the kernel)
+    uint32_t rank[MSM_MAX_WINDOWS];
 #pragma unroll
     for (int w = 0; w < MSM_WINDOWS; w++) {
         const bool on = i < n && mag[w] != 0;
-        lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
+        rank[w] = lds_take(hist, on ? mag[w] >> SORT_LO_BITS : 0u, on);
     }
     __syncthreads();
     uint32_t excl, c0, c1;
@@ -317,17 +320,14 @@ k_sortA_scatter(const MsmBatch batch, uint32_t* cursor, uint64_t* entries)
         lstart[h1] = excl + c0;
         gbase[h0] = (c0 ? atomicAdd(&cursor[h0], c0) : 0u) - excl; // one global reservation per (block, partition)
         gbase[h1] = (c1 ? atomicAdd(&cursor[h1], c1) : 0u) - (excl + c0);
-        hist[h0] = 0;
-        hist[h1] = 0;
     }
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < MSM_WINDOWS; w++) {
         const bool on = i < n && mag[w] != 0;
         const uint32_t h = on ? mag[w] >> SORT_LO_BITS : 0u;
-        const uint32_t rank = lds_take(hist, h, on);
         if (on) {
-            const uint32_t slot = lstart[h] + rank;
+            const uint32_t slot = lstart[h] + rank[w];
             st_val[slot] = (((signs >> w) & 1u) << 31) | ((uint32_t)w << MsmCfg<C>::idx_bits) | (uint32_t)(from + i);
             st_mag[slot] = (StMag)mag[w];
         }
@@ -404,6 +404,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     for (int b = tid; b < BINS; b += TPB) hist[b] = 0;
     __syncthreads();
     uint64_t e[PER];
+    uint32_t rk[PER]; // fast path: the entry's rank inside its bucket, as the counting atomic returned it
     constexpr uint32_t CHUNK = TPB * UNROLL;
     const uint32_t span = (len + CHUNK - 1) / CHUNK * CHUNK; // whole waves stay in the loops (lds_take is wave-cooperative)
     if (fast) {
@@ -414,7 +415,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
             e[u] = q < len ? v : ~0ull;
         }
 #pragma unroll
-        for (int u = 0; u < PER; u++) lds_take_bins<BINS>(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull);
+        for (int u = 0; u < PER; u++) rk[u] = lds_take_bins<BINS>(hist, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, e[u] != ~0ull); // count AND rank (r4)
     } else {
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
             uint32_t key[UNROLL];
@@ -441,9 +442,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
     if (fast) {
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const bool on = e[u] != ~0ull;
-            const uint32_t pos = lds_take_bins<BINS>(off, (uint32_t)(e[u] >> 32) & SORT_LO_MASK, on);
-            if (on) stage[pos] = (uint32_t)e[u];
+            if (e[u] != ~0ull) stage[off[(uint32_t)(e[u] >> 32) & SORT_LO_MASK] + rk[u]] = (uint32_t)e[u];
         }
         __syncthreads();
         for (uint32_t q = tid; q < len; q += TPB) svals[pb + q] = stage[q];
@@ -458,7 +457,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
         uint32_t* stage_bin = stage + CHUNK;
         for (uint32_t q0 = 0; q0 < span; q0 += CHUNK) {
             uint64_t x[UNROLL];
-            uint32_t rk[UNROLL];
+            uint32_t crk[UNROLL];
             for (int b = tid; b < BINS; b += TPB) cnt[b] = 0;
             __syncthreads();
 #pragma unroll
@@ -468,7 +467,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
                 x[u] = q < len ? v : ~0ull;
             }
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) rk[u] = lds_take_bins<BINS>(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
+            for (int u = 0; u < UNROLL; u++) crk[u] = lds_take_bins<BINS>(cnt, (uint32_t)(x[u] >> 32) & SORT_LO_MASK, x[u] != ~0ull);
             __syncthreads();
             block_scan_bins<BINS, TPB>(cnt, cstart, wsum); // exclusive scan of this chunk's counts
             __syncthreads();
@@ -476,7 +475,7 @@ k_sortB(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ part_
             for (int u = 0; u < UNROLL; u++) {
                 if (x[u] != ~0ull) {
                     const uint32_t b = (uint32_t)(x[u] >> 32) & SORT_LO_MASK;
-                    const uint32_t slot = cstart[b] + rk[u];
+                    const uint32_t slot = cstart[b] + crk[u];
                     stage_val[slot] = (uint32_t)x[u];
                     stage_bin[slot] = b;
                 }
