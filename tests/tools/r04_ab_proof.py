@@ -13,6 +13,10 @@ import bench  # noqa: E402
 
 bbg = pkg.Bbg(0)
 bbg.set_stream(torch.cuda.current_stream().cuda_stream)
+# OPT=key=value[,key=value] sets library options first (e.g. OPT=ntt_limbs29=1)
+for kv in filter(None, os.environ.get("OPT", "").split(",")):
+    k, v = kv.split("=")
+    bbg.set_option(k, int(v))
 for lg in [int(a) for a in sys.argv[1:]] or [20]:
     srs = bbg.srs_synth_hashed(0xBB254, 1 << lg)
     for _ in range(2):
