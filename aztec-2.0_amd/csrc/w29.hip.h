@@ -56,6 +56,8 @@ template <int C> __device__ __forceinline__ W<C, (C ? 64 : 2) * 64, M29> ld(cons
     return { f29_from_fe<FrP, C ? 5 : 0>(x) };
 }
 
+// one product of a dot().  Holds REFERENCES: write t(...) inside the dot(...) call, where temporaries such as ld<1>(x) live until the whole
+// expression is done; a Term kept in a variable would outlive them.
 template <class A, class B> struct Term {
     const A& a;
     const B& b;
