@@ -261,6 +261,10 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->prover_msm_batch = (int)value;
         return BBG_OK;
     }
+    if (!strcmp(key, "prover_early_cosets")) {
+        ctx->prover_early_cosets = value != 0;
+        return BBG_OK;
+    }
     if (!strcmp(key, "quotient_limbs29")) {
         ctx->quotient_limbs29 = value != 0;
         return BBG_OK;

@@ -119,6 +119,7 @@ struct bbg_ctx {
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    bool prover_early_cosets = true; // option "prover_early_cosets": the wires' 4n coset forms are queued behind round 1's last commitment (beside its reduce phase) instead of in front of round 3's grand product
     int prover_msm_batch = 4; // option "prover_msm_batch": commitments of a prover round per launch set (0 / 1 = one each; prover.hip commit())
     bool quotient_limbs29 = true; // option "quotient_limbs29": permutation / fixed-base / fused arithmetic + range + logic widgets on lazily reduced 29-bit limbs (quotient29.hip.h; 0 = the 32-bit kernels, A/B)
     bool quotient_fuse = true; // option "quotient_fuse": arithmetic + range + logic widgets of a chain in one pass over the wires (0 = one kernel each, A/B)

@@ -88,6 +88,7 @@ struct bbg_prover {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_up[4] = {};
     int stage = 0; // rounds completed in the current proof (guards the call order)
+    bool wire_cosets_done = false; // round 1 already queued the wires' 4n coset forms (option prover_early_cosets)
     std::vector<void*> allocs;
     size_t device_bytes = 0; // sum of `allocs` (bbg_prover_device_bytes, bbg_memory_report)
 };
@@ -400,6 +401,17 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
         int rc = commit(p, cnt, p->wire_coeff + k0, lens, k0, st);
         if (rc) return rc;
     }
+    // The wires' values on the 4n coset (the FFT work items of round 3, prover.cpp:255-264) depend on nothing but the wires: queued here they
+    // run beside the last commitment's accumulation and fill its reduce phase -- a chain of short kernels that leaves most of the chip idle at
+    // the end of the round -- instead of standing in front of round 3's grand product.
+    p->wire_cosets_done = false;
+    if (p->ctx->prover_early_cosets) {
+        for (int k = 0; k < p->width; k++) {
+            int rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+            if (rc) return rc;
+        }
+        p->wire_cosets_done = true;
+    }
     int rc = fetch_commitments(p, (size_t)p->width, commitments, st);
     if (rc) return rc;
     BBG_HIP(hipStreamSynchronize(p->copy_stream));
@@ -426,7 +438,7 @@ int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamm
     // main stream does the part of the round that does not depend on z -- the wires' coset FFTs (the FFT work items, prover.cpp:255-264)
     int rc = permutation_grand_product_begin(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, ch, p->z_coeff, st, p->copy_stream,
                                              p->ev_up[0], p->ev_up[1]);
-    for (int k = 0; k < p->width && !rc; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+    for (int k = 0; k < p->width && !rc && !p->wire_cosets_done; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
     if (!rc) rc = permutation_grand_product_finish(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, p->z_coeff, st, p->ev_up[1]);
     if (rc) return rc;
     // rows n-3 .. n-1 carry the zero-knowledge blinding of z (permutation_widget_impl.hpp:283-287); pinned staging, stream ordered
