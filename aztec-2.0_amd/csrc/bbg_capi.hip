@@ -265,6 +265,10 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->prover_early_cosets = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "prover_fail_round")) { // tests only: the next call of this prover round (1, 3, 4, 5, 6) fails once, as a device error would
+        ctx->prover_fail_round = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "quotient_limbs29")) {
         ctx->quotient_limbs29 = value != 0;
         return BBG_OK;
@@ -304,7 +308,7 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         if (value != 1 && value != 2) { set_error("ntt_kernel must be 1 or 2"); return BBG_E_INVALID; }
         ctx->ntt_kernel = (int)value;
     } else if (!strcmp(key, "ntt_big_tile")) {
-        if (value < 0 || value > 2) { set_error("ntt_big_tile must be 0, 1 or 2"); return BBG_E_INVALID; }
+        if (value < 0 || value > 3) { set_error("ntt_big_tile must be 0 .. 3"); return BBG_E_INVALID; }
         ctx->ntt_big_tile = (int)value;
     } else if (!strcmp(key, "ntt_max_logr8")) {
         if (value < 6 || value > 11) { set_error("ntt_max_logr8 must be 6..11"); return BBG_E_INVALID; }
@@ -334,6 +338,7 @@ int bbg_memory_report(bbg_ctx* ctx, bbg_memory_info* out)
         for (const bbg_srs* s : g_live_srs) {
             if (s->ctx != ctx) continue;
             out->live_srs++;
+            std::lock_guard<std::mutex> lk2(const_cast<bbg_srs*>(s)->s.mu);
             for (int k = 0; k < Srs::MAX_WIDTHS; k++)
                 if (s->s.tables[k]) out->srs_tables += s->s.n * (size_t)msm_windows_for(msm_width_of_slot(k)) * 64;
         }
@@ -385,6 +390,10 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
             std::lock_guard<std::mutex> lk2(g_srs_mu);
             for (bbg_srs* s : g_live_srs) {
                 if (s->ctx != ctx) continue;
+                // an MSM issued through ANOTHER context on this SRS holds Srs::mu while it picks a table and queues the kernels that read
+                // it: with the lock, whatever was queued before is on the device, and the synchronisation below waits for it
+                std::lock_guard<std::mutex> lk3(s->s.mu);
+                BBG_HIP(hipDeviceSynchronize());
                 for (int k = 0; k < Srs::MAX_WIDTHS; k++)
                     if (s->s.tables[k] && k != s->s.home_slot) { // the registration table holds the plain points: it stays
                         (void)hipFree(s->s.tables[k]);
@@ -395,7 +404,7 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
     }
     rc = bbg_memory_report(ctx, &after);
     if (rc) return rc;
-    if (released) *released = before.total - after.total;
+    if (released) *released = before.total > after.total ? before.total - after.total : 0; // another thread may have allocated in between
     return BBG_OK;
 }
 

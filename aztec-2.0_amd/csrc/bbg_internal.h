@@ -53,6 +53,10 @@ struct Srs {
     void* tables[MAX_WIDTHS] = {}; // window tables T[w][i] = 2^(MsmCfg<C>::table_offset(w)) P_i (balanced windows, halved weight for the narrow ones: msm_cfg.h) per compiled width C (slot = msm_width_slot(C), msm.hip); built on first use
     int home_slot = -1;    // the table built at registration: its window 0 IS `points`, so it is never released before the handle
     int device = 0;
+    // tables[] may be read, built (first MSM of a width) and released (bbg_memory_trim of the owning context) from DIFFERENT contexts'
+    // threads: held from the choice of a table until every kernel that reads it is queued, and by the trim around its device
+    // synchronisation + free (lock order: bbg_ctx::mu -> g_srs_mu -> Srs::mu)
+    std::mutex mu;
 };
 
 struct MsmScratch {
@@ -119,6 +123,7 @@ struct bbg_ctx {
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    int prover_fail_round = 0;       // option "prover_fail_round" (tests only): the next bbg_prover_round<k> returns BBG_E_HIP once -- how the shim's fallback to the reference body is exercised
     bool prover_early_cosets = true; // option "prover_early_cosets": the wires' 4n coset forms are queued behind round 1's last commitment (beside its reduce phase) instead of in front of round 3's grand product
     int prover_msm_batch = 4; // option "prover_msm_batch": commitments of a prover round per launch set (0 / 1 = one each; prover.hip commit())
     bool quotient_limbs29 = true; // option "quotient_limbs29": permutation / fixed-base / fused arithmetic + range + logic widgets on lazily reduced 29-bit limbs (quotient29.hip.h; 0 = the 32-bit kernels, A/B)

@@ -351,6 +351,7 @@ int msm_plan(bbg_ctx* ctx, const Srs* srs, size_t n, int* c_out)
         *c_out = msm_pick_window(ctx, n);
         return BBG_OK;
     }
+    std::lock_guard<std::mutex> srs_lk(const_cast<Srs*>(srs)->mu);
     return msm_choose(ctx, const_cast<Srs&>(*srs), n, false, nullptr, c_out);
 }
 
@@ -386,6 +387,7 @@ int msm_run_batch(bbg_ctx* ctx, Srs& srs, int sets, const void* const* d_scalars
         return BBG_OK;
     }
     int c = 0;
+    std::lock_guard<std::mutex> srs_lk(srs.mu); // until the accumulation that gathers from the table is queued (Srs::mu)
     int rc = msm_choose(ctx, srs, max_n, true, st, &c);
     if (rc) return rc;
     const void* table = srs.tables[msm_width_slot(c)];

@@ -1254,8 +1254,18 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
     const int cap_sets = (ctx->msm_zero_c == C && ctx->msm_zero_sets > sets) ? ctx->msm_zero_sets : sets;
     int rc = msm_layout<C>(total_n, sets, cap_sets, ctx->msm_sort == 0, L, ctx->msm_acc_waves);
     if (rc) return rc;
+    // The "already cleared" record (msm_zero_*) describes ONE allocation, not an address: a regrown arena may come back at the same base
+    // with arbitrary contents, and a call that fails between the counting kernel and the scan that clears the counters again leaves them
+    // non-zero.  So the record is dropped whenever the arena is (re)allocated and whenever this function leaves early (round-4 advisor).
+    struct ZeroRecordGuard {
+        bbg_ctx* c;
+        bool done = false;
+        ~ZeroRecordGuard() { if (!done) c->msm_zero_buf = nullptr; }
+    } zero_guard{ctx};
+    const size_t arena_had = ctx->msm.bytes;
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
+    if (ctx->msm.bytes != arena_had) ctx->msm_zero_buf = nullptr;
     if (!ctx->aux_stream) {
         // the reduce phase is latency work that only has to finish before its result is consumed: a LOW-priority stream, so that what
         // the caller queues next on the main stream (the following MSM's sort / accumulation, an NTT) is dispatched first
@@ -1461,6 +1471,7 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
         ctx->ev_done_valid[slot] = true;
     }
     BBG_HIP(hipGetLastError());
+    zero_guard.done = true;
     return BBG_OK;
 }
 

@@ -352,14 +352,14 @@ static void plan_passes(bbg_ctx* ctx, NttDomain& d)
     const int L = (int)d.log2n;
     d.use_pass8 = false;
     d.tile_log8 = P8_TILE_LOG;
-    if (ctx->ntt_kernel == 2 && ((ctx->ntt_big_tile >= 1 && L == 21) || (ctx->ntt_big_tile >= 2 && L == 22))) {
+    if (ctx->ntt_kernel == 2 && ((ctx->ntt_big_tile >= 1 && L == 21) || (ctx->ntt_big_tile >= 2 && L == 22) || (ctx->ntt_big_tile >= 3 && L == 20))) {
         // 4096-element tiles (512 threads): radix 2^11 x 2^10 in TWO passes, W = 2 / 4 columns per tile -- one whole pass over the array (and
         // its inter-pass twiddle table) less than the 2048-tile plan's three passes, paid for with 64-byte instead of 256-byte global runs.
         // Measured (HIP events, 50 back-to-back transforms): 2^21 0.2537 vs 0.2604 ms (kept, default); 2^22 (2^11 x 2^11, W = 2 in both
         // passes) 0.518 vs 0.502 ms (option value 2 only).
         d.passes = 2;
-        d.logR[0] = 11;
-        d.logR[1] = L - 11;
+        d.logR[0] = L == 20 ? 10 : 11; // (2^20 with 4096-element tiles: round-5 experiment, option value 3 -- 128-byte runs in the column pass, one block of eight waves per CU)
+        d.logR[1] = L - d.logR[0];
         d.logW[0] = P8_TILE_LOG_BIG - d.logR[0];
         d.logW[1] = P8_TILE_LOG_BIG - d.logR[1];
         d.tile_log8 = P8_TILE_LOG_BIG;
@@ -537,6 +537,22 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     const int R = 1 << p.logR, W = 1 << p.logW;
     const size_t lds_bytes = ((size_t)2 * W * (R + 1) + R) * 16 + 64;
     const size_t tiles = ((size_t)1 << d.log2n) >> (p.logR + p.logW);
+#ifdef BBG_NTT_FAST_AB // experiment builds only (build_ab/): k_ntt_pass29 at radix 2^7, 2^8, 2^10 alone -- n = 2^20, 2^22, 2^24 -- compiles in a fraction of the time
+    if (d.use_pass8) {
+        bool& attr29 = ctx->ntt_attr29_set;
+        if (!attr29) {
+            BBG_HIP(p29_attr<7>()); BBG_HIP(p29_attr<8>()); BBG_HIP(p29_attr<10>()); BBG_HIP((p29_attr<10, P8_TILE_LOG_BIG>()));
+            attr29 = true;
+        }
+        ProfScope ps(ctx, "ntt_pass", st);
+        if (d.tile_log8 == P8_TILE_LOG && p.logR == 10) p29_launch<10>(p, tiles, st);
+        else if (d.tile_log8 == P8_TILE_LOG_BIG && p.logR == 10) p29_launch<10, P8_TILE_LOG_BIG>(p, tiles, st);
+        else if (d.tile_log8 == P8_TILE_LOG && p.logR == 8) p29_launch<8>(p, tiles, st);
+        else if (d.tile_log8 == P8_TILE_LOG && p.logR == 7) p29_launch<7>(p, tiles, st);
+        else { set_error("ntt: BBG_NTT_FAST_AB build (radix 2^7, 2^8, 2^10 passes only: 2^20, 2^22, 2^24)"); return BBG_E_INVALID; }
+        return BBG_OK;
+    }
+#else
     if (d.use_pass8) {
         bool& attr8 = ctx->ntt_attr8_set; // hipFuncSetAttribute is per device: the flag lives in the context, not in a process-wide static
         if (!attr8) {
@@ -623,6 +639,7 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
         }
         return BBG_OK;
     }
+#endif
     bool& attr_set = ctx->ntt_attr_set;
     if (!attr_set) {
         BBG_HIP(hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

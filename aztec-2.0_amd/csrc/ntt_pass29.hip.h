@@ -14,7 +14,23 @@
 
 namespace bbg {
 
-template <int TL> constexpr size_t p29_lds_bytes() { return (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_TABLE_WORDS * 4; }
+// BBG_NTT29_EXCH1 (round 5): the exchange moves all nine words of an element in ONE round -- write, barrier, read: two barriers per exchange
+// instead of four -- through a buffer that holds the whole tile: limbs 0..3 and 4..7 as two 16-byte planes, limb 8 as a 4-byte plane, 36 bytes
+// per element and NO padding (a 2048-element tile: 73 728 B + 3 072 B of tables = 76 800 B, two blocks per CU in 153.6 of the 160 KB).  Bank
+// conflicts are kept down by an XOR swizzle of the slot index instead of padding (p29_slot; chosen on scripts/model/lds_conflicts.py, the
+// lane groups of MI355X_MICROARCH.md's LDS table: cheaper than the two-per-sixteen padding of the 16-byte planes on every step pattern).
+#ifndef BBG_NTT29_EXCH1
+#define BBG_NTT29_EXCH1 0
+#endif
+template <int TL> constexpr size_t p29_lds_bytes()
+{
+    return BBG_NTT29_EXCH1 ? ((size_t)36 << TL) + NTT29_TABLE_WORDS * 4 : (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_TABLE_WORDS * 4;
+}
+__device__ __forceinline__ int p29_slot(int p, int c, int logW) // swizzled slot of tile element (p, c): a bijection of [0, tile)
+{
+    const int q = (p << logW) + c;
+    return q ^ ((q >> 3) & 15);
+}
 
 __device__ __forceinline__ Fr29 p29_load_tw(const uint32_t* __restrict__ tw29, int idx) // a table row: 9 exact limbs of a value < p
 {
@@ -58,6 +74,9 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     int c0, pb0, ql0, c1, pb1, ql1;
     p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
     p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+#if defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 1) // timing experiment only (wrong results): no exchange at all
+    return;
+#endif
     if (T > 0) __syncthreads(); // everybody has taken limbs 4..7 of the previous exchange out of the buffer
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -87,6 +106,37 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     }
 }
 
+// single-round form of p29_exchange (BBG_NTT29_EXCH1): lo = limbs 0..3, hi = limbs 4..7, top = limb 8, one slot index for all three
+template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29_exchange1(Fr29 (&x)[8], uint4* lo, uint4* hi, uint32_t* top)
+{
+#if defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 1)
+    return;
+#endif
+    constexpr int LOGW = TL - LOGR;
+    constexpr int F0 = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    constexpr int F1 = (LOGR - 3 * (T + 1) >= 3) ? (LOGR - 3 * (T + 2)) : 0;
+    int c0, pb0, ql0, c1, pb1, ql1;
+    p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
+    p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+    if (T > 0) __syncthreads(); // everybody has read the previous exchange's elements
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int a = p29_slot(pb0 | (j << F0), c0, LOGW);
+        lo[a] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
+        hi[a] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
+        top[a] = x[j].v[8];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int a = p29_slot(pb1 | (j << F1), c1, LOGW);
+        const uint4 l = lo[a], h = hi[a];
+        x[j].v[0] = l.x; x[j].v[1] = l.y; x[j].v[2] = l.z; x[j].v[3] = l.w;
+        x[j].v[4] = h.x; x[j].v[5] = h.y; x[j].v[6] = h.z; x[j].v[7] = h.w;
+        x[j].v[8] = top[a];
+    }
+}
+
 // Two waves per SIMD (no register cap); the eight output multipliers are fetched where they are used.  Measured (profiles/r04_ntt29_ab.txt,
 // isolated fft, ms): capping the kernel at 168 VGPRs for three waves gives the same times with 23-46 spills (2^20 0.1193 vs 0.1190); fetching
 // the multipliers behind the data loads as k_ntt_pass8 does -- 64 registers held through the whole pass -- is SLOWER (2^20 0.1236 vs 0.1187,
@@ -100,12 +150,36 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
 template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), BBG_NTT29_OCC) k_ntt_pass29(PassParams p)
 {
     extern __shared__ uint4 lds[];
+#if BBG_NTT29_EXCH1
+    uint4* buf = lds;                  // limbs 0..3
+    uint4* bufhi = lds + (1 << TL);    // limbs 4..7
+    uint32_t* buf8 = reinterpret_cast<uint32_t*>(lds + (2 << TL)); // limb 8
+    uint32_t* red = buf8 + (1 << TL);
+#define P29_EXCHANGE(T) p29_exchange1<LOGR, ROW, T, TL>(x, buf, bufhi, buf8)
+#else
     uint4* buf = lds;
     uint32_t* buf8 = reinterpret_cast<uint32_t*>(lds + p8_plane<TL>());
     uint32_t* red = buf8 + p8_plane<TL>(); // 16-byte aligned: p8_plane is a multiple of 4
+#define P29_EXCHANGE(T) p29_exchange<LOGR, ROW, T, TL>(x, buf, buf8)
+#endif
     constexpr int NSTEPS = (LOGR + 2) / 3;
     constexpr int LOGW = TL - LOGR;
     if (threadIdx.x < NTT29_RED_ROWS) ntt29_fill_reduce_table(red, threadIdx.x);
+#if defined(BBG_NTT29_STAGGER_TICKS) // timing experiment: half of the blocks start late (ticks of the 100 MHz constant clock)
+    {
+#if BBG_NTT29_STAGGER_MODE == 1
+        const bool late = blockIdx.x & 1;
+#elif BBG_NTT29_STAGGER_MODE == 3 // the second half of the FIRST round of blocks only: later rounds inherit the phase shift
+        const bool late = blockIdx.x >= 256 && blockIdx.x < 512;
+#else
+        const bool late = (blockIdx.x >> 8) & 1;
+#endif
+        if (late) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < BBG_NTT29_STAGGER_TICKS) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+#endif
     const size_t tile = blockIdx.x;
     size_t base = 0, lo0 = 0, d1_0 = 0, rest = 0;
     int logRestCount = 0;
@@ -140,16 +214,24 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
                     for (int i = 0; i < 9; i++) x[j].v[i] = 0;
                     continue;
                 }
+#if defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 2) // timing experiment only: no global loads
+                { Fr t; for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)g * 2654435761u + i; t.v[7] &= 0x0fffffffu; x[j] = f29_from_fe<FrP, 0>(t); }
+#else
                 x[j] = f29_from_fe<FrP, 0>(fe_load<FrP>(p.in + g));
+#endif
                 if (p.pre && g < p.pre_count) x[j] = f29_mul(x[j], f29_from_fe<FrP, 5>(fe_load<FrP>(p.pre + g))); // V < 2 * 64 / 169 + 1
                 continue;
             }
             g = (((((d1_0 + c) << logRestCount) + rest)) << LOGR) + pj;
+#if defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 2)
+            { Fr t; for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)g * 2654435761u + i; t.v[7] &= 0x0fffffffu; x[j] = f29_from_fe<FrP, 0>(t); }
+#else
             x[j] = f29_from_fe<FrP, 0>(fe_load<FrP>(p.in + g));
+#endif
         }
     }
     Fr outmul[8];
-    if (BBG_NTT29_PREFETCH && have_outmul) {
+    if (BBG_NTT29_PREFETCH == 1 && have_outmul) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             int pj, cc;
@@ -157,20 +239,34 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
             outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, cc, base, lo0, d1_0, rest, true));
         }
     }
+    // BBG_NTT29_PREFETCH == 2 (round 5): the multipliers are requested in front of the LAST exchange where the last step is a cheap one
+    // (radix 2 or 4: log-radix 10, 8, 7 ...): 64 registers held through an exchange and a few butterflies, not through the whole pass
+    constexpr bool LATE_PREFETCH = BBG_NTT29_PREFETCH == 2 && NSTEPS > 1 && (LOGR % 3) != 0;
+    auto fetch_outmul = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int pj, cc;
+            p8_last_coords<LOGR, TL>(threadIdx.x, j, pj, cc);
+            outmul[j] = fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, cc, base, lo0, d1_0, rest, true));
+        }
+    };
     __syncthreads(); // the reduction table is complete
     p29_compute<LOGR, 0>(x, tw29, qlo, red);
     if constexpr (NSTEPS > 1) {
-        p29_exchange<LOGR, ROW, 0, TL>(x, buf, buf8);
+        if constexpr (LATE_PREFETCH && NSTEPS == 2) { if (have_outmul) fetch_outmul(); }
+        P29_EXCHANGE(0);
         p8s_coords<LOGR, ROW, 1, TL>(threadIdx.x, c, pbase, qlo);
         p29_compute<LOGR, 1>(x, tw29, qlo, red);
     }
     if constexpr (NSTEPS > 2) {
-        p29_exchange<LOGR, ROW, 1, TL>(x, buf, buf8);
+        if constexpr (LATE_PREFETCH && NSTEPS == 3) { if (have_outmul) fetch_outmul(); }
+        P29_EXCHANGE(1);
         p8s_coords<LOGR, ROW, 2, TL>(threadIdx.x, c, pbase, qlo);
         p29_compute<LOGR, 2>(x, tw29, qlo, red);
     }
     if constexpr (NSTEPS > 3) {
-        p29_exchange<LOGR, ROW, 2, TL>(x, buf, buf8);
+        if constexpr (LATE_PREFETCH && NSTEPS == 4) { if (have_outmul) fetch_outmul(); }
+        P29_EXCHANGE(2);
         p8s_coords<LOGR, ROW, 3, TL>(threadIdx.x, c, pbase, qlo);
         p29_compute<LOGR, 3>(x, tw29, qlo, red);
     }
@@ -182,13 +278,21 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
         for (int j = 0; j < 8; j++) {
             const int pj = pbase | (j << F);
             Fr v;
+#if defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 2) // timing experiment only: no twiddle loads, a store nobody executes
+            if (have_outmul) { Fr t; for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)pj * 40503u + i + c; t.v[7] &= 0x0fffffffu; v = n29_finish_mul(x[j], t, red); }
+            else v = n29_finish(x[j], red);
+            if (v.v[0] == 0x12345678u && v.v[1] == 0x9abcdef0u && v.v[5] == 77u) fe_store<FrP>(p.out + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false), v);
+#else
             if (have_outmul)
-                v = n29_finish_mul(x[j], BBG_NTT29_PREFETCH ? outmul[j] : fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, true)), red);
+                v = n29_finish_mul(x[j], (BBG_NTT29_PREFETCH == 1 || LATE_PREFETCH) ? outmul[j] : fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, true)), red);
             else v = n29_finish(x[j], red);
             fe_store<FrP>(p.out + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false), v);
+#endif
         }
     }
 }
+
+#undef P29_EXCHANGE
 
 template <int LOGR, int TL = P8_TILE_LOG> static void p29_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {

@@ -88,7 +88,10 @@ struct bbg_prover {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_up[4] = {};
     int stage = 0; // rounds completed in the current proof (guards the call order)
-    bool wire_cosets_done = false; // round 1 already queued the wires' 4n coset forms (option prover_early_cosets)
+    // Round 1 may already have queued the wires' 4n coset forms (option prover_early_cosets); round 3 skips them only if they were made
+    // from THIS proof's wire_coeff: round 1 is the only writer of wire_coeff and starts a new proof_seq before it touches them, so
+    // coset[0 .. width) are current exactly when wire_cosets_seq == proof_seq (round-4 advisor: the flag alone was not tied to a proof)
+    uint64_t proof_seq = 0, wire_cosets_seq = ~0ull;
     std::vector<void*> allocs;
     size_t device_bytes = 0; // sum of `allocs` (bbg_prover_device_bytes, bbg_memory_report)
 };
@@ -115,6 +118,16 @@ namespace {
         if (!(p) || !(p)->ctx) { set_error("null bbg_prover"); return BBG_E_INVALID; }                               \
         hipError_t _e = hipSetDevice((p)->ctx->device);                                                              \
         if (_e != hipSuccess) return hip_fail(_e, "hipSetDevice", __FILE__, __LINE__);                               \
+    } while (0)
+
+// option "prover_fail_round" (tests only): fail this round once, the way a device error in the middle of a proof would
+#define FAIL_INJECT(p, round)                                                                                        \
+    do {                                                                                                             \
+        if ((p)->ctx->prover_fail_round == (round)) {                                                                \
+            (p)->ctx->prover_fail_round = 0;                                                                         \
+            set_error("injected failure in prover round " #round " (option prover_fail_round)");                     \
+            return BBG_E_HIP;                                                                                        \
+        }                                                                                                            \
     } while (0)
 
 int dev_alloc(bbg_prover* p, void** out, size_t bytes)
@@ -374,11 +387,14 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     if (!wires_lagrange || !commitments) { set_error("bbg_prover_round1: null argument"); return BBG_E_INVALID; }
     if (!p->key_final) { set_error("bbg_prover_round1: call bbg_prover_finalize_key first"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
+    FAIL_INJECT(p, 1);
     hipStream_t st = p->ctx->stream;
     AsyncReduce ar(p->ctx);
     const size_t n = p->n;
     for (int k = 0; k < p->width; k++)
         if (!wires_lagrange[k]) { set_error("bbg_prover_round1: null wire"); return BBG_E_INVALID; }
+    p->stage = 0;   // a new proof: nothing of the previous one may be taken for this one's if the round fails half way
+    p->proof_seq++; // ... including coset forms of the previous wires
     // The wires travel on the copy stream (pageable host memory: each copy call returns when its data has been staged), the commitments go
     // in groups through one launch set each (commit()).  Small circuits (upload negligible) commit all wires at once.  Large ones keep one
     // wire per group: wire k+1 travels (0.65 ms at 2^20 gates) while wire k is transformed and committed (1.5 ms) -- a group of two would
@@ -404,13 +420,12 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     // The wires' values on the 4n coset (the FFT work items of round 3, prover.cpp:255-264) depend on nothing but the wires: queued here they
     // run beside the last commitment's accumulation and fill its reduce phase -- a chain of short kernels that leaves most of the chip idle at
     // the end of the round -- instead of standing in front of round 3's grand product.
-    p->wire_cosets_done = false;
     if (p->ctx->prover_early_cosets) {
         for (int k = 0; k < p->width; k++) {
             int rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
             if (rc) return rc;
         }
-        p->wire_cosets_done = true;
+        p->wire_cosets_seq = p->proof_seq;
     }
     int rc = fetch_commitments(p, (size_t)p->width, commitments, st);
     if (rc) return rc;
@@ -425,6 +440,7 @@ int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamm
     if (!beta || !gamma || !blind || !z_commitment) { set_error("bbg_prover_round3: null argument"); return BBG_E_INVALID; }
     if (p->stage < 1) { set_error("bbg_prover_round3: round 1 has not run for this proof"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
+    FAIL_INJECT(p, 3);
     hipStream_t st = p->ctx->stream;
     AsyncReduce ar(p->ctx);
     const size_t n = p->n;
@@ -438,7 +454,9 @@ int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamm
     // main stream does the part of the round that does not depend on z -- the wires' coset FFTs (the FFT work items, prover.cpp:255-264)
     int rc = permutation_grand_product_begin(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, ch, p->z_coeff, st, p->copy_stream,
                                              p->ev_up[0], p->ev_up[1]);
-    for (int k = 0; k < p->width && !rc && !p->wire_cosets_done; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+    const bool wire_cosets_current = p->wire_cosets_seq == p->proof_seq;
+    for (int k = 0; k < p->width && !rc && !wire_cosets_current; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+    if (!rc) p->wire_cosets_seq = p->proof_seq;
     if (!rc) rc = permutation_grand_product_finish(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, p->z_coeff, st, p->ev_up[1]);
     if (rc) return rc;
     // rows n-3 .. n-1 carry the zero-knowledge blinding of z (permutation_widget_impl.hpp:283-287); pinned staging, stream ordered
@@ -460,6 +478,7 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
     if (!alpha || !public_input_delta || !t_commitments) { set_error("bbg_prover_round4: null argument"); return BBG_E_INVALID; }
     if (p->stage < 3) { set_error("bbg_prover_round4: round 3 has not run for this proof"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
+    FAIL_INJECT(p, 4);
     hipStream_t st = p->ctx->stream;
     AsyncReduce ar(p->ctx);
     const size_t n = p->n;
@@ -506,6 +525,7 @@ int bbg_prover_evaluate(bbg_prover* p, size_t count, const int* ids, const int* 
     if (!ids || !zeta || !out || count == 0 || count > 32) { set_error("bbg_prover_evaluate: bad argument (1..32 evaluations per call)"); return BBG_E_INVALID; }
     if (p->stage < 4) { set_error("bbg_prover_evaluate: round 4 has not run for this proof (wires / z / quotient are not this proof's yet)"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
+    FAIL_INJECT(p, 5);
     hipStream_t st = p->ctx->stream;
     const void* ptrs[32];
     size_t lens[32];
@@ -562,6 +582,7 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
     if (p->stage < 4) { set_error("bbg_prover_round6: round 4 has not run for this proof"); return BBG_E_INVALID; }
     if (p->width == 3 && !t_high_top_scalar) { set_error("bbg_prover_round6: StandardPLONK needs the scalar of t_high's top coefficient"); return BBG_E_INVALID; }
     std::lock_guard<std::mutex> lk(p->ctx->mu);
+    FAIL_INJECT(p, 6);
     hipStream_t st = p->ctx->stream;
     AsyncReduce ar(p->ctx);
     const size_t n = p->n;

@@ -171,6 +171,65 @@ class ShardedMsmPipeline:
         return self.last_result()
 
 
+class HostStagedDist:
+    """The subset of torch.distributed the sharded paths use, with every payload staged through host memory: the REHEARSAL carrier of
+    `bench.py --gpus N` when all N ranks share ONE device (BBG_DIST_ONE_DEVICE=1; RCCL refuses a communicator with duplicate devices, gloo
+    has no device-side all-to-all).  A collective here = wait for the current stream, copy the operand to the host, run the gloo collective,
+    copy the result back on the current stream -- the same program order, the same shapes and the same arithmetic as the RCCL run, only the
+    wire is different (and blocking: timings taken this way say nothing about xGMI).  With CPU tensors the staging copies are no-ops, which
+    is how tests/test_distributed_cpu.py drives it."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self): return self._d.get_world_size()
+
+    def get_rank(self): return self._d.get_rank()
+
+    def barrier(self): self._d.barrier()
+
+    def destroy_process_group(self): self._d.destroy_process_group()
+
+    @staticmethod
+    def _host(t):
+        return t.detach().cpu().contiguous()  # .cpu() orders itself behind the work queued on the current stream
+
+    def all_reduce(self, t, op=None):
+        h = self._host(t)
+        self._d.all_reduce(h, op=op if op is not None else self._d.ReduceOp.SUM)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, t):
+        h = self._host(t).reshape(-1)
+        parts = [h.new_empty(h.shape) for _ in range(self.get_world_size())]
+        self._d.all_gather(parts, h)
+        import torch
+        out.copy_(torch.cat(parts).reshape(out.shape))
+
+    def all_gather(self, outs, t):
+        h = self._host(t)
+        parts = [h.new_empty(h.shape) for _ in outs]
+        self._d.all_gather(parts, h)
+        for o, p in zip(outs, parts):
+            o.copy_(p)
+
+    def all_to_all_single(self, out, t):
+        """Chunk s of `t` goes to rank s; chunk s of `out` comes from rank s (equal splits).  gloo's all-to-all exists for CPU tensors."""
+        h = self._host(t).reshape(-1)
+        r = h.new_empty(h.shape)
+        self._d.all_to_all_single(r, h)
+        out.copy_(r.reshape(out.shape))
+
+    def gather(self, t, gather_list=None, dst=0):
+        h = self._host(t)
+        parts = [h.new_empty(h.shape) for _ in range(self.get_world_size())] if self.get_rank() == dst else None
+        self._d.gather(h, parts, dst=dst)
+        if parts is not None:
+            for o, p in zip(gather_list, parts):
+                o.copy_(p)
+
+
 def msm_sharded_async(bbg, srs_local, d_scalars_ptr, n_local, d_partial, d_gathered, d_result, dist):
     """Stream-ordered variant used in the timed loop of bench.py: nothing leaves the GPU.  d_partial int64[12],
     d_gathered int64[world*12], d_result int64[12] are torch CUDA tensors; bbg must run on torch's current stream

@@ -10,7 +10,10 @@ built once, like compute_lookup_table).  `value` = scalars processed by all rank
 (MSM + NTT), so it under-states the MSM-only rate; the separately event-timed MSM / NTT rates are in `extra`.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          (no launcher: bench.py starts its N ranks itself, one per GPU -- self_launch() below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    BBG_DIST_ONE_DEVICE=1 python bench.py --gpus N ...   (REHEARSAL: all N ranks on device 0, exchanges staged through the host over gloo --
+                                                          the whole N-rank code path on one GPU; its timings say nothing about xGMI)
 
 Rank 0 prints ONE JSON line.  At N = 1, rank 0 also runs the CPU baseline on the host cores (the real reference
 binary oracle/_ref/libbbref.so when it runs on this CPU, else the oracle port) on a bounded sample, and checks the GPU
@@ -133,6 +136,117 @@ REAL_STDOUT = os.dup(1)
 os.dup2(2, 1)
 
 
+METRIC_FMT = "BN254 G1 MSM Mscalar-mults/s (+ Fr NTT Gfield-ops/s in extra) at n=2^%d"
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def shape_problem(world, args):
+    """Why the sharded paths cannot take this world / these sizes (None = fine).  Decided from the arguments alone, so every rank -- and the
+    self-launching parent before it starts anybody -- comes to the same answer."""
+    if world != args.gpus:
+        return "WORLD_SIZE = %d but --gpus %d" % (world, args.gpus)
+    if world < 1 or world & (world - 1) or world > 8:
+        return "the residue-class NTT split needs a power-of-two world <= 8 (got %d)" % world
+    if not args.no_config5 and ((1 << args.config5_log2n) // world) % world:
+        return "config 5: G^2 must divide n (G = %d, n = 2^%d)" % (world, args.config5_log2n)
+    if args.log2n < 1 or args.log2n > 27:
+        return "--log2n must be 1 .. 27 (2^27 points per device is the entry format's cap)"
+    return None
+
+
+def emit_error(args, world, problem, **more):
+    """The contract's ONE JSON line, for a run that cannot produce a number: `value` null and an `error` that says why."""
+    line = {"metric": METRIC_FMT % args.log2n, "value": None, "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "error": problem}
+    line.update(more)
+    os.write(REAL_STDOUT, (json.dumps(line) + "\n").encode())
+
+
+def visible_devices():
+    """HIP devices this process could open (0 without a GPU or without the runtime) -- asked in a child process so that the launching parent
+    never initialises the runtime its ranks are about to use."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, timeout=300)
+        return int(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else 0
+    except (subprocess.TimeoutExpired, ValueError, IndexError, OSError):
+        return 0
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks (this same file, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment -- what torch.distributed.run would have set), hand rank 0's ONE JSON line through, and return the worst exit code.
+    Never hangs and never leaves without a line: an impossible shape, too few devices, a rank that dies (the others are given
+    BBG_BENCH_GRACE_S to leave by themselves, then stopped) and the hard limit BBG_BENCH_LAUNCH_TIMEOUT all end in a line with `error`.
+    Only the exact processes started here are ever signalled."""
+    import signal
+    import subprocess
+    import tempfile
+    world = args.gpus
+    os.environ["WORLD_SIZE"] = str(world)  # what shape_problem() compares --gpus with
+    problem = shape_problem(world, args)
+    if problem:
+        emit_error(args, world, problem)
+        return 2
+    one_device = os.environ.get("BBG_DIST_ONE_DEVICE") == "1"
+    skip_check = os.environ.get("BBG_BENCH_SKIP_DEVICE_CHECK") == "1"  # tests only: lets the CPU suite see a rank die / hang under the launcher
+    have = world if skip_check else visible_devices()
+    need = 1 if one_device else world
+    if have < need:
+        emit_error(args, world, "%d GPU(s) visible, %d needed%s" % (have, need, "" if one_device else
+                   " (BBG_DIST_ONE_DEVICE=1 rehearses the N-rank path on one device)"), visible_devices=have)
+        return 3
+    limit = float(os.environ.get("BBG_BENCH_LAUNCH_TIMEOUT", "1500"))
+    grace = float(os.environ.get("BBG_BENCH_GRACE_S", "30"))
+    port = free_port()
+    line_file = tempfile.TemporaryFile()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("OMP_NUM_THREADS", "1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdin=subprocess.DEVNULL,
+                                      stdout=line_file if r == 0 else subprocess.DEVNULL, stderr=2, start_new_session=True))
+    t0 = time.monotonic()
+    failed_at, why = None, None
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() is not None and p.returncode != 0]
+        if bad and failed_at is None:
+            failed_at, why = now, "rank %d exited with code %d" % bad[0]
+        if now - t0 > limit:
+            why = why or "no answer within BBG_BENCH_LAUNCH_TIMEOUT = %d s" % limit
+            break
+        if failed_at is not None and now - failed_at > grace:
+            break
+        time.sleep(0.1)
+    for p in procs:  # whoever is still here after a failure or the limit: these exact process groups, nothing else
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            p.wait()
+    rcs = [p.returncode for p in procs]
+    if why is None:
+        why = next(("rank %d exited with code %d" % (r, rc) for r, rc in enumerate(rcs) if rc), None)
+    line_file.seek(0)
+    lines = [ln for ln in line_file.read().decode(errors="replace").splitlines() if ln.strip().startswith("{")]
+    if lines:
+        os.write(REAL_STDOUT, (lines[-1] + "\n").encode())
+    else:
+        emit_error(args, world, why or "rank 0 left without a line", exit_codes=rcs)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    return (worst if worst < 256 else 1) if (worst or lines) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,47 +268,45 @@ def main():
     ap.add_argument("--reduce-quad", type=int, default=-1, help="A/B: msm_reduce_quad stage mask (library default 14)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))  # no launcher around us: start the N ranks here (each re-enters main() with RANK / WORLD_SIZE set)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = os.environ.get("BBG_DIST_ONE_DEVICE") == "1"  # rehearsal: every rank on device 0, gloo + host staging (parallel.HostStagedDist)
+    if os.environ.get("BBG_BENCH_TEST_HANG_RANK") == str(rank) and world > 1:  # tests only: a rank that never answers (the launcher's limits)
+        time.sleep(3600)
+    if one_device:
+        local_rank = 0
+    # Shapes the sharded paths cannot take are refused HERE, before any process group exists: every rank sees the same arguments and
+    # leaves, rank 0 with a JSON line that says why -- never a rank waiting in a collective the others did not enter.
+    problem = shape_problem(world, args)
+    if problem:
+        if rank == 0:
+            emit_error(args, world, problem)
+        raise SystemExit(2)
+
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
     import importlib
     par = importlib.import_module("aztec_amd.parallel")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    # Shapes the sharded paths cannot take are refused HERE, before any process group exists: every rank sees the same arguments and
-    # leaves, rank 0 with a JSON line that says why -- never a rank waiting in a collective the others did not enter.
-    problem = None
-    if world != args.gpus:
-        problem = "WORLD_SIZE = %d but --gpus %d" % (world, args.gpus)
-    elif world & (world - 1) or world > 8:
-        problem = "the residue-class NTT split needs a power-of-two world <= 8 (got %d)" % world
-    elif not args.no_config5 and ((1 << args.config5_log2n) // world) % world:
-        problem = "config 5: G^2 must divide n (G = %d, n = 2^%d)" % (world, args.config5_log2n)
-    elif args.log2n < 1 or args.log2n > 27:
-        problem = "--log2n must be 1 .. 27 (2^27 points per device is the entry format's cap)"
-    if problem:
-        if rank == 0:
-            os.write(REAL_STDOUT, (json.dumps({"metric": "BN254 G1 MSM Mscalar-mults/s (+ Fr NTT Gfield-ops/s in extra) at n=2^%d" % args.log2n, "value": None,
-                                               "unit": "Mscalar-mults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": problem}) + "\n").encode())
-        raise SystemExit(2)
     dist = None
     force_dist = os.environ.get("BBG_FORCE_DIST") == "1"  # exercise the RCCL + pipeline code path with a world of 1
     if world > 1 or force_dist:
         import torch.distributed as dist_mod
-        dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:  # only without a launcher, i.e. a world of one (BBG_FORCE_DIST): any free port will do
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(free_port())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+            dist = par.HostStagedDist(dist_mod)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist = dist_mod
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -206,6 +318,9 @@ def main():
     # bucket reduction of MSM i overlaps sort/accumulate of step i+1; BBG_BENCH_INLINE_REDUCE=1 (profiling only: scripts/refresh_profiles.sh)
     # keeps it on the main stream so that a kernel trace shows every kernel alone on the device
     bbg.set_option("msm_async_reduce", 0 if os.environ.get("BBG_BENCH_INLINE_REDUCE") == "1" else 1)
+    if one_device and args.reduce_priority < 0:
+        # rehearsal: N processes' queues share one device; a LOW-priority reduce stream is then starved for seconds by the other ranks' work
+        bbg.set_option("msm_reduce_priority", 0)
     if args.msm_window:
         bbg.set_option("msm_window", args.msm_window)
     if args.reduce_priority >= 0:
@@ -333,7 +448,9 @@ def main():
         "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
         "config": {"workload": "per GPU and step: 1 Pippenger MSM (n=2^%d scalars, hashed synthetic SRS resident in HBM) + 1 forward "
                                "NTT (n=2^%d); N>1 = one N*2^%d-point MSM sharded by point range, RCCL all-gather of 96-B partials" % (lg, lg, lg),
-                   "log2n": lg, "sharding": "point-range" if world > 1 else "none"},
+                   "log2n": lg, "sharding": "point-range" if world > 1 else "none",
+                   "exchange": ("REHEARSAL: all %d ranks on ONE device, gloo with host staging (BBG_DIST_ONE_DEVICE=1) -- not a scaling number" % world) if one_device
+                               else ("RCCL (torch.distributed nccl)" if dist is not None else "none")},
         "roofline": roofline, "extra": extra,
     }
 
@@ -567,6 +684,11 @@ def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
         for rec in json.load(open(os.path.join(golden_dir, "ntt_large.json")))["ntt"]:
             if rec["log2n"] == lg and rec["op"] == 2 and rec["generator_size"] == 0:
                 want_ntt = rec["sha256"]
+        # the same two legs recorded from the reference at sizes a one-device rehearsal runs in seconds (gen_golden_config5_small.py)
+        for rec in json.load(open(os.path.join(golden_dir, "config5_small.json")))["sizes"]:
+            if rec["log2n"] == lg:
+                want_msm = np.frombuffer(bytes.fromhex(rec["msm_result"]), dtype=np.uint64)
+                want_ntt = rec["ntt_sha256"]
     except (OSError, KeyError, ValueError):
         pass
     start, count = par.shard_range(n, rank, world)
@@ -619,7 +741,7 @@ def config5(pkg, par, bbg, dist, dev, rank, world, lg, steps=3):
 
     t_msm, t_ntt = best(msm_step), best(ntt_step)
     # ---- self-check against the reference's recorded results (after the timed region)
-    check = {"msm": None, "ntt": None, "source": "tests/golden/msm24.json, tests/golden/ntt_large.json (compiled reference)"}
+    check = {"msm": None, "ntt": None, "source": "tests/golden/msm24.json, ntt_large.json, config5_small.json (compiled reference)"}
     if want_msm is not None:
         jac = last["msm"].cpu().numpy().view(np.uint64).reshape(1, 12)
         if rank == 0:

@@ -528,6 +528,9 @@ class RefProver:
         L.refp_wrap_bytes.restype = sz
         L.refp_wrap_trim.restype = sz
         L.refp_wrap_stats.argtypes = [vp]
+        L.refp_wrap_reuploads.restype = ctypes.c_uint64
+        L.refp_wrap_fail_round.argtypes = [cint]; L.refp_wrap_fail_round.restype = cint
+        L.refp_key_selector_scale3.argtypes = [vp, ctypes.c_char_p]; L.refp_key_selector_scale3.restype = cint
         L.refp_reset.argtypes = [vp]
         L.refp_new_flavour.argtypes = [cint, sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new_flavour.restype = vp
         L.refp_program_width.argtypes = [vp]; L.refp_program_width.restype = sz
@@ -617,6 +620,20 @@ class RefProver:
         out = (ctypes.c_uint64 * 3)()
         self.lib.refp_wrap_stats(out)
         return tuple(int(v) for v in out)
+
+    def wrap_reuploads(self):
+        """Keys uploaded again because a cached proving key's host polynomials had changed."""
+        return int(self.lib.refp_wrap_reuploads())
+
+    def wrap_fail_round(self, rnd):
+        """The next resident prover round `rnd` fails once (library option prover_fail_round, tests only)."""
+        if self.lib.refp_wrap_fail_round(rnd) != 0:
+            raise RuntimeError("refp_wrap_fail_round: not a wrap-linked build")
+
+    def key_selector_scale3(self, label):
+        """Rewrites selector `label` of this session's proving key in place (coefficients * 3, 4n coset form recomputed)."""
+        if self.lib.refp_key_selector_scale3(self.h, label.encode()) != 0:
+            raise RuntimeError("refp_key_selector_scale3 failed")
 
     def resident_key_create(self):
         """bbg_shim::ResidentKey for this circuit's proving key (shim-linked build only); seconds."""

@@ -58,6 +58,12 @@ size_t bbg_shim_resident_bytes(void) __attribute__((weak));
 size_t bbg_shim_resident_trim(void) __attribute__((weak));
 void bbg_shim_resident_clear(void) __attribute__((weak));
 void bbg_shim_resident_stats(uint64_t out[3]) __attribute__((weak));
+uint64_t bbg_shim_resident_reuploads(void) __attribute__((weak));
+#ifndef BBG_DRIVER_WITH_SHIM
+struct bbg_ctx;
+#endif
+extern "C" bbg_ctx* bbg_shim_context(void) __attribute__((weak));
+extern "C" int bbg_set_option(bbg_ctx* ctx, const char* key, long value) __attribute__((weak));
 }
 
 namespace {
@@ -710,6 +716,34 @@ void refp_wrap_stats(uint64_t out[3])
 {
     out[0] = out[1] = out[2] = 0;
     if (bbg_shim_resident_stats) bbg_shim_resident_stats(out);
+}
+// keys uploaded again because a cached proving key's host polynomials had changed (shim/bbg_prover_wrap.cpp: key_fingerprint)
+uint64_t refp_wrap_reuploads(void) { return bbg_shim_resident_reuploads ? bbg_shim_resident_reuploads() : 0; }
+// the next resident prover round `round` (1, 3, 4, 5, 6) fails once, as a device error in the middle of a proof would (library option
+// "prover_fail_round", tests only): the wrapped construct_proof() must then repeat the proof with the reference body
+int refp_wrap_fail_round(int round)
+{
+    if (!bbg_shim_context || !bbg_set_option) return -1;
+    return bbg_set_option(bbg_shim_context(), "prover_fail_round", round);
+}
+// What a host that rewrites a proving key AFTER proving with it does: selector `label` *= 3 in coefficient form, and its 4n coset form
+// recomputed from the new coefficients by the calls compute_proving_key makes (composer_base.cpp:200-210) -- in place, same buffers.
+int refp_key_selector_scale3(void* h, const char* label)
+{
+    try {
+        auto p = ((Session*)h)->view();
+        auto& key = *p.key;
+        polynomial& poly = key.constraint_selectors.at(label);
+        const fr three = fr(3);
+        for (size_t i = 0; i < key.n; i++) poly[i] *= three;
+        polynomial poly_fft(poly, key.n * 4 + 4);
+        poly_fft.coset_fft(key.large_domain);
+        polynomial& dst = key.constraint_selector_ffts.at(std::string(label) + "_fft");
+        for (size_t i = 0; i < key.n * 4 + 4 && i < dst.get_max_size(); i++) dst[i] = poly_fft[i];
+        return 0;
+    } catch (...) {
+        return -1;
+    }
 }
 
 // io::read_transcript_g1 (srs/io.cpp:134-162), the reference's own transcript reader: out = degree x 8 limbs

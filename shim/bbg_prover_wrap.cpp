@@ -43,12 +43,13 @@ struct ResidentCache {
         std::unique_ptr<ResidentKey> rk;
         size_t bytes = 0;
         uint64_t last_use = 0;
+        uint64_t fingerprint = 0; // of the host key polynomials the device copy was made from (key_fingerprint below)
     };
     std::map<const waffle::proving_key*, Entry> entries;
     uint64_t clock = 0;
     bool enabled = true;
     size_t budget = 0; // 0 = not initialised yet
-    uint64_t proofs = 0, fallbacks = 0, evictions = 0;
+    uint64_t proofs = 0, fallbacks = 0, evictions = 0, reuploads = 0;
     void (*draw)(void* user, uint64_t out[4]) = nullptr;
     void* draw_user = nullptr;
     ResidentCache()
@@ -97,6 +98,38 @@ ResidentCache& cache()
     return *c;
 }
 
+// The device copy is only as good as the host polynomials it was made from.  A host that rewrites a selector or a permutation polynomial
+// of a key it has already proved with (the reference never does: compute_proving_key fills them once, composer_base.hpp) would otherwise
+// get proofs over the OLD polynomials without an error.  Cheap check per proof: for every key polynomial the buffer address, its size and
+// 16 evenly spaced coefficients go into a 64-bit FNV-1a; a different value re-uploads the key.  A SAMPLED fingerprint: it catches
+// reallocation, resizing and any rewrite that touches the sampled rows (a recomputed polynomial does, a single poked coefficient may not) --
+// keys must be treated as immutable once proved with; this is a tripwire, not a guarantee (INTEGRATION.md 2a').
+uint64_t key_fingerprint(const waffle::proving_key& key)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](uint64_t v) {
+        for (int b = 0; b < 8; b++) {
+            h ^= (v >> (8 * b)) & 0xff;
+            h *= 1099511628211ull;
+        }
+    };
+    auto take = [&](const barretenberg::polynomial& poly) {
+        const size_t size = poly.get_size();
+        mix((uint64_t)(uintptr_t)&poly[0]);
+        mix((uint64_t)size);
+        if (size == 0) return;
+        for (size_t k = 0; k < 16; k++) {
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(&poly[(size - 1) * k / 15]);
+            for (int l = 0; l < 4; l++) mix(w[l]);
+        }
+    };
+    mix(key.n);
+    mix(key.num_public_inputs);
+    for (const auto& kv : key.constraint_selectors) take(kv.second);
+    for (const auto& kv : key.permutation_selectors) take(kv.second);
+    return h;
+}
+
 barretenberg::fr draw_adapter(void*)
 {
     ResidentCache& c = cache();
@@ -120,7 +153,13 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
         c.budget = bbg_memory_report(bbg_shim_context(), &info) == BBG_OK && info.device_total ? info.device_total / 2 : ((size_t)64 << 30);
     }
     const waffle::proving_key* id = self->key.get();
+    const uint64_t fingerprint = key_fingerprint(*self->key);
     auto it = c.entries.find(id);
+    if (it != c.entries.end() && it->second.fingerprint != fingerprint) { // the host polynomials changed under a cached key: upload again
+        c.entries.erase(it);
+        it = c.entries.end();
+        c.reuploads++;
+    }
     if (it == c.entries.end()) {
         std::unique_ptr<ResidentKey> rk;
         for (int attempt = 0; attempt < 2 && !rk; attempt++) {
@@ -142,6 +181,7 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
         size_t bytes = 0;
         if (bbg_prover_device_bytes(rk->handle(), &bytes) != BBG_OK) bytes = 0;
         e.bytes = bytes;
+        e.fingerprint = fingerprint;
         e.rk = std::move(rk);
         it = c.entries.emplace(id, std::move(e)).first;
     }
@@ -152,7 +192,21 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
     c.proofs++;
     // the lock is held for the whole proof: the reference's prover is not re-entrant either (process-global FFT scratch,
     // polynomial_arithmetic.cpp:13-34), and the shim's device context is one stream
-    return bbg_shim::construct_proof(*self, *it->second.rk, opt);
+    try {
+        return bbg_shim::construct_proof(*self, *it->second.rk, opt);
+    } catch (const std::exception& e) {
+        // A device error in the middle of a proof (out of memory, a HIP failure): the reference's construct_proof() never throws for
+        // that, so neither does this one.  The resident rounds have written only the blinding rows of the host witness (which the
+        // reference's preamble draws again) and the transcript, which ProverBase::reset() (prover.cpp:438-442) rebuilds from its
+        // manifest -- so the reference body can still make the proof from the start.  The key's device copy goes: whatever state the
+        // failed round left in it is not trusted.
+        std::fprintf(stderr, "bbg_shim: resident proof failed (%s); construct_proof() repeats it with the reference body\n", e.what());
+        c.entries.erase(id);
+        c.fallbacks++;
+        lk.unlock();
+        self->reset();
+        return real(self);
+    }
 }
 } // namespace
 
@@ -205,13 +259,20 @@ void bbg_shim_resident_clear(void)
     std::lock_guard<std::mutex> lk(cache().mu);
     cache().entries.clear();
 }
-// counters: [0] proofs through the resident path, [1] proofs that fell back to the reference body after a failed key upload, [2] evictions
+// counters: [0] proofs through the resident path, [1] proofs that fell back to the reference body (failed key upload, or a device error
+// in the middle of a resident proof), [2] evictions
 void bbg_shim_resident_stats(uint64_t out[3])
 {
     std::lock_guard<std::mutex> lk(cache().mu);
     out[0] = cache().proofs;
     out[1] = cache().fallbacks;
     out[2] = cache().evictions;
+}
+// keys uploaded again because the host polynomials of a cached proving key had changed (key_fingerprint)
+uint64_t bbg_shim_resident_reuploads(void)
+{
+    std::lock_guard<std::mutex> lk(cache().mu);
+    return cache().reuploads;
 }
 }
 

@@ -122,3 +122,45 @@ def test_bench_refuses_impossible_shapes_before_any_process_group():
     # a rank other than 0 leaves silently with the same status
     r = subprocess.run([sys.executable, bench, "--gpus", "3"], env=dict(os.environ, WORLD_SIZE="3", RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 2 and not r.stdout.decode().strip()
+
+
+def test_bench_launches_its_own_ranks_and_always_leaves_a_line():
+    """`python bench.py --gpus N` with NO launcher around it (WORLD_SIZE unset) starts its N ranks itself (bench.py self_launch; reference
+    precedent for the N-way split it then runs: ecc/curves/bn254/scalar_multiplication/c_bind.cpp:31-46, plonk/proof_system/prover/
+    work_queue.hpp:166-199).  Whatever happens it prints exactly ONE JSON line, exits non-zero on failure and never hangs: too few devices
+    (this box has none), an impossible shape, a rank that dies, a rank that never answers (grace period), the hard limit."""
+    import json
+    import subprocess
+    import sys
+    import time
+    bench = os.path.join(ROOT, "bench.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+
+    def run(argv, **envx):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, bench] + argv, env=dict(base, **envx), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+        assert len(lines) == 1, (argv, lines, r.stderr.decode()[-500:])
+        return r.returncode, json.loads(lines[0]), time.time() - t0
+
+    import torch
+    if not torch.cuda.is_available():
+        rc, line, _ = run(["--gpus", "8"])
+        assert rc == 3 and line["value"] is None and line["n_gpus"] == 8 and "GPU(s) visible" in line["error"], line
+        rc, line, _ = run(["--gpus", "2"], BBG_DIST_ONE_DEVICE="1")
+        assert rc == 3 and "0 GPU(s) visible, 1 needed" in line["error"], line
+    rc, line, _ = run(["--gpus", "3"])
+    assert rc == 2 and "power-of-two" in line["error"], line
+    rc, line, _ = run(["--gpus", "8", "--config5-log2n", "5"])
+    assert rc == 2 and "G^2" in line["error"], line
+    if not torch.cuda.is_available():
+        # both ranks start and die (no device to open): the parent says which rank left with which code
+        rc, line, _ = run(["--gpus", "2"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_GRACE_S="2")
+        assert rc != 0 and line["value"] is None and "exited with code" in line["error"] and line["exit_codes"] == [1, 1], line
+        # rank 1 never answers, rank 0 dies: after the grace period the parent stops rank 1 (SIGKILL to the group it started) and reports
+        rc, line, el = run(["--gpus", "2"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="1", BBG_BENCH_GRACE_S="2")
+        assert rc != 0 and "rank 0 exited with code 1" in line["error"] and line["exit_codes"] == [1, -9] and el < 60, (line, el)
+    # nobody answers at all: the hard limit
+    rc, line, el = run(["--gpus", "2", "--no-config5"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="0", BBG_BENCH_LAUNCH_TIMEOUT="4",
+                       BBG_BENCH_GRACE_S="1")
+    assert rc != 0 and line["value"] is None and line["error"] and el < 60, (line, el)

@@ -221,6 +221,27 @@ for lg6, ext in ((6, 4), (5, 8), (6, 2)):
     res = par.coset_fft_split_sharded(CpuNttOps(), dist, xt, lg6, ext)
     want = O.coset_fft_split(c6, ext)
     assert np.array_equal(O.canon(0, res.numpy().view(np.uint64).reshape(-1, 4)), O.canon(0, want)), ("coset split sharded", lg6, ext)
+# the REHEARSAL carrier of `bench.py --gpus N` with all ranks on one device (BBG_DIST_ONE_DEVICE=1): parallel.HostStagedDist stages every payload
+# through the host and runs the gloo collective -- every call bench.py makes through it, on the same shapes, must give the same results
+hs = par.HostStagedDist(dist)
+assert hs.get_world_size() == world and hs.get_rank() == rank
+tmax = torch.tensor([float(rank)], dtype=torch.float64)
+hs.all_reduce(tmax, op=hs.ReduceOp.MAX)
+assert float(tmax.item()) == world - 1
+run_pipeline(par.ShardedMsmPipeline(CpuOps(), hs, lambda k: torch.zeros(k, dtype=torch.int64), depth=4), range(400, 406))
+xl = torch.from_numpy(pkg.synthetic_scalars_strided(900 + lg, nn // world, rank, world).view(np.int64).reshape(-1).copy())
+res = par.ntt_sharded(CpuNttOps(), hs, xl, lg, coset_shift=five)
+nat = par.gather_natural_order(hs, res, lg)
+if rank == 0:
+    want = O.ntt(pkg.synthetic_scalars(900 + lg, nn), 2)
+    assert np.array_equal(pkg.fr_reduce_once(nat), np.ascontiguousarray(want)), "host-staged config-5 gather"
+if 8 % world == 0:
+    c6 = O.canon(0, pkg.synthetic_scalars(786, 1 << 5))
+    res = par.coset_fft_split_sharded(CpuNttOps(), hs, torch.from_numpy(c6.copy().view(np.int64).reshape(-1)), 5, 8)
+    assert np.array_equal(O.canon(0, res.numpy().view(np.uint64).reshape(-1, 4)), O.canon(0, O.coset_fft_split(c6, 8))), "host-staged coset split"
+parts_h = [torch.zeros(12, dtype=torch.int64) for _ in range(world)]
+hs.all_gather(parts_h, torch.full((12,), rank, dtype=torch.int64))
+assert all(int(parts_h[r][0]) == r for r in range(world))
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -1248,6 +1248,36 @@ def test_bench_contract_and_dist_path():
         assert out["extra"]["host_path"]["shim_linked_proof_ms"]["construct_proof_wrapped_too"] == rp["wrapped_zero_edits_ms"]
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launched_ranks_one_device_rehearsal(world):
+    """`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): bench.py starts its N ranks itself, and with
+    BBG_DIST_ONE_DEVICE=1 all of them share device 0 and exchange through gloo with host staging (parallel.HostStagedDist) -- the whole
+    N-rank bench on real kernels: ShardedMsmPipeline at depth 4 with its side stream and side context per rank, the max-over-ranks
+    timing, and config 5 (one MSM sharded by point range + all-gather of N partials; one coset NTT sharded by residue class + the
+    all-to-all + the cross-rank DFT), checked against the REFERENCE's recorded results (tests/golden/config5_small.json).
+    Reference precedent for the split: ecc/curves/bn254/scalar_multiplication/c_bind.cpp:31-46 (pippenger_unsafe(from, range) + g1_sum),
+    plonk/proof_system/prover/work_queue.hpp:166-199.  What this cannot show: RCCL and peer access between two distinct devices."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "BBG_FORCE_DIST")}
+    env.update(BBG_DIST_ONE_DEVICE="1", BBG_BENCH_LAUNCH_TIMEOUT="800")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--blocks", "2",
+                        "--log2n", "14", "--config5-log2n", "16"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, lines, r.stderr.decode()[-3000:])
+    out = json.loads(lines[0])
+    assert "error" not in out and out["n_gpus"] == world and out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "weak", out
+    assert out["config"]["sharding"] == "point-range" and "REHEARSAL" in out["config"]["exchange"]
+    c5 = out["extra"]["config5"]
+    assert c5["n_gpus"] == world and c5["msm_ms"] > 0 and c5["ntt_ms"] > 0, c5
+    assert c5["bit_exact_vs_reference"]["msm"] is True and c5["bit_exact_vs_reference"]["ntt"] is True, c5
+    assert c5["exchange"]["msm"] == "all_gather %d x 96 B" % world and not c5["exchange"]["ntt"].startswith("all_to_all 0.0"), c5
+    assert "cpu_baseline" not in out  # rank 0 runs the CPU leg at N = 1 only
+
+
 @pytest.mark.parametrize("G,lg,inverse,coset", [(2, 12, False, False), (4, 12, False, True), (8, 13, False, False), (8, 12, True, False),
                                                  (4, 14, True, True)])
 def test_sharded_ntt_device_blocks(pkg, oracle, bbg, G, lg, inverse, coset):
@@ -1601,6 +1631,67 @@ def test_wrapped_construct_proof_key_cache(pkg, oracle, bbg):
             if P is not None:
                 P.wrap_set_budget(0)
                 P.free()
+
+
+@pytest.mark.parametrize("fail_round", [1, 3, 4, 5, 6])
+def test_wrapped_construct_proof_survives_a_device_error(pkg, oracle, bbg, fail_round):
+    """The reference's construct_proof() (prover.cpp:420-436) never throws for a device's sake, so the wrapped one must not either: a device
+    round that fails in the middle of a resident proof (library option prover_fail_round, tests only) makes shim/bbg_prover_wrap.cpp drop the
+    key's device copy, rebuild the transcript (ProverBase::reset, prover.cpp:438-442) and repeat the proof with the reference body -- a valid
+    proof comes back, the fallback is counted, and the next proof over that key takes the resident path again (round-4 advisor finding)."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << 10) + 2)
+    B = RefProver(1 << 10, 61, pts, x, wrap_linked=True, flavour=0)
+    C = None
+    try:
+        first = B.prove_reference()
+        assert B.verify() == 1
+        keys, st0 = B.wrap_cached_keys(), B.wrap_stats()
+        B.wrap_fail_round(fail_round)
+        second = B.prove_reference(reset=True)
+        st1 = B.wrap_stats()
+        assert B.verify() == 1 and len(second) == len(first) and second != first
+        assert st1[1] == st0[1] + 1 and B.wrap_cached_keys() == keys - 1, (st0, st1)
+        # a new prover over the same circuit: the key is uploaded again and the proof is the resident one
+        C = RefProver(1 << 10, 61, pts, x, wrap_linked=True, flavour=0)
+        C.prove_reference()
+        st2 = C.wrap_stats()
+        assert C.verify() == 1 and st2[0] == st1[0] + 1 and st2[1] == st1[1]
+    finally:
+        B.wrap_fail_round(0)
+        B.free()
+        if C is not None:
+            C.free()
+
+
+def test_wrapped_construct_proof_reuploads_a_rewritten_key(pkg, oracle, bbg):
+    """A host that rewrites a polynomial of a proving key it has already proved with: the key cache is keyed by the key's address, so without
+    a check the device copy would be stale and the proof silently wrong.  shim/bbg_prover_wrap.cpp fingerprints the key's polynomials per
+    proof (buffer address, size, sampled coefficients) and uploads again on a change: after q_m is rewritten in both builds' keys, the
+    wrapped proof still equals the CPU prover's byte for byte (neither verifies any more -- the circuit no longer matches the key)."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << 10) + 2)
+    A = RefProver(1 << 10, 62, pts, x, flavour=0)
+    B = RefProver(1 << 10, 62, pts, x, wrap_linked=True, flavour=0)
+    try:
+        before = B.prove_reference()
+        assert B.verify() == 1
+        re0, keys = B.wrap_reuploads(), B.wrap_cached_keys()
+        again = B.prove_reference(reset=True)  # untouched key: no upload
+        assert B.wrap_reuploads() == re0 and B.verify() == 1 and len(again) == len(before)
+        A.key_selector_scale3("q_m")
+        B.key_selector_scale3("q_m")
+        proof_cpu, blind = A.prove_recording()
+        proof = B.prove_reference(replay=blind, reset=True)
+        assert B.wrap_reuploads() == re0 + 1 and B.wrap_cached_keys() == keys
+        assert proof == proof_cpu, "stale device copy of a rewritten proving key"
+    finally:
+        A.free()
+        B.free()
 
 
 def test_turbo_prover_2_20_gates_on_gpu(pkg, oracle, bbg):
