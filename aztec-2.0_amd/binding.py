@@ -74,6 +74,7 @@ def load_library():
         "bbg_msm_batch": (cint, [vp, vp, sz, vp, vp, vp, vp]),
         "bbg_msm_batch_device": (cint, [vp, vp, sz, vp, vp, vp, vp]),
         "bbg_msm_plan": (cint, [vp, vp, sz, ctypes.POINTER(cint), ctypes.POINTER(cint)]),
+        "bbg_ntt_plan": (cint, [vp, ctypes.c_uint, ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint), ctypes.POINTER(cint)]),
         "bbg_memory_report": (cint, [vp, vp]),
         "bbg_memory_trim": (cint, [vp, cint, ctypes.POINTER(sz)]),
         "bbg_prover_device_bytes": (cint, [vp, ctypes.POINTER(sz)]),
@@ -144,7 +145,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "bbg_device_count", "bbg_init", "bbg_destroy", "bbg_last_error", "bbg_sync", "bbg_join", "bbg_join_lag", "bbg_set_stream", "bbg_srs_register",
     "bbg_srs_register_device", "bbg_srs_synth_linear", "bbg_srs_synth_hashed", "bbg_srs_load_transcript", "bbg_srs_num_points", "bbg_srs_read",
-    "bbg_srs_free", "bbg_srs_retain", "bbg_msm", "bbg_msm_device", "bbg_msm_batch", "bbg_msm_batch_device", "bbg_msm_plan", "bbg_memory_report",
+    "bbg_srs_free", "bbg_srs_retain", "bbg_msm", "bbg_msm_device", "bbg_msm_batch", "bbg_msm_batch_device", "bbg_msm_plan", "bbg_ntt_plan", "bbg_memory_report",
     "bbg_memory_trim", "bbg_prover_device_bytes", "bbg_g1_sum", "bbg_g1_sum_device", "bbg_g1_normalize", "bbg_ntt", "bbg_ntt_device", "bbg_coset_fft_extend", "bbg_quotient_widget_device", "bbg_poly_linear_combination_device", "bbg_permutation_grand_product_device", "bbg_poly_evaluate", "bbg_kate_opening",
     "bbg_divide_by_pseudo_vanishing",
     "bbg_ntt_prepare", "bbg_coset_fft_split", "bbg_coset_fft_split_device", "bbg_scale_powers_device", "bbg_fr_root_pow", "bbg_fr_pow", "bbg_cross_dft_device", "bbg_poly_op_device", "bbg_poly_evaluate_device", "bbg_kate_opening_device",
@@ -289,6 +290,16 @@ class Bbg:
         nn = (ctypes.c_size_t * cnt)(*[int(v) for v in ns])
         fr = None if starts is None else (ctypes.c_size_t * cnt)(*[int(v) for v in starts])
         self._ck(self.lib.bbg_msm_batch_device(self.ctx, srs.handle, cnt, ptrs, fr, nn, ctypes.c_void_p(d_out)))
+
+    def ntt_plan(self, log2n):
+        """{passes, log_radix, kernel, tile_log} of a 2^log2n transform as it would run now (bbg_ntt_plan)."""
+        cint = ctypes.c_int
+        passes, kernel, tile = cint(), cint(), cint()
+        radix = (cint * 4)()
+        self._ck(self.lib.bbg_ntt_plan(self.ctx, log2n, ctypes.byref(passes), radix, ctypes.byref(kernel), ctypes.byref(tile)))
+        names = {0: "k_ntt_pass", 8: "k_ntt_pass8", 81: "k_ntt_pass8s", 29: "k_ntt_pass29"}
+        return {"passes": passes.value, "log_radix": [radix[q] for q in range(passes.value)], "kernel": names.get(kernel.value, str(kernel.value)),
+                "tile_log": tile.value}
 
     def msm_plan(self, n, srs=None):
         """(window bits C, windows) an n-term MSM would run with now (bbg_msm_plan)."""

@@ -897,6 +897,14 @@ int bbg_ntt_prepare(bbg_ctx* ctx, unsigned log2n)
     return ntt_prepare(ctx, log2n);
 }
 
+int bbg_ntt_plan(bbg_ctx* ctx, unsigned log2n, int* passes, int log_radix[4], int* kernel, int* tile_log)
+{
+    CHECK_CTX(ctx);
+    if (!passes || !log_radix || !kernel || !tile_log) { set_error("bbg_ntt_plan: null out"); return BBG_E_INVALID; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ntt_plan(ctx, log2n, passes, log_radix, kernel, tile_log);
+}
+
 int bbg_ntt_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant)
 {
     CHECK_CTX(ctx);

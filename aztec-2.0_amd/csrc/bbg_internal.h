@@ -174,10 +174,12 @@ struct ProfScope {
 int ensure_buffer(void** buf, size_t* have, size_t need);
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
             hipStream_t stream);
+int ntt_ifft_to(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2n, hipStream_t stream);
 void ntt_free_domain(NttDomain& d);
 int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, unsigned log2n, hipStream_t stream);
 int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);
 int ntt_prepare(bbg_ctx* ctx, unsigned log2n);
+int ntt_plan(bbg_ctx* ctx, unsigned log2n, int* passes, int* log_radix, int* kernel, int* tile_log);
 int ntt_domain_consts(bbg_ctx* ctx, unsigned log2n, void** consts);
 int ntt_domain_root_host(bbg_ctx* ctx, unsigned log2n, uint64_t out[4]);
 int poly_binop(int op, const void* a, const void* b, void* r, size_t n, hipStream_t st);

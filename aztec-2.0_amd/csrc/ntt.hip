@@ -693,6 +693,25 @@ int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, u
     return ntt_run(ctx, d_out, log2n, BBG_COSET_FFT, n_in, nullptr, st);
 }
 
+// ifft out of place: the values at d_in stay as they are, the coefficients go to d_out (no overlap) -- a wire of the resident prover keeps
+// its Lagrange form for the grand product and gets its coefficient form without a staging copy (r5: 15-60 us per wire at 2^20)
+int ntt_ifft_to(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2n, hipStream_t st)
+{
+    if (!d_in || !d_out || log2n > 28) { set_error("ntt_ifft_to: bad argument"); return BBG_E_INVALID; }
+    const size_t n = (size_t)1 << log2n;
+    if (log2n < 12) { // the small plans run in place
+        BBG_HIP(hipMemcpyAsync(d_out, d_in, n * 32, hipMemcpyDeviceToDevice, st));
+        return ntt_run(ctx, d_out, log2n, BBG_IFFT, 0, nullptr, st);
+    }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    rc = ntt_core(ctx, *dp, (const Fr*)d_in, (Fr*)d_out, 1, nullptr, st);
+    if (!rc && !dp->inv_scaled)
+        hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, (Fr*)d_out, &((DomainConsts*)dp->consts)->n_inv, n);
+    return rc;
+}
+
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
             hipStream_t st)
 {
@@ -984,6 +1003,33 @@ int ntt_domain_root_host(bbg_ctx* ctx, unsigned log2n, uint64_t out[4])
     int rc = build_domain(ctx, log2n, &d);
     if (rc) return rc;
     memcpy(out, d->root_host, 32);
+    return BBG_OK;
+}
+
+// bbg_ntt_plan: the passes a 2^log2n transform runs as NOW (options included) and which pass kernel executes them -- the selection
+// logic of launch_pass restated on the plan, without building tables.  kernel: 0 = k_ntt_pass (radix 2 in LDS), 8 = k_ntt_pass8,
+// 81 = k_ntt_pass8s (one-plane exchange), 29 = k_ntt_pass29 (lazily reduced 9 x 29-bit limbs)
+int ntt_plan(bbg_ctx* ctx, unsigned log2n, int* passes, int* log_radix, int* kernel, int* tile_log)
+{
+    if (log2n > 28) { set_error("bbg_ntt_plan: log2n > 28"); return BBG_E_INVALID; }
+    NttDomain d;
+    auto it = ctx->domains.find(log2n);
+    if (it != ctx->domains.end()) { // a built domain keeps the plan it was built with
+        d.passes = it->second.passes;
+        d.use_pass8 = it->second.use_pass8;
+        d.tile_log8 = it->second.tile_log8;
+        for (int q = 0; q < NTT_MAX_PASSES; q++) d.logR[q] = it->second.logR[q];
+    } else {
+        d.log2n = log2n;
+        plan_passes(ctx, d);
+    }
+    *passes = d.passes;
+    for (int q = 0; q < NTT_MAX_PASSES; q++) log_radix[q] = q < d.passes ? d.logR[q] : 0;
+    *tile_log = d.use_pass8 ? d.tile_log8 : ctx->ntt_tile_log;
+    if (!d.use_pass8) *kernel = 0;
+    else if (ctx->ntt_limbs29 == 1 || (ctx->ntt_limbs29 == -1 && NTT_LIMBS29_AUTO(log2n))) *kernel = 29;
+    else if (ctx->ntt_lds_planes == 1 || (ctx->ntt_lds_planes == 0 && log2n >= 22)) *kernel = 81;
+    else *kernel = 8;
     return BBG_OK;
 }
 

@@ -410,8 +410,7 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
         }
         for (int k = k0; k < k0 + cnt; k++) {
             BBG_HIP(hipStreamWaitEvent(st, p->ev_up[k], 0));
-            BBG_HIP(hipMemcpyAsync(p->wire_coeff[k], p->wire_lagrange[k], n * 32, hipMemcpyDeviceToDevice, st));
-            int rc = ntt_run(p->ctx, p->wire_coeff[k], p->log2n, BBG_IFFT, 0, nullptr, st);
+            int rc = ntt_ifft_to(p->ctx, p->wire_lagrange[k], p->wire_coeff[k], p->log2n, st); // out of place: no staging copy
             if (rc) return rc;
         }
         int rc = commit(p, cnt, p->wire_coeff + k0, lens, k0, st);

@@ -146,6 +146,10 @@ int bbg_ntt(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, int op, size_t gener
 int bbg_ntt_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant);
 /* Pre-builds the tables for a domain size (outside any timed region, like compute_lookup_table()). */
 int bbg_ntt_prepare(bbg_ctx* ctx, unsigned log2n);
+/* How a 2^log2n transform runs NOW (options included), without building anything: *passes = kernel launches per transform, log_radix[q] =
+ * log2 of pass q's radix (0 beyond the last pass), *tile_log = log2 elements per tile, *kernel = the pass kernel: 0 k_ntt_pass (radix 2 in LDS,
+ * n < 2^11), 8 k_ntt_pass8, 81 k_ntt_pass8s (one-plane exchange), 29 k_ntt_pass29 (9 x 29-bit limbs).  What bench.py labels its NTT roofline with. */
+int bbg_ntt_plan(bbg_ctx* ctx, unsigned log2n, int* passes, int log_radix[4], int* kernel, int* tile_log);
 /* coset_fft(coeffs, small_domain, large_domain, ext) (:401-456): coeffs holds 2^log2n coefficients in a buffer of
  * ext * 2^log2n elements; result interleaves ext size-n coset FFTs at index ext*i + k. */
 int bbg_coset_fft_split(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, size_t ext);

@@ -529,6 +529,8 @@ class RefProver:
         L.refp_wrap_trim.restype = sz
         L.refp_wrap_stats.argtypes = [vp]
         L.refp_wrap_reuploads.restype = ctypes.c_uint64
+        L.refp_wrap_in_progress.restype = sz
+        L.refp_construct_proof_rounds.argtypes = [vp, vp, vp]; L.refp_construct_proof_rounds.restype = ctypes.c_double
         L.refp_wrap_fail_round.argtypes = [cint]; L.refp_wrap_fail_round.restype = cint
         L.refp_key_selector_scale3.argtypes = [vp, ctypes.c_char_p]; L.refp_key_selector_scale3.restype = cint
         L.refp_reset.argtypes = [vp]
@@ -620,6 +622,33 @@ class RefProver:
         out = (ctypes.c_uint64 * 3)()
         self.lib.refp_wrap_stats(out)
         return tuple(int(v) for v in out)
+
+    def wrap_in_progress(self):
+        """Proofs the wrap holds in progress round by round."""
+        return int(self.lib.refp_wrap_in_progress())
+
+    def prove_round_by_round(self, replay=None, reset=False, order=None):
+        """The seven execute_*_round entry points + process_queue() between them + export_proof, the way a host of the reference's C binding
+        drives a prover (plonk/proof_system/prover/c_bind.cpp:59-92).  Returns (proof bytes, seconds, work items queued after each round).
+        In the wrap-linked build the rounds are the wrapped symbols (shim/bbg_prover_wrap.cpp); replay / reset as prove_reference."""
+        if reset:
+            self.lib.refp_reset(self.h)
+        if replay is not None:
+            r = _arr(replay, 4)
+            self.lib.refp_wrap_set_replay(r.ctypes.data, r.shape[0])
+        q = (ctypes.c_size_t * 7)()
+        o = (ctypes.c_int * 7)(*order) if order is not None else None
+        try:
+            t = self.lib.refp_construct_proof_rounds(self.h, o, q)
+            if t < 0:
+                raise RuntimeError("refp_construct_proof_rounds failed: " + (self.lib.refp_last_error(self.h) or b"").decode())
+        finally:
+            if replay is not None:
+                self.lib.refp_wrap_set_replay(None, 0)
+        size = self.lib.refp_export_proof(self.h, None, 0)
+        buf = (ctypes.c_uint8 * size)()
+        self.lib.refp_export_proof(self.h, buf, size)
+        return bytes(buf), float(t), [int(v) for v in q]
 
     def wrap_reuploads(self):
         """Keys uploaded again because a cached proving key's host polynomials had changed."""

@@ -59,6 +59,7 @@ size_t bbg_shim_resident_trim(void) __attribute__((weak));
 void bbg_shim_resident_clear(void) __attribute__((weak));
 void bbg_shim_resident_stats(uint64_t out[3]) __attribute__((weak));
 uint64_t bbg_shim_resident_reuploads(void) __attribute__((weak));
+size_t bbg_shim_resident_in_progress(void) __attribute__((weak));
 #ifndef BBG_DRIVER_WITH_SHIM
 struct bbg_ctx;
 #endif
@@ -716,6 +717,31 @@ void refp_wrap_stats(uint64_t out[3])
 {
     out[0] = out[1] = out[2] = 0;
     if (bbg_shim_resident_stats) bbg_shim_resident_stats(out);
+}
+// proofs the wrap has in progress round by round (begun with the preamble round, not yet through the sixth)
+size_t refp_wrap_in_progress(void) { return bbg_shim_resident_in_progress ? bbg_shim_resident_in_progress() : 0; }
+// What a host of the reference's C binding does (plonk/proof_system/prover/c_bind.cpp:59-92 + prover_process_queue, :9-12): the seven
+// execute_*_round entry points in order with process_queue() between them, then export_proof.  `order` (7 round numbers, or NULL for
+// 0 .. 6) lets a test call them out of order.  queue_sizes[k] = work items queued after the k-th call.  Returns seconds, < 0 on an exception.
+double refp_construct_proof_rounds(void* h, const int* order, size_t* queue_sizes)
+{
+    auto* s = (Session*)h;
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 7; i++) {
+            const int k = order ? order[i] : i;
+            s->execute_round(k);
+            if (queue_sizes) queue_sizes[i] = s->view().queue.get_queue().size();
+            if (k != 5) s->view().queue.process_queue(); // construct_proof (prover.cpp:420-436): no process_queue between rounds five and six
+        }
+        s->proof = s->export_proof();
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } catch (const std::exception& e) {
+        s->error = e.what();
+        return -1;
+    } catch (...) {
+        return -2;
+    }
 }
 // keys uploaded again because a cached proving key's host polynomials had changed (shim/bbg_prover_wrap.cpp: key_fingerprint)
 uint64_t refp_wrap_reuploads(void) { return bbg_shim_resident_reuploads ? bbg_shim_resident_reuploads() : 0; }

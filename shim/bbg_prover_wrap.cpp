@@ -40,12 +40,24 @@ using bbg_shim::ResidentKey;
 struct ResidentCache {
     std::mutex mu;
     struct Entry {
-        std::unique_ptr<ResidentKey> rk;
+        std::shared_ptr<ResidentKey> rk; // shared with a round-by-round proof in progress: an eviction cannot pull the key from under it
         size_t bytes = 0;
         uint64_t last_use = 0;
         uint64_t fingerprint = 0; // of the host key polynomials the device copy was made from (key_fingerprint below)
     };
     std::map<const waffle::proving_key*, Entry> entries;
+    // proofs a host drives round by round (execute_preamble_round ... execute_sixth_round), keyed by the prover object
+    struct ProofIface {
+        virtual ~ProofIface() {}
+        virtual void step(int k) = 0;
+    };
+    struct Progress {
+        std::shared_ptr<ResidentKey> rk;
+        std::unique_ptr<ProofIface> proof; // null: this prover's current proof runs on the reference rounds
+        int next = 0;                      // the round expected next (resident mode)
+        const waffle::proving_key* id = nullptr;
+    };
+    std::map<const void*, Progress> in_progress;
     uint64_t clock = 0;
     bool enabled = true;
     size_t budget = 0; // 0 = not initialised yet
@@ -138,15 +150,11 @@ barretenberg::fr draw_adapter(void*)
     return v;
 }
 
-template <typename settings>
-waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle::plonk_proof& (*real)(waffle::ProverBase<settings>*))
+// The device copy of self's proving key: cached, re-uploaded when the host polynomials changed (key_fingerprint), created (evicting every
+// other key once if the first attempt fails: most likely device memory) -- or null, counted as a fallback, when it cannot be had.
+// Called with the cache locked.
+template <typename settings> ResidentCache::Entry* acquire_key(ResidentCache& c, waffle::ProverBase<settings>* self, const char* what)
 {
-    ResidentCache& c = cache();
-    std::unique_lock<std::mutex> lk(c.mu);
-    if (!c.enabled || !self->key || !bbg_shim::resident_supported(*self)) {
-        lk.unlock();
-        return real(self);
-    }
     c.sweep();
     if (c.budget == 0) {
         bbg_memory_info info;
@@ -161,10 +169,10 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
         c.reuploads++;
     }
     if (it == c.entries.end()) {
-        std::unique_ptr<ResidentKey> rk;
+        std::shared_ptr<ResidentKey> rk;
         for (int attempt = 0; attempt < 2 && !rk; attempt++) {
             try {
-                rk = std::make_unique<ResidentKey>(self->key, settings::program_width);
+                rk = std::make_shared<ResidentKey>(self->key, settings::program_width);
             } catch (const std::exception& e) {
                 if (attempt == 0 && !c.entries.empty()) { // most likely device memory: give back every other key and try once more
                     c.evictions += c.entries.size();
@@ -172,9 +180,8 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
                     continue;
                 }
                 // the reference's body still proves (its MSMs / FFTs are wrapped onto the GPU): slower, never wrong
-                if (c.fallbacks++ == 0) std::fprintf(stderr, "bbg_shim: resident key not created (%s); construct_proof() takes the reference body\n", e.what());
-                lk.unlock();
-                return real(self);
+                if (c.fallbacks++ == 0) std::fprintf(stderr, "bbg_shim: resident key not created (%s); %s takes the reference body\n", e.what(), what);
+                return nullptr;
             }
         }
         ResidentCache::Entry e;
@@ -187,13 +194,45 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
     }
     it->second.last_use = ++c.clock;
     c.evict_to_budget(id);
+    return &it->second;
+}
+
+// set while a reference body runs on this thread on behalf of a wrapped entry point: should a reference body reach another wrapped symbol
+// (it does not when prover.cpp is one translation unit -- its internal calls are not undefined references --, but a build may split it), the
+// call goes straight to the reference
+thread_local int t_in_reference = 0;
+struct ReferenceScope {
+    ReferenceScope() { t_in_reference++; }
+    ~ReferenceScope() { t_in_reference--; }
+};
+
+template <typename settings>
+waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle::plonk_proof& (*real)(waffle::ProverBase<settings>*))
+{
+    ResidentCache& c = cache();
+    if (t_in_reference) return real(self);
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.in_progress.erase(self); // whatever a host began round by round on this prover is superseded
+    if (!c.enabled || !self->key || !bbg_shim::resident_supported(*self)) {
+        lk.unlock();
+        ReferenceScope rs;
+        return real(self);
+    }
+    ResidentCache::Entry* entry = acquire_key(c, self, "construct_proof()");
+    if (!entry) {
+        lk.unlock();
+        ReferenceScope rs;
+        return real(self);
+    }
+    const waffle::proving_key* id = self->key.get();
+    std::shared_ptr<ResidentKey> rk = entry->rk;
     bbg_shim::ResidentOptions opt;
     if (c.draw) opt.random = &draw_adapter;
     c.proofs++;
     // the lock is held for the whole proof: the reference's prover is not re-entrant either (process-global FFT scratch,
     // polynomial_arithmetic.cpp:13-34), and the shim's device context is one stream
     try {
-        return bbg_shim::construct_proof(*self, *it->second.rk, opt);
+        return bbg_shim::construct_proof(*self, *rk, opt);
     } catch (const std::exception& e) {
         // A device error in the middle of a proof (out of memory, a HIP failure): the reference's construct_proof() never throws for
         // that, so neither does this one.  The resident rounds have written only the blinding rows of the host witness (which the
@@ -205,7 +244,83 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
         c.fallbacks++;
         lk.unlock();
         self->reset();
+        ReferenceScope rs;
         return real(self);
+    }
+}
+
+// ---- round by round.  A host that drives the prover through execute_preamble_round() ... execute_sixth_round() with process_queue()
+// between them (the reference's C binding, plonk/proof_system/prover/c_bind.cpp:59-92; construct_proof() itself is exactly that sequence,
+// prover.cpp:420-436) gets the same device rounds one at a time.  The preamble decides: a prover the device rounds implement, called in
+// order, runs resident (each wrapped round leaves its commitments in the transcript and the work queue empty, so the process_queue() that
+// follows finds nothing to do); anything else -- unsupported widgets, the wrap switched off, a round called out of order, a round for a
+// proof that did not begin with the preamble -- runs the reference round.  A device error inside round r rebuilds the transcript
+// (ProverBase::reset) and replays the reference rounds 0 .. r with their process_queue() calls, so the host continues from the same place.
+template <typename settings> struct RoundTable {
+    using Fn = void (*)(waffle::ProverBase<settings>*);
+    Fn real[7];
+};
+template <typename settings> struct ProofImpl : ResidentCache::ProofIface {
+    bbg_shim::ResidentProof<settings> pr;
+    ProofImpl(waffle::ProverBase<settings>& p, ResidentKey& rk, const bbg_shim::ResidentOptions& opt)
+        : pr(p, rk, opt)
+    {}
+    void step(int k) override { pr.step(k); }
+};
+
+template <typename settings> void resident_round(waffle::ProverBase<settings>* self, int round, const RoundTable<settings>& table)
+{
+    ResidentCache& c = cache();
+    if (t_in_reference) return table.real[round](self);
+    std::unique_lock<std::mutex> lk(c.mu);
+    auto reference = [&]() {
+        lk.unlock();
+        ReferenceScope rs;
+        table.real[round](self);
+    };
+    if (round == 0) { // a new proof begins on this prover (first use, or after ProverBase::reset())
+        c.in_progress.erase(self);
+        if (!c.enabled || !self->key || !bbg_shim::resident_supported(*self)) return reference();
+        ResidentCache::Entry* entry = acquire_key(c, self, "execute_preamble_round()");
+        if (!entry) {
+            c.in_progress[self]; // reference mode for the rest of this proof
+            return reference();
+        }
+        ResidentCache::Progress& pg = c.in_progress[self];
+        pg.rk = entry->rk;
+        pg.id = self->key.get();
+        bbg_shim::ResidentOptions opt;
+        if (c.draw) opt.random = &draw_adapter;
+        pg.proof = std::make_unique<ProofImpl<settings>>(*self, *pg.rk, opt);
+        pg.next = 0;
+        c.proofs++;
+    }
+    auto it = c.in_progress.find(self);
+    if (it == c.in_progress.end() || !it->second.proof) return reference(); // not begun here, or on the reference rounds already
+    ResidentCache::Progress& pg = it->second;
+    if (round != pg.next) { // out of order: the resident state is abandoned, the reference does whatever it does with such a call
+        pg.proof.reset();
+        pg.rk.reset();
+        return reference();
+    }
+    try {
+        pg.proof->step(round);
+        pg.next = round + 1;
+        if (round == 6) c.in_progress.erase(it); // the proof is in the transcript: export_proof() is the reference's
+        return;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "bbg_shim: resident round %d failed (%s); the proof is repeated on the reference rounds\n", round, e.what());
+        c.entries.erase(pg.id);
+        pg.proof.reset();
+        pg.rk.reset(); // reference mode from here on
+        c.fallbacks++;
+    }
+    lk.unlock();
+    ReferenceScope rs;
+    self->reset();
+    for (int k = 0; k <= round; k++) {
+        table.real[k](self);
+        if (k < round) self->queue.process_queue(); // the host's own process_queue() follows round `round`
     }
 }
 } // namespace
@@ -257,7 +372,16 @@ size_t bbg_shim_resident_trim(void)
 void bbg_shim_resident_clear(void)
 {
     std::lock_guard<std::mutex> lk(cache().mu);
+    cache().in_progress.clear();
     cache().entries.clear();
+}
+// proofs in progress round by round (begun with execute_preamble_round(), not yet through execute_sixth_round())
+size_t bbg_shim_resident_in_progress(void)
+{
+    std::lock_guard<std::mutex> lk(cache().mu);
+    size_t live = 0;
+    for (const auto& kv : cache().in_progress) live += kv.second.proof ? 1 : 0;
+    return live;
 }
 // counters: [0] proofs through the resident path, [1] proofs that fell back to the reference body (failed key upload, or a device error
 // in the middle of a resident proof), [2] evictions
@@ -291,4 +415,34 @@ BBG_WRAP_CONSTRUCT_PROOF(standard_settings, "_ZN6waffle10ProverBaseINS_17standar
 BBG_WRAP_CONSTRUCT_PROOF(unrolled_turbo_settings, "_ZN6waffle10ProverBaseINS_23unrolled_turbo_settingsEE15construct_proofEv")
 BBG_WRAP_CONSTRUCT_PROOF(unrolled_standard_settings, "_ZN6waffle10ProverBaseINS_26unrolled_standard_settingsEE15construct_proofEv")
 #undef BBG_WRAP_CONSTRUCT_PROOF
+
+// the seven rounds, four instantiations each (shim/wrap_flags_prover.txt lists the same 28 names)
+#define BBG_WRAP_ROUND(settings, tag, index, mangled)                                                                  \
+    void bbg_real_##tag##_##settings(ProverBase<settings>* self) asm("__real_" mangled);                              \
+    void bbg_wrap_##tag##_##settings(ProverBase<settings>* self) asm("__wrap_" mangled);
+#define BBG_WRAP_ROUNDS(settings, len, mangled_settings)                                                               \
+    BBG_WRAP_ROUND(settings, preamble, 0, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE22execute_preamble_roundEv")   \
+    BBG_WRAP_ROUND(settings, first, 1, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE19execute_first_roundEv")         \
+    BBG_WRAP_ROUND(settings, second, 2, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE20execute_second_roundEv")       \
+    BBG_WRAP_ROUND(settings, third, 3, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE19execute_third_roundEv")         \
+    BBG_WRAP_ROUND(settings, fourth, 4, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE20execute_fourth_roundEv")       \
+    BBG_WRAP_ROUND(settings, fifth, 5, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE19execute_fifth_roundEv")         \
+    BBG_WRAP_ROUND(settings, sixth, 6, "_ZN6waffle10ProverBaseINS_" #len mangled_settings "EE19execute_sixth_roundEv")         \
+    static const RoundTable<settings> bbg_round_table_##settings = { { &bbg_real_preamble_##settings, &bbg_real_first_##settings,        \
+                                                                       &bbg_real_second_##settings, &bbg_real_third_##settings,         \
+                                                                       &bbg_real_fourth_##settings, &bbg_real_fifth_##settings,         \
+                                                                       &bbg_real_sixth_##settings } };                                  \
+    void bbg_wrap_preamble_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 0, bbg_round_table_##settings); }    \
+    void bbg_wrap_first_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 1, bbg_round_table_##settings); }       \
+    void bbg_wrap_second_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 2, bbg_round_table_##settings); }      \
+    void bbg_wrap_third_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 3, bbg_round_table_##settings); }       \
+    void bbg_wrap_fourth_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 4, bbg_round_table_##settings); }      \
+    void bbg_wrap_fifth_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 5, bbg_round_table_##settings); }       \
+    void bbg_wrap_sixth_##settings(ProverBase<settings>* self) { resident_round<settings>(self, 6, bbg_round_table_##settings); }
+BBG_WRAP_ROUNDS(turbo_settings, 14, "turbo_settings")
+BBG_WRAP_ROUNDS(standard_settings, 17, "standard_settings")
+BBG_WRAP_ROUNDS(unrolled_turbo_settings, 23, "unrolled_turbo_settings")
+BBG_WRAP_ROUNDS(unrolled_standard_settings, 26, "unrolled_standard_settings")
+#undef BBG_WRAP_ROUNDS
+#undef BBG_WRAP_ROUND
 } // namespace waffle

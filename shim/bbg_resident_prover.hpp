@@ -278,72 +278,94 @@ template <typename settings> bool resident_supported(waffle::ProverBase<settings
     return false;
 }
 
-// ProverBase::construct_proof() with every O(n) step on the device.  `p` must have been created over rk.key() (same proving key).
-template <typename settings>
-waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKey& rk, const ResidentOptions& opt = ResidentOptions())
-{
-    using namespace waffle;
-    constexpr size_t W = settings::program_width;
-    constexpr size_t CUT = settings::num_roots_cut_out_of_vanishing_polynomial;
-    if (p.key.get() != rk.key().get() || rk.program_width() != W) throw std::runtime_error("bbg_shim::construct_proof: prover and ResidentKey belong to different proving keys");
-    if (!resident_supported(p)) throw std::runtime_error("bbg_shim::construct_proof: unsupported widget set (TurboPLONK / StandardPLONK / MiMC composer provers only)");
-    bbg_prover* dev = rk.handle();
-    auto& transcript = p.transcript;
-    auto* key = p.key.get();
-    auto* witness = p.witness.get();
-    const size_t n = key->n;
-    auto random = [&]() { return opt.random ? opt.random(opt.user) : os_random_fr(); };
-    p.queue.flush_queue();
+// One proof in progress on the device rounds, ROUND BY ROUND -- the seven steps ProverBase<settings>::construct_proof() is made of
+// (prover.cpp:420-436) and a host may also drive one at a time through the reference's C binding (prover_execute_preamble_round ...
+// prover_execute_sixth_round + prover_process_queue, plonk/proof_system/prover/c_bind.cpp:59-92).  Each step does what the reference round of
+// the same name does to the transcript AND what the following process_queue() would: its commitments are in the transcript when it returns,
+// the work queue stays empty.  `p` must have been created over rk.key() (same proving key).  Steps must be called in order, once each.
+template <typename settings> class ResidentProof {
+  public:
+    static constexpr size_t W = settings::program_width;
+    static constexpr size_t CUT = settings::num_roots_cut_out_of_vanishing_polynomial;
 
-    // ---- preamble (prover.cpp:139-190): sizes, "init", three blinding scalars per wire in rows n-4 .. n-2 of its Lagrange form
-    transcript.add_element("circuit_size", { static_cast<uint8_t>(n >> 24), static_cast<uint8_t>(n >> 16), static_cast<uint8_t>(n >> 8),
-                                             static_cast<uint8_t>(n) });
-    transcript.add_element("public_input_size", { static_cast<uint8_t>(key->num_public_inputs >> 24), static_cast<uint8_t>(key->num_public_inputs >> 16),
-                                                  static_cast<uint8_t>(key->num_public_inputs >> 8), static_cast<uint8_t>(key->num_public_inputs) });
-    transcript.apply_fiat_shamir("init");
-    const uint64_t* wire_ptrs[W];
-    for (size_t i = 0; i < W; ++i) {
-        barretenberg::polynomial& wire = witness->wires.at("w_" + std::to_string(i + 1));
-        for (size_t k = 0; k < 3; ++k) wire.at(n - CUT + k) = random();
-        wire_ptrs[i] = reinterpret_cast<const uint64_t*>(&wire[0]);
-    }
-    // ---- round 1 (:192-222, :66-84): the public inputs are rows of w_2 in Lagrange form; W_1 .. W_w
+    ResidentProof(waffle::ProverBase<settings>& prover, ResidentKey& rk, const ResidentOptions& options = ResidentOptions())
+        : p(prover)
+        , opt(options)
+        , dev(rk.handle())
+        , key(prover.key.get())
+        , witness(prover.witness.get())
+        , n(prover.key->n)
     {
-        const barretenberg::polynomial& w_2 = witness->wires.at("w_2");
-        std::vector<fr> public_wires;
-        for (size_t i = 0; i < key->num_public_inputs; ++i) public_wires.push_back(w_2[i]);
-        transcript.add_element("public_inputs", ::to_buffer(public_wires));
+        if (p.key.get() != rk.key().get() || rk.program_width() != W)
+            throw std::runtime_error("bbg_shim::construct_proof: prover and ResidentKey belong to different proving keys");
+        if (!resident_supported(p))
+            throw std::runtime_error("bbg_shim::construct_proof: unsupported widget set (TurboPLONK / StandardPLONK / MiMC composer provers only)");
     }
-    g1::element commitments[4];
-    if (bbg_prover_round1(dev, wire_ptrs, reinterpret_cast<uint64_t*>(commitments)) != BBG_OK) resident_fail("bbg_prover_round1");
-    for (size_t i = 0; i < W; ++i) detail::add_commitment(transcript, "W_" + std::to_string(i + 1), commitments[i]);
-    // ---- round 2 (:224-231): nothing to commit for these flavours
-    transcript.apply_fiat_shamir("eta");
-    // ---- round 3 (:233-268): z
-    transcript.apply_fiat_shamir("beta");
-    const fr beta = fr::serialize_from_buffer(transcript.get_challenge("beta").begin());
-    const fr gamma = fr::serialize_from_buffer(transcript.get_challenge("beta", 1).begin());
+
+    // execute_preamble_round (prover.cpp:136-190): sizes, "init", three blinding scalars per wire in rows n-4 .. n-2 of its Lagrange form
+    void preamble()
     {
+        auto& transcript = p.transcript;
+        p.queue.flush_queue();
+        transcript.add_element("circuit_size", { static_cast<uint8_t>(n >> 24), static_cast<uint8_t>(n >> 16), static_cast<uint8_t>(n >> 8),
+                                                 static_cast<uint8_t>(n) });
+        transcript.add_element("public_input_size",
+                               { static_cast<uint8_t>(key->num_public_inputs >> 24), static_cast<uint8_t>(key->num_public_inputs >> 16),
+                                 static_cast<uint8_t>(key->num_public_inputs >> 8), static_cast<uint8_t>(key->num_public_inputs) });
+        transcript.apply_fiat_shamir("init");
+        for (size_t i = 0; i < W; ++i) {
+            barretenberg::polynomial& wire = witness->wires.at("w_" + std::to_string(i + 1));
+            for (size_t k = 0; k < 3; ++k) wire.at(n - CUT + k) = random();
+            wire_ptrs[i] = reinterpret_cast<const uint64_t*>(&wire[0]);
+        }
+    }
+    // execute_first_round (:192-222, :66-84): the public inputs are rows of w_2 in Lagrange form; W_1 .. W_w
+    void first()
+    {
+        auto& transcript = p.transcript;
+        {
+            const barretenberg::polynomial& w_2 = witness->wires.at("w_2");
+            std::vector<fr> public_wires;
+            for (size_t i = 0; i < key->num_public_inputs; ++i) public_wires.push_back(w_2[i]);
+            transcript.add_element("public_inputs", ::to_buffer(public_wires));
+        }
+        if (bbg_prover_round1(dev, wire_ptrs, reinterpret_cast<uint64_t*>(commitments)) != BBG_OK) resident_fail("bbg_prover_round1");
+        for (size_t i = 0; i < W; ++i) detail::add_commitment(transcript, "W_" + std::to_string(i + 1), commitments[i]);
+    }
+    // execute_second_round (:224-231): nothing to commit for these flavours
+    void second() { p.transcript.apply_fiat_shamir("eta"); }
+    // execute_third_round (:233-268): z
+    void third()
+    {
+        auto& transcript = p.transcript;
+        transcript.apply_fiat_shamir("beta");
+        beta = fr::serialize_from_buffer(transcript.get_challenge("beta").begin());
+        gamma = fr::serialize_from_buffer(transcript.get_challenge("beta", 1).begin());
         const fr blind[3] = { random(), random(), random() }; // rows n-3 .. n-1 of z (permutation_widget_impl.hpp:283-287)
         if (bbg_prover_round3(dev, detail::limbs(beta), detail::limbs(gamma), reinterpret_cast<const uint64_t*>(blind),
                               reinterpret_cast<uint64_t*>(commitments)) != BBG_OK)
             resident_fail("bbg_prover_round3");
         detail::add_commitment(transcript, "Z", commitments[0]);
     }
-    // ---- round 4 (:270-363): the quotient
-    transcript.apply_fiat_shamir("alpha");
-    const fr alpha = fr::serialize_from_buffer(transcript.get_challenge("alpha").begin());
+    // execute_fourth_round (:270-363): the quotient
+    void fourth()
     {
+        auto& transcript = p.transcript;
+        transcript.apply_fiat_shamir("alpha");
+        alpha = fr::serialize_from_buffer(transcript.get_challenge("alpha").begin());
         const std::vector<fr> public_inputs = many_from_buffer<fr>(transcript.get_element("public_inputs"));
-        const fr delta = compute_public_input_delta<fr>(public_inputs, beta, gamma, key->small_domain.root);
+        const fr delta = waffle::compute_public_input_delta<fr>(public_inputs, beta, gamma, key->small_domain.root);
         if (bbg_prover_round4(dev, detail::limbs(alpha), detail::limbs(delta), reinterpret_cast<uint64_t*>(commitments)) != BBG_OK)
             resident_fail("bbg_prover_round4");
         for (size_t i = 0; i < W; ++i) detail::add_commitment(transcript, "T_" + std::to_string(i + 1), commitments[i]);
     }
-    // ---- round 5 (:365-410): opening evaluations in manifest order (kate_commitment_scheme.cpp:362-420), t(zeta), r(X), r(zeta)
-    transcript.apply_fiat_shamir("z");
-    const fr zeta = fr::serialize_from_buffer(transcript.get_challenge("z").begin());
+    // execute_fifth_round (:365-410): opening evaluations in manifest order (kate_commitment_scheme.cpp:362-420), t(zeta), r(X), r(zeta)
+    void fifth()
     {
+        using namespace waffle;
+        auto& transcript = p.transcript;
+        transcript.apply_fiat_shamir("z");
+        zeta = fr::serialize_from_buffer(transcript.get_challenge("z").begin());
         std::vector<int> ids, shifted;
         std::vector<std::string> labels;
         for (const auto& info : key->polynomial_manifest) {
@@ -387,9 +409,11 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
         }
         transcript.add_element("t", t_eval.to_buffer());
     }
-    // ---- round 6 (:412-418, KateCommitmentScheme::batch_open kate_commitment_scheme.cpp:133-236)
-    transcript.apply_fiat_shamir("nu");
+    // execute_sixth_round (:412-418, KateCommitmentScheme::batch_open kate_commitment_scheme.cpp:133-236)
+    void sixth()
     {
+        auto& transcript = p.transcript;
+        transcript.apply_fiat_shamir("nu");
         std::vector<int> at_zeta, at_omega;
         std::vector<fr> nu_zeta, nu_omega;
         for (const auto& info : key->polynomial_manifest) {
@@ -423,6 +447,40 @@ waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKe
         detail::add_commitment(transcript, "PI_Z", commitments[0]);
         detail::add_commitment(transcript, "PI_Z_OMEGA", commitments[1]);
     }
+    // step k of the seven (0 = preamble ... 6 = sixth round)
+    void step(int k)
+    {
+        switch (k) {
+        case 0: preamble(); break;
+        case 1: first(); break;
+        case 2: second(); break;
+        case 3: third(); break;
+        case 4: fourth(); break;
+        case 5: fifth(); break;
+        case 6: sixth(); break;
+        default: throw std::runtime_error("bbg_shim::ResidentProof: no such round");
+        }
+    }
+
+  private:
+    fr random() { return opt.random ? opt.random(opt.user) : os_random_fr(); }
+    waffle::ProverBase<settings>& p;
+    ResidentOptions opt;
+    bbg_prover* dev;
+    waffle::proving_key* key;
+    waffle::program_witness* witness;
+    size_t n;
+    const uint64_t* wire_ptrs[4] = { nullptr, nullptr, nullptr, nullptr };
+    g1::element commitments[4];
+    fr beta, gamma, alpha, zeta;
+};
+
+// ProverBase::construct_proof() with every O(n) step on the device.  `p` must have been created over rk.key() (same proving key).
+template <typename settings>
+waffle::plonk_proof& construct_proof(waffle::ProverBase<settings>& p, ResidentKey& rk, const ResidentOptions& opt = ResidentOptions())
+{
+    ResidentProof<settings> proof(p, rk, opt);
+    for (int k = 0; k <= 6; k++) proof.step(k);
     return p.export_proof();
 }
 

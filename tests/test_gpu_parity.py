@@ -1694,6 +1694,93 @@ def test_wrapped_construct_proof_reuploads_a_rewritten_key(pkg, oracle, bbg):
         B.free()
 
 
+@pytest.mark.parametrize("flavour,log2_gates", [(0, 13), (1, 13), (2, 11), (3, 11), (4, 11)])
+def test_wrapped_rounds_reproduce_the_reference_proof(pkg, oracle, bbg, flavour, log2_gates):
+    """Hosts that drive the prover ROUND BY ROUND (the reference's C binding: prover_execute_preamble_round ... prover_execute_sixth_round +
+    prover_process_queue, plonk/proof_system/prover/c_bind.cpp:9-12, :59-92; the same sequence construct_proof() is made of, prover.cpp:420-436):
+    with ProverBase<settings>::execute_*_round wrapped at link time (shim/wrap_flags_prover.txt, shim/bbg_prover_wrap.cpp) each call runs the
+    resident device round of the same name, leaves its commitments in the transcript and the work queue EMPTY, and the exported proof equals
+    the reference CPU prover's byte for byte on the blinding scalars that proof drew.  All five prover types; zero source edits (the driver
+    object is the CPU build's)."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << log2_gates) + 2)
+    A = RefProver(1 << log2_gates, 41 + flavour, pts, x, flavour=flavour)
+    proof_cpu, blind = A.prove_recording()
+    A2 = RefProver(1 << log2_gates, 41 + flavour, pts, x, flavour=flavour)
+    _, _, q_cpu = A2.prove_round_by_round()  # the CPU build's rounds queue their MSMs / FFTs for process_queue()
+    assert A2.verify() == 1 and sum(q_cpu) > 0
+    A2.free()
+    B = RefProver(1 << log2_gates, 41 + flavour, pts, x, wrap_linked=True, flavour=flavour)
+    try:
+        st0 = B.wrap_stats()
+        proof, _, q = B.prove_round_by_round(replay=blind)
+        st1 = B.wrap_stats()
+        assert q == [0] * 7, ("a resident round left work in the queue", q)
+        assert st1[0] == st0[0] + 1 and st1[1] == st0[1] and B.wrap_in_progress() == 0
+        assert B.verify() == 1
+        assert proof == proof_cpu, f"round-by-round resident proof differs from the reference CPU proof (flavour {flavour})"
+        # the same prover again after ProverBase::reset(): fresh randomness, same cached key, another valid proof
+        keys = B.wrap_cached_keys()
+        again, _, q = B.prove_round_by_round(reset=True)
+        assert B.verify() == 1 and again != proof and q == [0] * 7 and B.wrap_cached_keys() == keys
+        # and construct_proof() on the same object after the rounds: still byte-identical on the replayed scalars
+        assert B.prove_reference(replay=blind, reset=True) == proof_cpu
+    finally:
+        A.free()
+        B.free()
+
+
+def test_wrapped_rounds_reference_mode_and_device_errors(pkg, oracle, bbg):
+    """The fall-backs of the round-by-round wrap: (i) a proof whose preamble ran while the wrap was switched off stays on the reference rounds
+    when it is switched on afterwards (no resident state to continue from): the queue fills as in the CPU build and the proof verifies;
+    (ii) a device error inside round r (library option prover_fail_round) rebuilds the transcript and replays the reference rounds 0 .. r, so the
+    host's remaining calls complete a valid proof; the failure is counted and the next proof is resident again."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << 10) + 2)
+    P = RefProver(1 << 10, 71, pts, x, wrap_linked=True, flavour=0)
+    try:
+        P.wrap_set_enabled(False)
+        assert P.lib.refp_execute_round(P.h, 0) == 4  # the reference preamble queues the four wire iFFTs
+        P.lib.refp_process_queue_reference(P.h)
+        P.wrap_set_enabled(True)
+        sizes = []
+        for k in range(1, 7):
+            sizes.append(int(P.lib.refp_execute_round(P.h, k)))
+            if k != 5:
+                P.lib.refp_process_queue_reference(P.h)
+        assert sizes == [4, 0, 6, 4, 0, 2], sizes
+        P.lib.refp_export_proof(P.h, None, 0)
+        assert P.verify() == 1 and P.wrap_in_progress() == 0
+    finally:
+        P.wrap_set_enabled(True)
+        P.free()
+    for fail_round in (1, 3, 4, 5, 6):
+        Q = RefProver(1 << 10, 72, pts, x, wrap_linked=True, flavour=0)
+        R = None
+        try:
+            st0 = Q.wrap_stats()
+            Q.wrap_fail_round(fail_round)
+            proof, _, q = Q.prove_round_by_round()
+            st1 = Q.wrap_stats()
+            assert Q.verify() == 1 and len(proof) == 1248, fail_round
+            assert st1[1] == st0[1] + 1 and Q.wrap_in_progress() == 0, (fail_round, st0, st1)
+            # rounds before the failing one ran resident (empty queue); from the failing round on the reference rounds queue their work
+            want = [0 if k < fail_round else v for k, v in enumerate([4, 4, 0, 6, 4, 0, 2])]
+            assert q == want, (fail_round, q, want)
+            R = RefProver(1 << 10, 72, pts, x, wrap_linked=True, flavour=0)
+            _, _, q2 = R.prove_round_by_round()
+            assert R.verify() == 1 and q2 == [0] * 7 and R.wrap_stats()[1] == st1[1]
+        finally:
+            Q.wrap_fail_round(0)
+            Q.free()
+            if R is not None:
+                R.free()
+
+
 def test_turbo_prover_2_20_gates_on_gpu(pkg, oracle, bbg):
     """BASELINE config 4 at its stated size, under the driver-run suite: a 2^20-gate TurboPLONK circuit.
       (a) every MSM / coset-FFT / iFFT work item of the reference prover computed by this library and compared with the reference
@@ -1755,6 +1842,13 @@ def test_turbo_prover_2_20_gates_on_gpu(pkg, oracle, bbg):
         t_wrap = min(ts)
         assert D.verify() == 1
         assert t_wrap < 0.060, f"wrapped construct_proof() at 2^20 gates took {t_wrap*1e3:.1f} ms (resident path not taken?)"
+        # (e) the same prover driven ROUND BY ROUND through the seven wrapped execute_*_round symbols (c_bind.cpp:59-92)
+        proof_rounds, _, q = D.prove_round_by_round(replay=blind, reset=True)
+        assert proof_rounds == proof_cpu and q == [0] * 7, "2^20 gates: round-by-round resident proof differs from the reference CPU proof"
+        t_rounds = min(D.prove_round_by_round(reset=True)[1] for _ in range(3))
+        assert D.verify() == 1
+        assert t_rounds < 0.060, f"round-by-round proof at 2^20 gates took {t_rounds*1e3:.1f} ms (resident rounds not taken?)"
+        print(f"\n2^20 gates, seven wrapped execute_*_round calls + process_queue: {t_rounds*1e3:.1f} ms")
         D.free()
         D.wrap_trim()
     print(f"\n2^20-gate TurboPLONK proof: reference CPU {t_cpu*1e3:.0f} ms ({A.threads} threads), shim-linked (MSM / FFT wrapped only) {t_shim*1e3:.0f} ms, "
