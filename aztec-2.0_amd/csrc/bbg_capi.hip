@@ -265,6 +265,10 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->prover_early_cosets = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "prover_ntt_batch")) {
+        ctx->prover_ntt_batch = value != 0;
+        return BBG_OK;
+    }
     if (!strcmp(key, "prover_fail_round")) { // tests only: the next call of this prover round (1, 3, 4, 5, 6) fails once, as a device error would
         ctx->prover_fail_round = (int)value;
         return BBG_OK;

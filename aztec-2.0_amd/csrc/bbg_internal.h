@@ -123,6 +123,7 @@ struct bbg_ctx {
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    bool prover_ntt_batch = true;    // option "prover_ntt_batch": the wires' iFFTs (round 1) and 4n coset forms of circuits up to 2^17 gates go through ONE launch set each (grid.y = wires) instead of one per wire (A/B)
     int prover_fail_round = 0;       // option "prover_fail_round" (tests only): the next bbg_prover_round<k> returns BBG_E_HIP once -- how the shim's fallback to the reference body is exercised
     bool prover_early_cosets = true; // option "prover_early_cosets": the wires' 4n coset forms are queued behind round 1's last commitment (beside its reduce phase) instead of in front of round 3's grand product
     int prover_msm_batch = 4; // option "prover_msm_batch": commitments of a prover round per launch set (0 / 1 = one each; prover.hip commit())
@@ -175,6 +176,8 @@ int ensure_buffer(void** buf, size_t* have, size_t need);
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
             hipStream_t stream);
 int ntt_ifft_to(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2n, hipStream_t stream);
+int ntt_ifft_to_batch(bbg_ctx* ctx, int count, const void* const* d_in, void* const* d_out, unsigned log2n, hipStream_t stream);
+int ntt_coset_extend_batch(bbg_ctx* ctx, int count, const void* const* d_in, size_t n_in, void* const* d_out, unsigned log2n, hipStream_t stream);
 void ntt_free_domain(NttDomain& d);
 int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, unsigned log2n, hipStream_t stream);
 int ntt_coset_split(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, size_t ext, hipStream_t stream);

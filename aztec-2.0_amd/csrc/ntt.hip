@@ -199,13 +199,29 @@ struct PassParams {
     int logR1;   // row pass: log2 of the first digit's radix (rows of a tile differ in d_1)
     int nmid;    // row pass: number of middle digits (0..2)
     int logMid[2];
+    // a BATCH of independent transforms of the same domain through one launch (r5: the wires of a small circuit -- at n <= 2^18 one transform
+    // has 32 .. 128 tiles for 256 CUs): grid.y = batch, transform y reads in_b[y] and writes out_b[y]; batch <= 1: in / out as they are
+    // (scalar fields and a select chain, NOT arrays indexed by blockIdx.y: a dynamically indexed kernel-argument array makes the compiler
+    // keep the whole parameter block in scratch memory -- every p.field access a scratch load: the pass kernels ran 12-19 % slower)
+    int batch;
+    const Fr *in_b1, *in_b2, *in_b3; // transform 0 is in / out
+    Fr *out_b1, *out_b2, *out_b3;
 };
+#define BBG_NTT_SELECT_BATCH(p)                                                                                      \
+    do {                                                                                                             \
+        const unsigned y_ = blockIdx.y;                                                                              \
+        if (y_ != 0) {                                                                                               \
+            (p).in = y_ == 1 ? (p).in_b1 : y_ == 2 ? (p).in_b2 : (p).in_b3;                                          \
+            (p).out = y_ == 1 ? (p).out_b1 : y_ == 2 ? (p).out_b2 : (p).out_b3;                                      \
+        }                                                                                                            \
+    } while (0)
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
 __global__ void __launch_bounds__(1024) k_ntt_pass(PassParams p)
 {
     extern __shared__ uint4 lds[];
+    BBG_NTT_SELECT_BATCH(p);
     const int R = 1 << p.logR, W = 1 << p.logW;
     const int pitch = R + 1;
     uint4* plo = lds;
@@ -511,11 +527,23 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
 }
 
 static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, const Fr* in, Fr* out, const Fr* post, hipStream_t st,
-                       const Fr* pre = nullptr, size_t pre_count = 0, size_t in_count = ~(size_t)0)
+                       const Fr* pre = nullptr, size_t pre_count = 0, size_t in_count = ~(size_t)0, int batch = 1, const Fr* const* in_b = nullptr,
+                       Fr* const* out_b = nullptr)
 {
     PassParams p;
     p.in = in;
     p.out = out;
+    p.batch = batch;
+    if (batch > 1) {
+        p.in = in_b[0];
+        p.out = out_b[0];
+    }
+    p.in_b1 = batch > 1 ? in_b[1] : nullptr;
+    p.out_b1 = batch > 1 ? out_b[1] : nullptr;
+    p.in_b2 = batch > 2 ? in_b[2] : nullptr;
+    p.out_b2 = batch > 2 ? out_b[2] : nullptr;
+    p.in_b3 = batch > 3 ? in_b[3] : nullptr;
+    p.out_b3 = batch > 3 ? out_b[3] : nullptr;
     p.pre = pre;
     p.pre_count = pre_count;
     p.in_count = in_count;
@@ -649,7 +677,7 @@ static int launch_pass(bbg_ctx* ctx, const NttDomain& d, int q, int inverse, con
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
     ProfScope ps(ctx, "ntt_pass", st);
-    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(threads), lds_bytes, st, p);
+    hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(threads), lds_bytes, st, p);
     return BBG_OK;
 }
 
@@ -674,6 +702,25 @@ static int ntt_core(bbg_ctx* ctx, NttDomain& d, const Fr* in, Fr* out, int inver
     rc = launch_pass(ctx, d, 0, inverse, in, scratch, nullptr, st, pre, pre_count, in_count);
     for (int q = 1; q < d.passes - 1 && !rc; q++) rc = launch_pass(ctx, d, q, inverse, scratch, scratch, nullptr, st);
     if (!rc) rc = launch_pass(ctx, d, d.passes - 1, inverse, scratch, out, post, st);
+    return rc;
+}
+
+// `count` (<= 4) independent transforms of ONE domain through the same launches (grid.y = count): what ntt_core does, for each k, with in[k]
+// -> out[k].  For domains whose single transform leaves most of the chip idle (2^18: 128 tiles for 256 CUs).
+static int ntt_core_batch(bbg_ctx* ctx, NttDomain& d, int count, const Fr* const* in, Fr* const* out, int inverse, const Fr* post, hipStream_t st,
+                          const Fr* pre = nullptr, size_t pre_count = 0, size_t in_count = ~(size_t)0)
+{
+    if (count == 1) return ntt_core(ctx, d, in[0], out[0], inverse, post, st, pre, pre_count, in_count);
+    if (count < 1 || count > 4 || d.log2n == 0) { set_error("ntt_core_batch: 1 .. 4 transforms of a domain of at least two points"); return BBG_E_INVALID; }
+    const size_t n = (size_t)1 << d.log2n;
+    if (d.passes == 1) return launch_pass(ctx, d, 0, inverse, nullptr, nullptr, post, st, nullptr, 0, ~(size_t)0, count, in, out);
+    int rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, (size_t)count * n * sizeof(Fr));
+    if (rc) return rc;
+    Fr* scratch[4] = { nullptr, nullptr, nullptr, nullptr };
+    for (int k = 0; k < count; k++) scratch[k] = (Fr*)ctx->ntt_scratch + (size_t)k * n;
+    rc = launch_pass(ctx, d, 0, inverse, nullptr, nullptr, nullptr, st, pre, pre_count, in_count, count, in, scratch);
+    for (int q = 1; q < d.passes - 1 && !rc; q++) rc = launch_pass(ctx, d, q, inverse, nullptr, nullptr, nullptr, st, nullptr, 0, ~(size_t)0, count, scratch, scratch);
+    if (!rc) rc = launch_pass(ctx, d, d.passes - 1, inverse, nullptr, nullptr, post, st, nullptr, 0, ~(size_t)0, count, scratch, out);
     return rc;
 }
 
@@ -710,6 +757,42 @@ int ntt_ifft_to(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2n, hip
     if (!rc && !dp->inv_scaled)
         hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, (Fr*)d_out, &((DomainConsts*)dp->consts)->n_inv, n);
     return rc;
+}
+
+// the same for `count` (<= 4) arrays at once -- the wires of a round (r5): one launch set instead of `count`
+int ntt_ifft_to_batch(bbg_ctx* ctx, int count, const void* const* d_in, void* const* d_out, unsigned log2n, hipStream_t st)
+{
+    if (count < 1 || count > 4) { set_error("ntt_ifft_to_batch: 1 .. 4 arrays"); return BBG_E_INVALID; }
+    if (count == 1 || log2n < 12) {
+        for (int k = 0; k < count; k++) {
+            int rc = ntt_ifft_to(ctx, d_in[k], d_out[k], log2n, st);
+            if (rc) return rc;
+        }
+        return BBG_OK;
+    }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log2n;
+    rc = ntt_core_batch(ctx, *dp, count, (const Fr* const*)d_in, (Fr* const*)d_out, 1, nullptr, st);
+    for (int k = 0; k < count && !rc && !dp->inv_scaled; k++)
+        hipLaunchKernelGGL(k_scale_const, dim3(grid_for(n, 256)), dim3(256), 0, st, (Fr*)d_out[k], &((DomainConsts*)dp->consts)->n_inv, n);
+    return rc;
+}
+// ntt_coset_extend for `count` (<= 4) inputs of the same length at once
+int ntt_coset_extend_batch(bbg_ctx* ctx, int count, const void* const* d_in, size_t n_in, void* const* d_out, unsigned log2n, hipStream_t st)
+{
+    if (count < 1 || count > 4) { set_error("ntt_coset_extend_batch: 1 .. 4 arrays"); return BBG_E_INVALID; }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    if (count > 1 && can_fuse(*dp) && n_in <= ((size_t)1 << log2n))
+        return ntt_core_batch(ctx, *dp, count, (const Fr* const*)d_in, (Fr* const*)d_out, 0, nullptr, st, (const Fr*)dp->coset_fwd, n_in, n_in);
+    for (int k = 0; k < count; k++) {
+        rc = ntt_coset_extend(ctx, d_in[k], n_in, d_out[k], log2n, st);
+        if (rc) return rc;
+    }
+    return BBG_OK;
 }
 
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,

@@ -150,6 +150,7 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
 template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), BBG_NTT29_OCC) k_ntt_pass29(PassParams p)
 {
     extern __shared__ uint4 lds[];
+    BBG_NTT_SELECT_BATCH(p);
 #if BBG_NTT29_EXCH1
     uint4* buf = lds;                  // limbs 0..3
     uint4* bufhi = lds + (1 << TL);    // limbs 4..7
@@ -296,8 +297,8 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
 
 template <int LOGR, int TL = P8_TILE_LOG> static void p29_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {
-    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass29<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
-    else hipLaunchKernelGGL((k_ntt_pass29<LOGR, false, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass29<LOGR, true, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
+    else hipLaunchKernelGGL((k_ntt_pass29<LOGR, false, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
 }
 template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p29_attr()
 {

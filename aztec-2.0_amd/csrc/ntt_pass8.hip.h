@@ -204,6 +204,7 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
 template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3)) k_ntt_pass8(PassParams p)
 {
     extern __shared__ uint4 lds[];
+    BBG_NTT_SELECT_BATCH(p);
     uint4* plo = lds;
     uint4* phi = lds + p8_plane<TL>();
     constexpr int NSTEPS = (LOGR + 2) / 3;
@@ -383,6 +384,7 @@ template <int TL> constexpr size_t p8s_lds_bytes() { return (size_t)p8_plane<TL>
 template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), BBG_NTT_OCC) k_ntt_pass8s(PassParams p)
 {
     extern __shared__ uint4 lds[];
+    BBG_NTT_SELECT_BATCH(p);
     constexpr int NSTEPS = (LOGR + 2) / 3;
     constexpr int LOGW = TL - LOGR;
     const size_t tile = blockIdx.x;
@@ -487,8 +489,8 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
 
 template <int LOGR, int TL = P8_TILE_LOG> static void p8s_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {
-    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8s<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8s_lds_bytes<TL>(), st, p);
-    else hipLaunchKernelGGL((k_ntt_pass8s<LOGR, false, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8s_lds_bytes<TL>(), st, p);
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8s<LOGR, true, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p8s_lds_bytes<TL>(), st, p);
+    else hipLaunchKernelGGL((k_ntt_pass8s<LOGR, false, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p8s_lds_bytes<TL>(), st, p);
 }
 template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p8s_attr()
 {
@@ -499,8 +501,8 @@ template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p8s_attr()
 
 template <int LOGR, int TL = P8_TILE_LOG> static void p8_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {
-    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8<LOGR, true, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);
-    else hipLaunchKernelGGL((k_ntt_pass8<LOGR, false, TL>), dim3((unsigned)tiles), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass8<LOGR, true, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);
+    else hipLaunchKernelGGL((k_ntt_pass8<LOGR, false, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p8_lds_bytes<TL>(), st, p);
 }
 template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p8_attr()
 {

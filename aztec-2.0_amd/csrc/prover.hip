@@ -183,6 +183,18 @@ int to_coset(bbg_prover* p, const void* d_coeff, void* d_out, hipStream_t st)
     return ntt_coset_extend(p->ctx, d_coeff, p->n, d_out, p->log2n + 2, st); // no staging copy, no zero fill, g^j fused into the first load
 }
 
+// the wires' 4n coset forms (the FFT work items of round 3, prover.cpp:255-264).  Up to 2^19-point domains the transforms of all wires go
+// through one launch set (r5: a 2^18-point transform has 128 tiles for 256 CUs); larger ones fill the chip by themselves.
+int wires_to_coset(bbg_prover* p, hipStream_t st)
+{
+    if (p->log2n + 2 <= 19 && p->ctx->prover_ntt_batch) return ntt_coset_extend_batch(p->ctx, p->width, p->wire_coeff, p->n, p->coset, p->log2n + 2, st);
+    for (int k = 0; k < p->width; k++) {
+        int rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+        if (rc) return rc;
+    }
+    return BBG_OK;
+}
+
 // slot of a key polynomial id in key_coeff / key_coset (the widget table's index), -1 for ids that are not key polynomials
 int key_slot(int id)
 {
@@ -408,11 +420,13 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
             BBG_HIP(hipMemcpyAsync(p->wire_lagrange[k], wires_lagrange[k], n * 32, hipMemcpyHostToDevice, p->copy_stream));
             BBG_HIP(hipEventRecord(p->ev_up[k], p->copy_stream));
         }
-        for (int k = k0; k < k0 + cnt; k++) {
-            BBG_HIP(hipStreamWaitEvent(st, p->ev_up[k], 0));
-            int rc = ntt_ifft_to(p->ctx, p->wire_lagrange[k], p->wire_coeff[k], p->log2n, st); // out of place: no staging copy
-            if (rc) return rc;
-        }
+        for (int k = k0; k < k0 + cnt; k++) BBG_HIP(hipStreamWaitEvent(st, p->ev_up[k], 0));
+        // out of place (no staging copy); the wires of a group in ONE launch set (r5): at n <= 2^17 a single transform has at most 64 tiles
+        int rc0 = BBG_OK;
+        if (p->ctx->prover_ntt_batch) rc0 = ntt_ifft_to_batch(p->ctx, cnt, p->wire_lagrange + k0, p->wire_coeff + k0, p->log2n, st);
+        else
+            for (int k = k0; k < k0 + cnt && !rc0; k++) rc0 = ntt_ifft_to(p->ctx, p->wire_lagrange[k], p->wire_coeff[k], p->log2n, st);
+        if (rc0) return rc0;
         int rc = commit(p, cnt, p->wire_coeff + k0, lens, k0, st);
         if (rc) return rc;
     }
@@ -420,10 +434,8 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     // run beside the last commitment's accumulation and fill its reduce phase -- a chain of short kernels that leaves most of the chip idle at
     // the end of the round -- instead of standing in front of round 3's grand product.
     if (p->ctx->prover_early_cosets) {
-        for (int k = 0; k < p->width; k++) {
-            int rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
-            if (rc) return rc;
-        }
+        int rc = wires_to_coset(p, st);
+        if (rc) return rc;
         p->wire_cosets_seq = p->proof_seq;
     }
     int rc = fetch_commitments(p, (size_t)p->width, commitments, st);
@@ -454,7 +466,7 @@ int bbg_prover_round3(bbg_prover* p, const uint64_t beta[4], const uint64_t gamm
     int rc = permutation_grand_product_begin(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, ch, p->z_coeff, st, p->copy_stream,
                                              p->ev_up[0], p->ev_up[1]);
     const bool wire_cosets_current = p->wire_cosets_seq == p->proof_seq;
-    for (int k = 0; k < p->width && !rc && !wire_cosets_current; k++) rc = to_coset(p, p->wire_coeff[k], p->coset[k], st);
+    if (!rc && !wire_cosets_current) rc = wires_to_coset(p, st);
     if (!rc) p->wire_cosets_seq = p->proof_seq;
     if (!rc) rc = permutation_grand_product_finish(p->ctx, p->width, p->wire_lagrange, p->sigma_lagrange, p->log2n, p->z_coeff, st, p->ev_up[1]);
     if (rc) return rc;
