@@ -1,11 +1,11 @@
 #!/bin/bash
-# Runs the sanitizer configuration built by scripts/sanitize_build.sh on the GPU box and writes gpurun_out/r04_sanitizers.txt:
+# Runs the sanitizer configuration built by scripts/sanitize_build.sh on the GPU box and writes gpurun_out/r05_sanitizers.txt:
 #   gpurun --timeout 1500 -- 'bash scripts/sanitize_run.sh'
 # protect_shadow_gap=0: the HIP runtime maps device memory into the range ASan's shadow gap covers.  Leak checking is on for the C-ABI driver
 # (suppressing the runtime's own exit-time allocations), off under Python.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r04_sanitizers.txt
+OUT=$ROOT/gpurun_out/r05_sanitizers.txt
 S=$ROOT/build_san
 mkdir -p $ROOT/gpurun_out
 cat > /tmp/lsan.supp <<EOS
@@ -27,7 +27,7 @@ export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0
   echo "## (3) the same with the 4-context device group behind pippenger_unsafe (BBG_SHIM_DEVICES=0,0,0,0)"
   ASAN_OPTIONS=protect_shadow_gap=0:detect_leaks=0 BBG_SHIM_DEVICES=0,0,0,0 BBG_SHIM_MULTI_MIN_POINTS=1000 $S/shim_check_san 12 2>&1 | tee /tmp/san3.log | tail -12
   echo "exit status: ${PIPESTATUS[0]}"
-  echo "## (4) the wrapped construct_proof() build with shim TUs + driver instrumented (libbbprover_wrap_san.so), under LD_PRELOAD=libasan: key cache, replay, all five prover types at 2^9"
+  echo "## (4) the wrapped construct_proof() build with shim TUs + driver instrumented (libbbprover_wrap_san.so), under LD_PRELOAD=libasan: key cache, replay, all five prover types at 2^9; r5: the seven wrapped rounds, device-error fall-backs, key re-upload"
   ASAN_OPTIONS=protect_shadow_gap=0:detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) BBG_PROVER_WRAP_SO=$S/libbbprover_wrap_san.so \
     python $ROOT/tests/tools/san_wrap_check.py 2>&1 | tee /tmp/san4.log | tail -25
   echo "exit status: ${PIPESTATUS[0]}"

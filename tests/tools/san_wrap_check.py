@@ -63,4 +63,39 @@ P1.free()
 Q = RefProver(1 << 9, 93, pts, x, wrap_linked=True, flavour=0)
 assert Q.wrap_trim() == 0
 Q.free()
+# round 5: the seven wrapped execute_*_round symbols (a proof driven round by round), a device error inside a resident round (replay on the
+# reference rounds) and inside a wrapped construct_proof() (reference body), and a proving key rewritten after its first proof (re-upload)
+for flavour in (0, 1, 3):
+    A = RefProver(1 << 9, 51 + flavour, pts, x, flavour=flavour)
+    proof_cpu, blind_r = A.prove_recording()
+    B = RefProver(1 << 9, 51 + flavour, pts, x, wrap_linked=True, flavour=flavour)
+    proof, _, q = B.prove_round_by_round(replay=blind_r)
+    assert proof == proof_cpu and q == [0] * 7 and B.verify() == 1 and B.wrap_in_progress() == 0, flavour
+    assert B.prove_reference(replay=blind_r, reset=True) == proof_cpu
+    A.free(); B.free()
+    print("flavour", flavour, "byte-identical through the seven wrapped rounds", flush=True)
+for fail_round in (1, 4, 6):
+    Q = RefProver(1 << 9, 61, pts, x, wrap_linked=True, flavour=0)
+    st0 = Q.wrap_stats()
+    Q.wrap_fail_round(fail_round)
+    proof, _, q = Q.prove_round_by_round()
+    assert Q.verify() == 1 and Q.wrap_stats()[1] == st0[1] + 1 and Q.wrap_in_progress() == 0 and q[fail_round] > 0 or fail_round == 5, fail_round
+    Q.free()
+    Q = RefProver(1 << 9, 61, pts, x, wrap_linked=True, flavour=0)
+    Q.prove_reference()
+    Q.wrap_fail_round(fail_round)
+    Q.prove_reference(reset=True)
+    assert Q.verify() == 1
+    Q.wrap_fail_round(0)
+    Q.free()
+print("device errors inside rounds 1 / 4 / 6: proofs completed on the reference rounds / body", flush=True)
+A = RefProver(1 << 9, 62, pts, x, flavour=0)
+B = RefProver(1 << 9, 62, pts, x, wrap_linked=True, flavour=0)
+B.prove_reference()
+re0 = B.wrap_reuploads()
+A.key_selector_scale3("q_m"); B.key_selector_scale3("q_m")
+proof_cpu, blind_r = A.prove_recording()
+assert B.prove_reference(replay=blind_r, reset=True) == proof_cpu and B.wrap_reuploads() == re0 + 1
+A.free(); B.free()
+print("rewritten proving key: re-uploaded, byte-identical", flush=True)
 print("san_wrap_check PASS")
