@@ -341,16 +341,70 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(PassParams p)
 #include "ntt_pass8.hip.h"
 #include "ntt_pass29.hip.h"
 namespace bbg {
-// out row j = in[j] * 32 (canonical) as 9 x 29-bit limbs in a 12-word row: w R -> w R' for R' = 2^261 = 32 R, the multiplier form of the
-// 29-bit-limb pass kernel, already in the limbs its products take (three 16-byte loads, no split)
-__global__ void k_to_rprime(uint32_t* out, const Fr* in, size_t count)
+// The per-radix table of the 29-bit-limb pass kernel from the R-form one (ntt29.hip.h), rows of NTT29_TW_ROW words.  shoup (the pass's kernel takes
+// the constant-operand product: p29_shoup(log-radix)): row j = the limbs of the PLAIN twiddle
+// w (canonical) and of wq = floor(w 2^261 / p), 18 words in a 20-word row (field29c.hip.h: the constant-operand product) -- wq by binary long
+// division, 261 steps on a 9-word remainder, once per table entry (a table has at most 2048).  Otherwise: row j = in[j] * 32 (canonical) as
+// 9 x 29-bit limbs in a 12-word row: w R -> w R' for R' = 2^261 = 32 R, the operand of the Montgomery product.
+__global__ void k_to_rprime(uint32_t* out, const Fr* in, size_t count, int shoup)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
+    uint32_t* row = out + idx * NTT29_TW_ROW;
+    if (shoup) {
+    const Fr w = fe_canon(fe_from_mont(fe_load<FrP>(in + idx)));
+    uint32_t rem[9], q[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        rem[i] = i < 8 ? w.v[i] : 0u;
+        q[i] = 0;
+    }
+    for (int b = 0; b < 261; b++) {
+        // rem <<= 1 (rem < p < 2^254 before: no overflow of 9 words), q <<= 1
+#pragma unroll
+        for (int i = 8; i > 0; i--) {
+            rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
+            q[i] = (q[i] << 1) | (q[i - 1] >> 31);
+        }
+        rem[0] <<= 1;
+        q[0] <<= 1;
+        // rem >= p ?  (compare from the top; rem[8] can only be 0 or 1 here and p has 8 words)
+        bool ge = rem[8] != 0;
+        if (!ge) {
+            ge = true;
+            for (int i = 7; i >= 0; i--) {
+                if (rem[i] != FrP::MOD[i]) {
+                    ge = rem[i] > FrP::MOD[i];
+                    break;
+                }
+            }
+        }
+        if (ge) {
+            uint32_t borrow = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const uint64_t d = (uint64_t)rem[i] - (i < 8 ? FrP::MOD[i] : 0u) - borrow;
+                rem[i] = (uint32_t)d;
+                borrow = (uint32_t)(d >> 63);
+            }
+            q[0] |= 1u;
+        }
+    }
+    // 29-bit limbs of w (8 words) and of q (261 bits in 9 words)
+    const Fr29 wl = f29_from_fe<FrP, 0>(w);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int bit = 29 * j, i = bit >> 5, o = bit & 31;
+        const uint64_t lo = q[i], hi = i + 1 < 9 ? q[i + 1] : 0;
+        row[j] = wl.v[j];
+        row[9 + j] = (uint32_t)(((lo | (hi << 32)) >> o) & M29);
+    }
+    row[18] = row[19] = 0;
+    return;
+    }
     Fr c = Fr::zero();
     c.v[0] = 32;
     const Fr29 l = f29_from_fe<FrP, 0>(fe_canon(fe_mul(fe_load<FrP>(in + idx), fe_to_mont(c))));
-    uint32_t* row = out + idx * NTT29_TW_ROW;
 #pragma unroll
     for (int i = 0; i < NTT29_TW_ROW; i++) row[i] = i < 9 ? l.v[i] : 0u;
 }
@@ -483,10 +537,11 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
             d.bytes += half * sizeof(Fr);
             hipLaunchKernelGGL(k_twiddle_1d, dim3(grid_for(half, 256)), dim3(256), 0, st, (Fr*)d.tw_radix[inv][q], pow2, half,
                                (uint64_t)(n >> logR));
-            if (d.use_pass8) { // the same table in R'-form, as 9-limb rows, for k_ntt_pass29 (R <= 2048 entries of 48 bytes: 96 KB)
+            if (d.use_pass8) { // the same table in R'-form, as 9-limb rows, for k_ntt_pass29 (R <= 2048 entries of 48 or 80 bytes)
                 BBG_HIP(hipMalloc(&d.tw_radix29[inv][q], half * NTT29_TW_ROW * 4));
                 d.bytes += half * NTT29_TW_ROW * 4;
-                hipLaunchKernelGGL(k_to_rprime, dim3(grid_for(half, 256)), dim3(256), 0, st, (uint32_t*)d.tw_radix29[inv][q], (const Fr*)d.tw_radix[inv][q], half);
+                hipLaunchKernelGGL(k_to_rprime, dim3(grid_for(half, 256)), dim3(256), 0, st, (uint32_t*)d.tw_radix29[inv][q], (const Fr*)d.tw_radix[inv][q], half,
+                                   p29_shoup(logR) ? 1 : 0);
             }
             if (q < d.passes - 1) {
                 // inter-pass twiddles w_{N_q}^(i*lo), N_q = R*S ; w_{N_q} = w_n^(n/N_q): use the pow2 table shifted

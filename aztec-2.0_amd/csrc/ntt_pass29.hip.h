@@ -32,14 +32,32 @@ __device__ __forceinline__ int p29_slot(int p, int c, int logW) // swizzled slot
     return q ^ ((q >> 3) & 15);
 }
 
-__device__ __forceinline__ Fr29 p29_load_tw(const uint32_t* __restrict__ tw29, int idx) // a table row: 9 exact limbs of a value < p
+// Which multiplier a pass kernel takes for its table twiddles (ntt29.hip.h N29M): the constant-operand product where the kernel runs two waves
+// per SIMD anyway (log-radix >= 9: 182 - 198 VGPRs with Montgomery, 223 - 233 with it); the radix-2^7 / 2^8 kernels of the three-pass plans keep
+// Montgomery and their third wave (144 - 168 VGPRs; with the constant-operand product 225 - 240).  BBG_NTT_SHOUP = 0: Montgomery everywhere (A/B).
+#ifndef BBG_NTT_SHOUP
+#define BBG_NTT_SHOUP 1
+#endif
+constexpr bool p29_shoup(int logR) { return BBG_NTT_SHOUP && logR >= 9; }
+
+template <bool SH> __device__ __forceinline__ typename N29M<SH>::Tw p29_load_tw(const uint32_t* __restrict__ tw29, int idx) // a table row
 {
     const uint4* row = reinterpret_cast<const uint4*>(tw29 + (size_t)idx * NTT29_TW_ROW);
-    const uint4 a = row[0], b = row[1];
-    Fr29 r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    r.v[8] = tw29[(size_t)idx * NTT29_TW_ROW + 8];
+    typename N29M<SH>::Tw r;
+    if constexpr (SH) {
+        const uint4 a = row[0], b = row[1], c = row[2], d = row[3];
+        const uint2 e = *reinterpret_cast<const uint2*>(row + 4);
+        r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+        r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+        r.w[8] = c.x; r.q[0] = c.y; r.q[1] = c.z; r.q[2] = c.w;
+        r.q[3] = d.x; r.q[4] = d.y; r.q[5] = d.z; r.q[6] = d.w;
+        r.q[7] = e.x; r.q[8] = e.y;
+    } else {
+        const uint4 a = row[0], b = row[1];
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+        r.v[8] = tw29[(size_t)idx * NTT29_TW_ROW + 8];
+    }
     return r;
 }
 
@@ -49,16 +67,18 @@ template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)
 {
     constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
     constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
+    constexpr bool SH = p29_shoup(LOGR);
+    using Tw29 = typename N29M<SH>::Tw;
     if constexpr (S == 3) {
-        const Fr29 w1 = p29_load_tw(tw29, 1 << (LOGR - 3)), w2 = p29_load_tw(tw29, 1 << (LOGR - 2)), w3 = p29_load_tw(tw29, 3 << (LOGR - 3));
+        const Tw29 w1 = p29_load_tw<SH>(tw29, 1 << (LOGR - 3)), w2 = p29_load_tw<SH>(tw29, 1 << (LOGR - 2)), w3 = p29_load_tw<SH>(tw29, 3 << (LOGR - 3));
         if constexpr (F > 0) {
             constexpr int DONE = LOGR - 3 - F;
-            n29_step8<true>(x, w1, w2, w3, [&](int j) { return p29_load_tw(tw29, (p8_brev3(j) * qlo) << DONE); }, red);
+            n29_step8<SH, true>(x, w1, w2, w3, [&](int j) { return p29_load_tw<SH>(tw29, (p8_brev3(j) * qlo) << DONE); }, red);
         } else {
-            n29_step8_raw(x, w1, w2, w3);
+            n29_step8_raw<SH>(x, w1, w2, w3);
         }
     } else if constexpr (S == 2) {
-        n29_step4(x, p29_load_tw(tw29, 1 << (LOGR - 2)));
+        n29_step4<SH>(x, p29_load_tw<SH>(tw29, 1 << (LOGR - 2)));
     } else {
         n29_step2(x);
     }

@@ -8,6 +8,8 @@ inputs pushed to the stated entry bound (every register just below 3p, every lim
 steps, and checks every output against plain modular arithmetic.  Test infrastructure only: the product never runs it."""
 import random
 
+import pytest
+
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001  # BN254 Fr (fr.hpp:12-15)
 M29 = (1 << 29) - 1
 R1 = 1 << 261
@@ -86,6 +88,64 @@ def mul(a, b):
     return r
 
 
+PBAR29 = limbs(R1 - P)
+
+
+def mulc(a, w):
+    """f29_mulc (field29c.hip.h): x * w mod p for a TABLE constant w < p through the precomputed quotient multiplier wq = floor(w 2^261 / p):
+    q^ from columns 7 .. 16 of x * wq, r = low 261 bits of x w + q^ (2^261 - p).  Asserts every column sum, the quotient estimate (q or q - 1)
+    and the result: exact limbs, value below (2 + V / 169) p."""
+    wv = val(w)
+    assert wv < P and max(w) <= M29
+    wq = limbs(wv * R1 // P)
+    assert max(wq) <= M29 and all(x <= (1 << 31) + (1 << 29) for x in a) and val(a) < 64 * P
+    acc, q = 0, [0] * 9
+    for k in range(7, 17):
+        lo, hi = max(0, k - 8), min(k, 8)
+        for i in range(lo, hi + 1):
+            acc += a[i] * wq[k - i]
+            assert acc < U64, "column overflow (x * wq)"
+        if k >= 9:
+            q[k - 9] = acc & M29
+        acc >>= 29
+    assert acc < U32
+    q[8] = acc
+    qtrue = val(a) * val(wq) >> 261
+    assert val(q) in (qtrue, qtrue - 1), "quotient estimate off by more than one"
+    acc, r = 0, [0] * 9
+    for k in range(9):
+        for i in range(k + 1):
+            acc += a[i] * w[k - i]
+            assert acc < U64, "column overflow (x * w)"
+        for i in range(k + 1):
+            acc += q[i] * PBAR29[k - i]
+            assert acc < U64, "column overflow (q * pbar)"
+        r[k] = acc & M29
+        acc >>= 29
+    v = val(a) * wv - val(q) * P
+    assert val(r) == v and 0 <= v and v * 169 < (2 * 169 + val(a) // P + 1) * P, "remainder"
+    return r
+
+
+SHOUP = True  # the variant under test (ntt29.hip.h BBG_NTT_SHOUP); the tests run both
+
+
+def mulw(a, w):  # a product by a per-radix table value
+    return mulc(a, w) if SHOUP else mul(a, w)
+
+
+def vp(mont, shoup):  # a value bound that differs between the two multipliers
+    return shoup if SHOUP else mont
+
+
+def kp():  # multiple of p a subtraction adds when its subtrahend is a product / a sum of two products
+    return 4 if SHOUP else 3
+
+
+def kpp():
+    return 6 if SHOUP else 4
+
+
 def reduce_table():
     rows = []
     for k in range(32):
@@ -134,31 +194,31 @@ def step8(x, w1, w2, w3, tw):  # n29_step8<true>
         x[i], x[j] = u, d
     for i in range(4):
         bfly(i, i + 4, 4)
-    x[5], x[6], x[7] = mul(x[5], w1), mul(x[6], w2), mul(x[7], w3)
+    x[5], x[6], x[7] = mulw(x[5], w1), mulw(x[6], w2), mulw(x[7], w3)
     for j in (5, 6, 7):
-        vbound(x[j], 1.05)
+        vbound(x[j], vp(1.05, 2.05))
     for j in range(4):
         vbound(x[j], 6)
     vbound(x[4], 7)
-    bfly(0, 2, 7, 31); bfly(1, 3, 7, 31); bfly(4, 6, 3); bfly(5, 7, 3)
+    bfly(0, 2, 7, 31); bfly(1, 3, 7, 31); bfly(4, 6, kp()); bfly(5, 7, kp())
     x[3] = carry(x[3])
-    x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
-    vbound(x[3], 1.08); vbound(x[7], 1.03)
+    x[3], x[7] = mulw(x[3], w2), mulw(x[7], w2)
+    vbound(x[3], vp(1.08, 2.08)); vbound(x[7], vp(1.03, 2.04))
     for j in (0, 1, 2, 4, 6):
         x[j] = carry(x[j])
-    vbound(x[0], 12); vbound(x[1], 12); vbound(x[2], 13); vbound(x[4], 8.05); vbound(x[6], 10); vbound(x[5], 2.1)
-    bfly(0, 1, 13); bfly(2, 3, 3); bfly(4, 5, 4); bfly(6, 7, 3)
-    for j, v in enumerate((24, 25, 14.1, 16, 10.2, 12.05, 11.03, 13)):
+    vbound(x[0], 12); vbound(x[1], 12); vbound(x[2], 13); vbound(x[4], vp(8.05, 9.05)); vbound(x[6], vp(10, 11)); vbound(x[5], vp(2.1, 4.1))
+    bfly(0, 1, 13); bfly(2, 3, kp()); bfly(4, 5, kpp()); bfly(6, 7, kp())
+    for j, v in enumerate((24, 25) + vp((14.1, 16, 10.2, 12.05, 11.03, 13), (15.1, 17, 13.15, 15.05, 13.05, 15))):
         vbound(x[j], v)
     for j in range(1, 8):
-        x[j] = mul(x[j], tw[j])
-        vbound(x[j], 1.15)
+        x[j] = mulw(x[j], tw[j])
+        vbound(x[j], vp(1.15, 2.15))
     x[0] = reduce(x[0])
     return x
 
 
-def step8_mod(x, w1, w2, w3, tw):  # the same butterfly on residues (x R' form: a product with a table value w R' divides by R' again)
-    rinv = pow(R1, -1, P)
+def step8_mod(x, w1, w2, w3, tw):  # the same butterfly on residues (x R' form: a product with a table value w R' divides by R' again; Shoup: plain w)
+    rinv = 1 if SHOUP else pow(R1, -1, P)
     x = list(x)
 
     def b(i, j, w=None):
@@ -186,10 +246,10 @@ def step4(x, w2):  # n29_step4
         u, d = add(x[i], x[j]), sub(x[i], x[j], k)
         x[i], x[j] = u, d
     bfly(0, 2, 4); bfly(1, 3, 4); bfly(4, 6, 4); bfly(5, 7, 4)
-    x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
+    x[3], x[7] = mulw(x[3], w2), mulw(x[7], w2)
     for j in (0, 1, 4, 5, 2, 6):
         x[j] = carry(x[j])
-    bfly(0, 1, 7); bfly(2, 3, 3); bfly(4, 5, 7); bfly(6, 7, 3)
+    bfly(0, 1, 7); bfly(2, 3, kp()); bfly(4, 5, 7); bfly(6, 7, kp())
     for a in x:
         check_lazy(a, 13, (1 << 31) + 8)
     return x
@@ -213,13 +273,13 @@ def step8_raw(x, w1, w2, w3):  # n29_step8_raw: the radix-8 butterfly without st
         x[i], x[j] = u, d
     for i in range(4):
         bfly(i, i + 4, 4)
-    x[5], x[6], x[7] = mul(x[5], w1), mul(x[6], w2), mul(x[7], w3)
-    bfly(0, 2, 7, 31); bfly(1, 3, 7, 31); bfly(4, 6, 3); bfly(5, 7, 3)
+    x[5], x[6], x[7] = mulw(x[5], w1), mulw(x[6], w2), mulw(x[7], w3)
+    bfly(0, 2, 7, 31); bfly(1, 3, 7, 31); bfly(4, 6, kp()); bfly(5, 7, kp())
     x[3] = carry(x[3])
-    x[3], x[7] = mul(x[3], w2), mul(x[7], w2)
+    x[3], x[7] = mulw(x[3], w2), mulw(x[7], w2)
     for j in (0, 1, 2, 4, 6):
         x[j] = carry(x[j])
-    bfly(0, 1, 13); bfly(2, 3, 3); bfly(4, 5, 4); bfly(6, 7, 3)
+    bfly(0, 1, 13); bfly(2, 3, kp()); bfly(4, 5, kpp()); bfly(6, 7, kp())
     for a in x:
         check_lazy(a, 25, (1 << 31) + 8)
     return x
@@ -272,7 +332,10 @@ def test_reduce_table_and_estimate_over_the_whole_range():
         assert val(r) % P == (val(a) + val(b)) % P
 
 
-def test_step8_random_and_chained():
+@pytest.mark.parametrize("shoup", [True, False])
+def test_step8_random_and_chained(shoup):
+    global SHOUP
+    SHOUP = shoup
     rng = random.Random(2929)
     for trial in range(60):
         w = [exact(rng.randrange(P)) for _ in range(3)]
@@ -285,8 +348,11 @@ def test_step8_random_and_chained():
             assert [val(a) % P for a in x] == ref
 
 
-def test_step8_at_the_entry_bounds():
+@pytest.mark.parametrize("shoup", [True, False])
+def test_step8_at_the_entry_bounds(shoup):
     """Every register just below 3p with every limb as large as a carried value allows; twiddles p - 1 (the largest table value)."""
+    global SHOUP
+    SHOUP = shoup
     big = 3 * P - 1
     fat = limbs(big)
     # move weight downwards: limb i gives 1 to limb i-1 as 2^29 where that keeps limb i-1 below 2^29 + 8
@@ -302,11 +368,15 @@ def test_step8_at_the_entry_bounds():
         assert [val(a) % P for a in out] == ref
 
 
-def test_partial_last_steps_and_the_way_out():
+@pytest.mark.parametrize("shoup", [True, False])
+def test_partial_last_steps_and_the_way_out(shoup):
     """n29_step4 / n29_step2 / n29_step8_raw on inputs at the bound, followed by n29_finish with and without a multiplier: the words written
     back are the residues plain modular arithmetic gives, below 2p."""
+    global SHOUP
+    SHOUP = shoup
     rng = random.Random(404)
-    rinv = pow(R1, -1, P)
+    rinv = pow(R1, -1, P)   # of the way out's Montgomery product (both variants)
+    rinv_tw = 1 if SHOUP else rinv  # of the products by per-radix table values
     big = limbs(3 * P - 1)
     for trial in range(40):
         x = [big] * 8 if trial == 0 else [limbs(rng.randrange(3 * P)) for _ in range(8)]
@@ -318,7 +388,7 @@ def test_partial_last_steps_and_the_way_out():
 
         def b(i, j, ww=None):
             u, d = (ref[i] + ref[j]) % P, (ref[i] - ref[j]) % P
-            ref[i], ref[j] = u, d if ww is None else d * ww * rinv % P
+            ref[i], ref[j] = u, d if ww is None else d * ww * rinv_tw % P
         b(0, 2); b(1, 3, w[1]); b(4, 6); b(5, 7, w[1]); b(0, 1); b(2, 3); b(4, 5); b(6, 7)
         assert [val(a) % P for a in out] == ref
         mult = rng.randrange(2 * P) if trial else 2 * P - 1
@@ -350,3 +420,23 @@ def test_premultiplied_load():
         r = mul(limbs(x), limbs(pre << 5))
         vbound(r, 1.76 + 0.01)
         assert max(r[:8]) < (1 << 29)
+
+
+def test_constant_operand_product_at_its_bounds():
+    """f29_mulc (field29c.hip.h) on its own: random and extreme constants (0, 1, p - 1), operands from 0 to the largest lazily reduced value a
+    step hands it (V < 26, limbs up to 2^31 + 2^29 after an uncarried subtraction), every column and the quotient estimate asserted inside mulc."""
+    rng = random.Random(261)
+    consts = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 1 << 253] + [rng.randrange(P) for _ in range(40)]
+    for w in consts:
+        for v in (0, 1, P - 1, P, 3 * P - 1, 26 * P - 1, rng.randrange(26 * P), rng.randrange(P)):
+            r = mulc(limbs(v), exact(w))
+            assert val(r) % P == v * w % P and max(r) <= M29
+        # an uncarried operand: the difference a - b + 13 p of two carried values just below 12 p, limbs raised by the spread constant
+        a, b = limbs(12 * P - 1), limbs(rng.randrange(12 * P))
+        d = sub(a, b, 13)
+        r = mulc(d, exact(w))
+        assert val(r) % P == (val(a) - val(b)) * w % P
+        fat = [min(x, (1 << 31) + (1 << 29)) for x in [(1 << 31) + (1 << 29)] * 8] + [limbs(20 * P)[8]]
+        if val(fat) < 64 * P:
+            r = mulc(fat, exact(w))
+            assert val(r) % P == val(fat) * w % P
