@@ -415,7 +415,11 @@ static int grid_for(size_t n, int block) { return (int)((n + block - 1) / block)
 // sizes at which the 29-bit-limb pass kernel is the automatic choice (option ntt_limbs29 = -1).  Measured, isolated fft, ms
 // (profiles/r04_ntt29_ab.txt, last series; best 32-bit kernel -> k_ntt_pass29): 2^16 0.0523 -> 0.0507, 2^19 0.0773 -> 0.0748,
 // 2^20 0.1225 -> 0.1107, 2^21 0.2540 -> 0.2329, 2^22 0.4788 -> 0.4447, 2^23 0.9477 -> 0.8851, 2^24 1.9194 -> 1.7706.
-#define NTT_LIMBS29_AUTO(log2n) ((log2n) >= 19)
+// r5, with the constant-operand product in the radix >= 2^9 kernels (isolated fft, ms, 32-bit -> 29-bit kernel): 2^14 0.0485 -> 0.0477, 2^16 0.0523 -> 0.0504,
+// 2^17 0.0573 -> 0.0542, 2^18 0.0646 -> 0.0583 (2^9 x 2^9: both passes take it), 2^19 0.0776 -> 0.0705: the threshold moves to 2^18.  Below it the gain is
+// 1-5 % in isolation and NEGATIVE inside small proofs (2^16 gates 3.86 -> 3.88 ms, 2^14 2.71 -> 2.73 with the 29-bit kernel forced: its 180+ VGPRs
+// leave less room beside the reduce chains it runs next to).
+#define NTT_LIMBS29_AUTO(log2n) ((log2n) >= 18)
 
 static void plan_passes(bbg_ctx* ctx, NttDomain& d)
 {

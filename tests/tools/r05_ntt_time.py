@@ -15,7 +15,7 @@ import torch  # noqa: E402
 pkg = ge.load_package()
 bbg = pkg.Bbg(0)
 bbg.set_stream(torch.cuda.current_stream().cuda_stream)
-bbg.set_option("ntt_limbs29", 1)
+bbg.set_option("ntt_limbs29", int(os.environ.get("R05_LIMBS29", "1")))
 if os.environ.get("R05_BIG_TILE"):
     bbg.set_option("ntt_big_tile", int(os.environ["R05_BIG_TILE"]))
 check = "--check" in sys.argv  # forward + coset transforms of the size against the REFERENCE digests (tests/golden: committed fixture data)
