@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One-off soak (not collected by pytest): random NTT sizes / ops / generator sizes / constants against the oracle, plus
-coset_fft_extend and coset_fft_split.  python tests/tools/soak_ntt.py [cases]"""
+"""One-off soak (not collected by pytest): random NTT sizes / ops / generator sizes / constants / pass plans / pass kernels against the oracle,
+plus coset_fft_extend and coset_fft_split.  python tests/tools/soak_ntt.py [cases]"""
 import os
 import sys
 
@@ -18,7 +18,12 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(7)
 bad = 0
 for c in range(cases):
-    lg = int(rng.integers(0, 15))
+    if c % 8 == 0:  # r5: another pass plan and pass kernel -- the 29-bit-limb kernel (with the constant-operand product in its radix >= 2^9
+        # passes: ntt_max_logr8 up to 11 puts such passes into plans of 2^11 .. 2^16 points) against the 32-bit ones
+        B.set_option("ntt_max_logr8", int(rng.integers(6, 12)))
+        B.set_option("ntt_limbs29", int(rng.integers(-1, 2)))
+        B.set_option("ntt_lds_planes", int(rng.integers(0, 3)))
+    lg = int(rng.integers(0, 15)) if c % 16 else int(rng.integers(15, 18))
     n = 1 << lg
     op = int(rng.integers(0, 8))
     gs = int(rng.integers(1, n + 1)) if op in (2, 5, 6) and rng.integers(2) else 0
