@@ -545,7 +545,7 @@ static int build_domain(bbg_ctx* ctx, unsigned log2n, NttDomain** out)
                 BBG_HIP(hipMalloc(&d.tw_radix29[inv][q], half * NTT29_TW_ROW * 4));
                 d.bytes += half * NTT29_TW_ROW * 4;
                 hipLaunchKernelGGL(k_to_rprime, dim3(grid_for(half, 256)), dim3(256), 0, st, (uint32_t*)d.tw_radix29[inv][q], (const Fr*)d.tw_radix[inv][q], half,
-                                   p29_shoup(logR) ? 1 : 0);
+                                   p29_shoup(logR) != 0 ? 1 : 0);
             }
             if (q < d.passes - 1) {
                 // inter-pass twiddles w_{N_q}^(i*lo), N_q = R*S ; w_{N_q} = w_n^(n/N_q): use the pow2 table shifted

@@ -27,28 +27,34 @@ namespace bbg {
 using Fr29 = F29<FrP>;
 
 // ---- the multiplier of the TABLE twiddles (r5): a per-kernel choice, template argument SH of the steps below.
-//   SH = true : every product by a per-radix table value -- the butterfly's own w8 powers and the step twiddles, twelve of the 13.5 products per
+//   SH = 1, 2  : every product by a per-radix table value -- the butterfly's own w8 powers and the step twiddles, twelve of the 13.5 products per
 //               eight elements and step -- is the constant-operand product of field29c.hip.h (143 mads, no m digits): a table row holds w and
 //               wq = floor(w 2^261 / p).  The same residue with exact limbs but a looser value bound: below (2 + V / 169) p where Montgomery
 //               leaves (1 + V / 169) p, so a subtraction whose subtrahend is a product adds one more multiple of p (KP / KPP) and the values
 //               downstream grow accordingly; every bound is restated in the comments and asserted on the big-integer model
 //               (tests/test_ntt29_model.py, both variants).  Costs 9 more registers per live twiddle: the kernels that run two waves per SIMD
 //               anyway take it (log-radix >= 9: ntt_pass29.hip.h p29_shoup), measured -4 % at 2^20 (profiles/r05_ntt_attempts.txt).
-//   SH = false: Montgomery products against w R' (round 4): the kernels that fit three waves per SIMD (log-radix <= 8).
+//   SH = 0     : Montgomery products against w R' (round 4): the kernels that fit three waves per SIMD (log-radix <= 8).
 constexpr int NTT29_TW_ROW = C29_ROW; // words per row of a per-radix table, either format (9 limbs of w R' in the first 12 words, or w and wq in 18)
-template <bool SH> struct N29M;
-template <> struct N29M<true> {
+// SH: 0 = Montgomery, 1 = constant-operand product, 2 = the same with the butterfly's own (wave-uniform) multipliers as SGPR operands (no VGPRs for
+// them: the variant for kernels that must stay within 168 VGPRs; slower than 1 where registers do not matter: 0.1092 vs 0.1073 ms at 2^20)
+template <int SH> struct N29M {
     using Tw = C29<FrP>;
     static constexpr int KP = 4;  // a - b + KP p for b a product (V < 2.16)
     static constexpr int KPP = 6; // ... for b a sum of two products (V < 4.1)
     static __device__ __forceinline__ void mul2(Fr29& a, const Tw& wa, Fr29& b, const Tw& wb) { f29_mulc2(a, wa, b, wb, a, b); }
     static __device__ __forceinline__ void mul(Fr29& a, const Tw& w) { a = f29_mulc(a, w); }
+    // u = the multiplier is the same for every lane of the wave
+    static __device__ __forceinline__ void mul2u(Fr29& a, const Tw& wa, Fr29& b, const Tw& wb) { f29_mulc2<SH == 2, SH == 2>(a, wa, b, wb, a, b); }
+    static __device__ __forceinline__ void mulu(Fr29& a, const Tw& w) { a = f29_mulc<SH == 2>(a, w); }
 };
-template <> struct N29M<false> {
+template <> struct N29M<0> {
     using Tw = Fr29;
     static constexpr int KP = 3, KPP = 4;
     static __device__ __forceinline__ void mul2(Fr29& a, const Tw& wa, Fr29& b, const Tw& wb) { f29_mul2(a, wa, b, wb, a, b); }
     static __device__ __forceinline__ void mul(Fr29& a, const Tw& w) { a = f29_mul(a, w); }
+    static __device__ __forceinline__ void mul2u(Fr29& a, const Tw& wa, Fr29& b, const Tw& wb) { f29_mul2(a, wa, b, wb, a, b); }
+    static __device__ __forceinline__ void mulu(Fr29& a, const Tw& w) { a = f29_mul(a, w); }
 };
 
 // ---- reduction of a value < 32 p to < 3 p without a multiplication: estimate q = floor(x / p) from the top limb (never too large, at
@@ -114,7 +120,7 @@ __device__ __forceinline__ void n29_carry(Fr29& a) { a = f29_carry(a); }
 // Bounds with SH (a product leaves V < 2 + V_in / 169 <= 2.16, exact limbs): level 2 (4,6) d = a - b + 4p V < 11, u V < 9.04;
 // (5,7) u V < 4.08 (L < 2^30), d (+4p) V < 6.04; products of level 2 V < 2.08; level 3 (2,3) d (+4p) V < 17, u V < 15.1; (4,5) a V < 9.04,
 // b V < 4.08: d (+6p) V < 15.04, u V < 13.1; (6,7) a V < 11: d (+4p) V < 15, u V < 13.04; (0,1) unchanged (24 / 25).  Step twiddle products V < 2.15.
-template <bool SH, bool HAVE_TW, class TW>
+template <int SH, bool HAVE_TW, class TW>
 __device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const typename N29M<SH>::Tw& w1, const typename N29M<SH>::Tw& w2, const typename N29M<SH>::Tw& w3,
                                           TW tw, const uint32_t* red)
 {
@@ -126,8 +132,8 @@ __device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const typename N29M<SH>:
     n29_bfly<4>(x[1], x[5]);
     n29_bfly<4>(x[2], x[6]);
     n29_bfly<4>(x[3], x[7]);
-    M::mul2(x[5], w1, x[6], w2); // V < 7/169 + 1 = 1.05 (Shoup: 2.05), L < 2^29
-    M::mul(x[7], w3);
+    M::mul2u(x[5], w1, x[6], w2); // V < 7/169 + 1 = 1.05 (Shoup: 2.05), L < 2^29
+    M::mulu(x[7], w3);
     // level 2.  (0,2), (1,3): a, b V < 6, L < 2^30 + 16: u V < 12, L < 2^31 + 32; d = a - b + 7p (E = 31) V < 13, L < 2^30 + 16 + 2^31 + 2^29.
     // (4,6): a V < 7, L < 2^31 + 8, b V < 1.05 exact: u V < 8.05, L < 2^31 + 2^29 + 8; d = a - b + 3p V < 10, L < 2^31 + 8 + 2^30 + 2^29.
     // (5,7): a, b V < 1.05 exact: u V < 2.1 (L < 2^30), d = a - b + 3p V < 4.05.
@@ -136,7 +142,7 @@ __device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const typename N29M<SH>:
     n29_bfly<M::KP>(x[4], x[6]);
     n29_bfly<M::KP>(x[5], x[7]);
     n29_carry(x[3]);                          // a multiplication's operand: limbs back below 2^29 + 8
-    M::mul2(x[3], w2, x[7], w2); // V < 13/169 + 1 = 1.08 ; V < 1.03 (Shoup: 2.08 / 2.04)
+    M::mul2u(x[3], w2, x[7], w2); // V < 13/169 + 1 = 1.08 ; V < 1.03 (Shoup: 2.08 / 2.04)
     n29_carry(x[0]); n29_carry(x[1]);         // V < 12
     n29_carry(x[2]);                          // V < 13
     n29_carry(x[4]);                          // V < 8.05
@@ -174,7 +180,7 @@ __device__ __forceinline__ void n29_step8(Fr29 (&x)[8], const typename N29M<SH>:
 // outputs leave for the pass's final multiplication / conversion.  in: x[j] carried, V < 3.
 //   S = 2: radix-4 on (b1 b0) -- pairs (0,2), (1,3) w4, (4,6), (5,7) w4, then (0,1), (2,3), (4,5), (6,7).  out: V < 13, L < 2^31 + 8.
 //   S = 1: pairs (0,1), (2,3), (4,5), (6,7).                                                              out: V < 7,  L < 2^31 + 8.
-template <bool SH> __device__ __forceinline__ void n29_step4(Fr29 (&x)[8], const typename N29M<SH>::Tw& w2)
+template <int SH> __device__ __forceinline__ void n29_step4(Fr29 (&x)[8], const typename N29M<SH>::Tw& w2)
 {
     using M = N29M<SH>;
     // level A: u V < 6, d = a - b + 4p V < 7
@@ -182,7 +188,7 @@ template <bool SH> __device__ __forceinline__ void n29_step4(Fr29 (&x)[8], const
     n29_bfly<4>(x[1], x[3]);
     n29_bfly<4>(x[4], x[6]);
     n29_bfly<4>(x[5], x[7]);
-    M::mul2(x[3], w2, x[7], w2); // V < 7/169 + 1 = 1.05 (Shoup: 2.05)
+    M::mul2u(x[3], w2, x[7], w2); // V < 7/169 + 1 = 1.05 (Shoup: 2.05)
     n29_carry(x[0]); n29_carry(x[1]); n29_carry(x[4]); n29_carry(x[5]); // V < 6
     n29_carry(x[2]); n29_carry(x[6]);                                   // V < 7
     // level B: (0,1), (4,5): a, b V < 6: u V < 12, d (+7p) V < 13.  (2,3), (6,7): a V < 7, b V < 1.05 exact: u V < 8.05, d (+3p) V < 10
@@ -201,7 +207,7 @@ __device__ __forceinline__ void n29_step2(Fr29 (&x)[8])
 }
 // A radix-8 step WITHOUT step twiddles (the last step of a pass whose log-radix is a multiple of 3): n29_step8<false> reduces every register;
 // when a final multiplication follows, the reduction can wait for it: out V < 25, L < 2^31 + 8 (see n29_step8's level 3).
-template <bool SH>
+template <int SH>
 __device__ __forceinline__ void n29_step8_raw(Fr29 (&x)[8], const typename N29M<SH>::Tw& w1, const typename N29M<SH>::Tw& w2, const typename N29M<SH>::Tw& w3)
 {
     using M = N29M<SH>;
@@ -209,14 +215,14 @@ __device__ __forceinline__ void n29_step8_raw(Fr29 (&x)[8], const typename N29M<
     n29_bfly<4>(x[1], x[5]);
     n29_bfly<4>(x[2], x[6]);
     n29_bfly<4>(x[3], x[7]);
-    M::mul2(x[5], w1, x[6], w2);
-    M::mul(x[7], w3);
+    M::mul2u(x[5], w1, x[6], w2);
+    M::mulu(x[7], w3);
     n29_bfly<7, 31>(x[0], x[2]);
     n29_bfly<7, 31>(x[1], x[3]);
     n29_bfly<M::KP>(x[4], x[6]);
     n29_bfly<M::KP>(x[5], x[7]);
     n29_carry(x[3]);
-    M::mul2(x[3], w2, x[7], w2);
+    M::mul2u(x[3], w2, x[7], w2);
     n29_carry(x[0]); n29_carry(x[1]);
     n29_carry(x[2]);
     n29_carry(x[4]);

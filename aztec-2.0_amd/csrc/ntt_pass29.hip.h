@@ -32,19 +32,29 @@ __device__ __forceinline__ int p29_slot(int p, int c, int logW) // swizzled slot
     return q ^ ((q >> 3) & 15);
 }
 
-// Which multiplier a pass kernel takes for its table twiddles (ntt29.hip.h N29M): the constant-operand product where the kernel runs two waves
-// per SIMD anyway (log-radix >= 9: 182 - 198 VGPRs with Montgomery, 223 - 233 with it); the radix-2^7 / 2^8 kernels of the three-pass plans keep
-// Montgomery and their third wave (144 - 168 VGPRs; with the constant-operand product 225 - 240).  BBG_NTT_SHOUP = 0: Montgomery everywhere (A/B).
+// Which multiplier a pass kernel takes for its table twiddles (ntt29.hip.h N29M<SH>), r5.  Log-radix >= 9 (two waves per SIMD anyway: 182 - 198
+// VGPRs with Montgomery): SH = 1, the constant-operand product with every twiddle in VGPRs (223 - 233).  Log-radix <= 8 (the three-pass plans of
+// 2^22 .. 2^24, three waves per SIMD in 144 - 168 VGPRs): SH = 2, the same product with the butterfly's own, wave-uniform multipliers as SGPR operands,
+// compiled for three waves (168 VGPRs: radix 2^8 fits, radix 2^7 spills 12 - 14 registers and still wins).  With SH = 1 everywhere those kernels need
+// 225 - 240 VGPRs, lose their third wave and 2^22 / 2^24 get 2 - 5 % SLOWER; with SH = 2: 2^24 1.745 -> 1.670 ms, 2^22 0.456 -> 0.444
+// (profiles/r05_ntt_attempts.txt).  BBG_NTT_SHOUP = 0: Montgomery everywhere; BBG_NTT_SHOUP_SMALL = 0: Montgomery in the radix <= 2^8 kernels (A/B).
+#ifndef BBG_NTT29_OCC
+#define BBG_NTT29_OCC 2
+#endif
 #ifndef BBG_NTT_SHOUP
 #define BBG_NTT_SHOUP 1
 #endif
-constexpr bool p29_shoup(int logR) { return BBG_NTT_SHOUP && logR >= 9; }
+#ifndef BBG_NTT_SHOUP_SMALL
+#define BBG_NTT_SHOUP_SMALL 2
+#endif
+constexpr int p29_shoup(int logR) { return !BBG_NTT_SHOUP ? 0 : logR >= 9 ? 1 : BBG_NTT_SHOUP_SMALL; }
+constexpr int p29_occ(int logR) { return (BBG_NTT_SHOUP && BBG_NTT_SHOUP_SMALL && logR <= 8) ? 3 : BBG_NTT29_OCC; }
 
-template <bool SH> __device__ __forceinline__ typename N29M<SH>::Tw p29_load_tw(const uint32_t* __restrict__ tw29, int idx) // a table row
+template <int SH> __device__ __forceinline__ typename N29M<SH>::Tw p29_load_tw(const uint32_t* __restrict__ tw29, int idx) // a table row
 {
     const uint4* row = reinterpret_cast<const uint4*>(tw29 + (size_t)idx * NTT29_TW_ROW);
     typename N29M<SH>::Tw r;
-    if constexpr (SH) {
+    if constexpr (SH != 0) {
         const uint4 a = row[0], b = row[1], c = row[2], d = row[3];
         const uint2 e = *reinterpret_cast<const uint2*>(row + 4);
         r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
@@ -67,7 +77,7 @@ template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)
 {
     constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
     constexpr int F = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
-    constexpr bool SH = p29_shoup(LOGR);
+    constexpr int SH = p29_shoup(LOGR);
     using Tw29 = typename N29M<SH>::Tw;
     if constexpr (S == 3) {
         const Tw29 w1 = p29_load_tw<SH>(tw29, 1 << (LOGR - 3)), w2 = p29_load_tw<SH>(tw29, 1 << (LOGR - 2)), w3 = p29_load_tw<SH>(tw29, 3 << (LOGR - 3));
@@ -161,13 +171,10 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
 // isolated fft, ms): capping the kernel at 168 VGPRs for three waves gives the same times with 23-46 spills (2^20 0.1193 vs 0.1190); fetching
 // the multipliers behind the data loads as k_ntt_pass8 does -- 64 registers held through the whole pass -- is SLOWER (2^20 0.1236 vs 0.1187,
 // 2^22 0.508 vs 0.455): with 9-word elements the registers are worth more than the latency they would hide.
-#ifndef BBG_NTT29_OCC
-#define BBG_NTT29_OCC 2
-#endif
 #ifndef BBG_NTT29_PREFETCH
 #define BBG_NTT29_PREFETCH 0 // 1 = multipliers fetched at the start (64 registers held through the pass), 0 = fetched where they are used
 #endif
-template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), BBG_NTT29_OCC) k_ntt_pass29(PassParams p)
+template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bounds__(1 << (TL - 3), p29_occ(LOGR)) k_ntt_pass29(PassParams p)
 {
     extern __shared__ uint4 lds[];
     BBG_NTT_SELECT_BATCH(p);

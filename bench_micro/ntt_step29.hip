@@ -54,7 +54,7 @@ template <int V> __global__ void __launch_bounds__(256) k_step(uint32_t* out, co
             t29[j] = f29_from_fe<FrP, 0>(to_rprime(tw[j])); // w R' mod p, exact limbs
         }
         const Fr29 W1 = t29[1], W2 = t29[2], W3 = t29[3];
-        for (int it = 0; it < ITERS; it++) n29_step8<false, true>(y, W1, W2, W3, [&](int j) { return t29[j]; }, red);
+        for (int it = 0; it < ITERS; it++) n29_step8<0, true>(y, W1, W2, W3, [&](int j) { return t29[j]; }, red);
         int fails = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
