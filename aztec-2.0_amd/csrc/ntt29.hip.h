@@ -233,6 +233,28 @@ __device__ __forceinline__ void n29_step8_raw(Fr29 (&x)[8], const typename N29M<
     n29_bfly<M::KP>(x[6], x[7]);
 }
 
+// the second half of n29_step8<SH, true> on its own: the seven step twiddles and the reduction of register 0, applied to n29_step8_raw's outputs
+// (V < 25, L < 2^31 + 8) -- for the pass kernel's steps in which some waves have unit twiddles and skip this half (ntt_pass29.hip.h)
+template <int SH, class TW> __device__ __forceinline__ void n29_step8_twiddles(Fr29 (&x)[8], TW tw, const uint32_t* red)
+{
+    using M = N29M<SH>;
+    using Tw29 = typename M::Tw;
+    {
+        const Tw29 t1 = tw(1), t2 = tw(2);
+        M::mul2(x[1], t1, x[2], t2);
+    }
+    {
+        const Tw29 t3 = tw(3), t4 = tw(4);
+        M::mul2(x[3], t3, x[4], t4);
+    }
+    {
+        const Tw29 t5 = tw(5), t6 = tw(6);
+        M::mul2(x[5], t5, x[6], t6);
+    }
+    M::mul(x[7], tw(7));
+    x[0] = ntt29_reduce(x[0], red); // V < 24 -> < 3
+}
+
 // ---- the way out of a pass.  x: V < 25, L < 2^31 + 8 (any output of the last step).  With a multiplier (inter-pass twiddle / post-scale table
 // entry, the R-form words of the table shifted by 5 bits: w R' as an integer < 64 p, exact limbs): product V < 25 * 64 / 169 + 1 = 10.5, then the
 // table reduction (V < 3), exact limbs, the 8 words, one conditional subtraction -> the coarse [0, 2p) residue the device arrays hold.

@@ -73,6 +73,41 @@ template <int SH> __device__ __forceinline__ typename N29M<SH>::Tw p29_load_tw(c
 
 // butterfly of step T + its step twiddles (p8s_compute's structure on F29 values).  `raw_last`: a LAST step with S = 3 leaves its outputs
 // un-reduced for the pass's final multiplication / reduction (n29_step8_raw)
+// ---- unit step twiddles (r5).  The step twiddle of register j is w_R^((brev3(j) * qlo) << DONE): for qlo = 0 all seven are ONE.  In the radix-8
+// step whose qlo has one or two bits (F = 1, 2: the step in front of a pass's last) that is every second / fourth thread -- 7 of its 12 products
+// multiply by one.  With the standard thread -> element assignment qlo sits in the low bits of the thread index (lanes of every wave differ); in
+// such a step k_ntt_pass29 takes qlo from the TOP bits of the thread index instead (a relabelling of which thread holds which eight elements of
+// the tile: the exchanges on either side use the same function), so that it is the same for a whole wave, and a wave with qlo = 0 runs the step
+// without twiddles (n29_step8<SH, false>: a table reduction per register instead of a product).  Radix 2^10: 3.5 of a thread's 44 products per
+// pass on average, 2^7: 3.5 of 32, 2^8: 1.75 of 34.  BBG_NTT29_UNIT = 0: the standard assignment (A/B).
+#ifndef BBG_NTT29_UNIT
+#define BBG_NTT29_UNIT 1
+#endif
+#ifndef BBG_NTT29_UNIT_MIN_LOGR
+#define BBG_NTT29_UNIT_MIN_LOGR 9 // the radix <= 2^8 kernels (168 VGPRs for three waves) spill 29 registers around the branch and get 5 % slower
+#endif
+constexpr bool p29_unit_step(int logR, int T)
+{
+    const int S = (logR - 3 * T >= 3) ? 3 : (logR - 3 * T), F = (logR - 3 * T >= 3) ? (logR - 3 * (T + 1)) : 0;
+    return BBG_NTT29_UNIT && logR >= BBG_NTT29_UNIT_MIN_LOGR && T >= 1 && S == 3 && F >= 1 && F <= 2 && logR - 3 > F;
+}
+template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29_coords(int tid, int& c, int& pbase, int& qlo)
+{
+    if constexpr (p29_unit_step(LOGR, T)) {
+        constexpr int F = LOGR - 3 * (T + 1), LOGW = TL - LOGR, QBITS = LOGR - 3;
+        c = tid & ((1 << LOGW) - 1);
+        const int q = tid >> LOGW;
+        qlo = q >> (QBITS - F); // thread-index bits [TL - 3 - F, TL - 3): above the lane bits, one value per wave
+        // which waves of a block have qlo = 0 alternates with the block: the waves of one block sit on four different SIMDs, and two blocks whose
+        // unit waves share SIMDs leave the other SIMDs with all the work (measured at 2^20: 0.1074 ms without the alternation, 0.1055 with it,
+        // 0.1083 without the unit steps at all)
+        qlo ^= (blockIdx.x & 1) ? ((1 << F) - 1) : 0;
+        pbase = ((q & ((1 << (QBITS - F)) - 1)) << (F + 3)) | qlo;
+    } else {
+        p8s_coords<LOGR, ROW, T, TL>(tid, c, pbase, qlo);
+    }
+}
+
 template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)[8], const uint32_t* __restrict__ tw29, int qlo, const uint32_t* red)
 {
     constexpr int S = (LOGR - 3 * T >= 3) ? 3 : (LOGR - 3 * T);
@@ -83,7 +118,21 @@ template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)
         const Tw29 w1 = p29_load_tw<SH>(tw29, 1 << (LOGR - 3)), w2 = p29_load_tw<SH>(tw29, 1 << (LOGR - 2)), w3 = p29_load_tw<SH>(tw29, 3 << (LOGR - 3));
         if constexpr (F > 0) {
             constexpr int DONE = LOGR - 3 - F;
-            n29_step8<SH, true>(x, w1, w2, w3, [&](int j) { return p29_load_tw<SH>(tw29, (p8_brev3(j) * qlo) << DONE); }, red);
+            if constexpr (p29_unit_step(LOGR, T)) {
+                // the butterfly is the same for both kinds of wave; only what follows it differs
+                n29_step8_raw<SH>(x, w1, w2, w3);
+                if (__builtin_amdgcn_readfirstlane(qlo) == 0) { // the whole wave: every step twiddle is one -> a table reduction per register
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        x[j] = ntt29_reduce(x[j], red);
+                        asm volatile("" ::: "memory"); // one table row in flight at a time: eight hoisted rows are 96 registers
+                    }
+                } else {
+                    n29_step8_twiddles<SH>(x, [&](int j) { return p29_load_tw<SH>(tw29, (p8_brev3(j) * qlo) << DONE); }, red);
+                }
+            } else {
+                n29_step8<SH, true>(x, w1, w2, w3, [&](int j) { return p29_load_tw<SH>(tw29, (p8_brev3(j) * qlo) << DONE); }, red);
+            }
         } else {
             n29_step8_raw<SH>(x, w1, w2, w3);
         }
@@ -102,8 +151,8 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     constexpr int F0 = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
     constexpr int F1 = (LOGR - 3 * (T + 1) >= 3) ? (LOGR - 3 * (T + 2)) : 0;
     int c0, pb0, ql0, c1, pb1, ql1;
-    p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
-    p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+    p29_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
+    p29_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
 #if defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 1) // timing experiment only (wrong results): no exchange at all
     return;
 #endif
@@ -146,8 +195,8 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     constexpr int F0 = (LOGR - 3 * T >= 3) ? (LOGR - 3 * (T + 1)) : 0;
     constexpr int F1 = (LOGR - 3 * (T + 1) >= 3) ? (LOGR - 3 * (T + 2)) : 0;
     int c0, pb0, ql0, c1, pb1, ql1;
-    p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
-    p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+    p29_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
+    p29_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
     if (T > 0) __syncthreads(); // everybody has read the previous exchange's elements
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -228,7 +277,7 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
     const bool have_outmul = mul_table != nullptr;
     // ---- step 0: the tile from global memory (the addressing of k_ntt_pass8), re-limbed; the first pass's coset factor as a product
     int c, pbase, qlo;
-    p8s_coords<LOGR, ROW, 0, TL>(threadIdx.x, c, pbase, qlo);
+    p29_coords<LOGR, ROW, 0, TL>(threadIdx.x, c, pbase, qlo);
     {
         constexpr int F = (LOGR >= 3) ? (LOGR - 3) : 0;
 #pragma unroll
@@ -283,19 +332,19 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
     if constexpr (NSTEPS > 1) {
         if constexpr (LATE_PREFETCH && NSTEPS == 2) { if (have_outmul) fetch_outmul(); }
         P29_EXCHANGE(0);
-        p8s_coords<LOGR, ROW, 1, TL>(threadIdx.x, c, pbase, qlo);
+        p29_coords<LOGR, ROW, 1, TL>(threadIdx.x, c, pbase, qlo);
         p29_compute<LOGR, 1>(x, tw29, qlo, red);
     }
     if constexpr (NSTEPS > 2) {
         if constexpr (LATE_PREFETCH && NSTEPS == 3) { if (have_outmul) fetch_outmul(); }
         P29_EXCHANGE(1);
-        p8s_coords<LOGR, ROW, 2, TL>(threadIdx.x, c, pbase, qlo);
+        p29_coords<LOGR, ROW, 2, TL>(threadIdx.x, c, pbase, qlo);
         p29_compute<LOGR, 2>(x, tw29, qlo, red);
     }
     if constexpr (NSTEPS > 3) {
         if constexpr (LATE_PREFETCH && NSTEPS == 4) { if (have_outmul) fetch_outmul(); }
         P29_EXCHANGE(2);
-        p8s_coords<LOGR, ROW, 3, TL>(threadIdx.x, c, pbase, qlo);
+        p29_coords<LOGR, ROW, 3, TL>(threadIdx.x, c, pbase, qlo);
         p29_compute<LOGR, 3>(x, tw29, qlo, red);
     }
     // ---- the last step's elements: final multiplier (inter-pass twiddle / post table), reduction, back to 8 words, out (bit reversal in the index)
