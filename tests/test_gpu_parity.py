@@ -36,6 +36,19 @@ def test_quad_ec_operations_device_check():
     assert r.returncode == 0 and "failure mask 0x0 (PASS)" in out, out[-600:]
 
 
+def test_constant_operand_product_device_check():
+    """field29c.hip.h (the NTT's multiplier for table twiddles: x * w mod p through wq = floor(w 2^261 / p), no Montgomery digits) ON THE DEVICE
+    against field.hip.h's fe_mul: 524 288 lazily reduced operands x 256 constants incl. 0, 1 and p - 1, exact limbs asserted
+    (bench_micro/mul_shoup29.hip; the bounds themselves are asserted on big integers in tests/test_ntt29_model.py)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_micro", "mul_shoup29")
+    if not os.path.exists(exe):
+        pytest.fail("bench_micro/mul_shoup29 has not been built: run __graft_entry__.build()")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "failure mask 0x0 (PASS)" in out, out[-600:]
+
+
 @pytest.mark.parametrize("which", [0, 1])
 def test_field_ops(pkg, oracle, bbg, which):
     a = pkg.synthetic_scalars(11, 20000)
