@@ -265,6 +265,11 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->prover_early_cosets = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "prover_tail_window")) {
+        if (value != 0 && msm_width_slot((int)value) < 0) { set_error("prover_tail_window: 0 or a compiled window width"); return BBG_E_INVALID; }
+        ctx->prover_tail_window = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "prover_ntt_batch")) {
         ctx->prover_ntt_batch = value != 0;
         return BBG_OK;

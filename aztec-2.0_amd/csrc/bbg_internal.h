@@ -123,6 +123,7 @@ struct bbg_ctx {
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    int prover_tail_window = 0;      // option "prover_tail_window" (A/B): window width of the commitments whose reduce phase ends a round (rounds 4 and 6: the host waits for them with the chip idle) -- fewer buckets, shorter tail, more windows; 0 = the automatic width
     bool prover_ntt_batch = true;    // option "prover_ntt_batch": the wires' iFFTs (round 1) and 4n coset forms of circuits up to 2^17 gates go through ONE launch set each (grid.y = wires) instead of one per wire (A/B)
     int prover_fail_round = 0;       // option "prover_fail_round" (tests only): the next bbg_prover_round<k> returns BBG_E_HIP once -- how the shim's fallback to the reference body is exercised
     bool prover_early_cosets = true; // option "prover_early_cosets": the wires' 4n coset forms are queued behind round 1's last commitment (beside its reduce phase) instead of in front of round 3's grand product

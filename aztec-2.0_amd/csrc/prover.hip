@@ -141,16 +141,20 @@ int dev_alloc(bbg_prover* p, void** out, size_t bytes)
 // The independent commitments of a round -- the reference queues them and processes the queue as one unit (prover.cpp:66-74 the wires,
 // :120-135 the quotient parts, work_queue.hpp:208-282) -- go through ONE sort / accumulate / reduce launch set, `max_batch` at a time
 // (option "prover_msm_batch": 0 / 1 = one launch set per commitment, the round-3 behaviour, A/B).  Result k lands at d_jac + 96 (first + k).
-int commit(bbg_prover* p, int count, const void* const* d_polys, const size_t* lens, int first, hipStream_t st)
+int commit(bbg_prover* p, int count, const void* const* d_polys, const size_t* lens, int first, hipStream_t st, bool tail = false)
 {
     const int max_batch = std::max(1, std::min(p->ctx->prover_msm_batch, BBG_MSM_BATCH_MAX));
     const size_t zero[BBG_MSM_BATCH_MAX] = { 0 };
-    for (int k = 0; k < count; k += max_batch) {
+    // `tail`: the host waits for these commitments with nothing else queued (rounds 4 and 6): option prover_tail_window trades windows for buckets there
+    const int saved_window = p->ctx->msm_window;
+    if (tail && p->ctx->prover_tail_window && !saved_window) p->ctx->msm_window = p->ctx->prover_tail_window;
+    int rc = BBG_OK;
+    for (int k = 0; k < count && !rc; k += max_batch) {
         const int c = std::min(max_batch, count - k);
-        int rc = msm_run_batch(p->ctx, p->srs->s, c, d_polys + k, zero, lens + k, (char*)p->d_jac + (size_t)(first + k) * 96, st);
-        if (rc) return rc;
+        rc = msm_run_batch(p->ctx, p->srs->s, c, d_polys + k, zero, lens + k, (char*)p->d_jac + (size_t)(first + k) * 96, st);
     }
-    return BBG_OK;
+    p->ctx->msm_window = saved_window;
+    return rc;
 }
 int grid_for(size_t n, int block) { return (int)((n + block - 1) / block); }
 
@@ -521,7 +525,7 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
             parts[k] = (char*)p->quotient + (size_t)k * n * 32;
             lens[k] = (p->width == 3 && k == 2) ? n + 1 : n;
         }
-        rc = commit(p, p->width, parts, lens, 0, st);
+        rc = commit(p, p->width, parts, lens, 0, st, true);
     }
     if (rc) return rc;
     rc = fetch_commitments(p, (size_t)p->width, t_commitments, st);
@@ -626,7 +630,7 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
     if (!rc && !together) rc = msm_run(p->ctx, p->srs->s, p->opening[1], 0, n, (char*)p->d_jac + 96, st);
     if (!rc && together) {
         const size_t lens[2] = { n, n };
-        rc = commit(p, 2, p->opening, lens, 0, st);
+        rc = commit(p, 2, p->opening, lens, 0, st, true);
     }
     if (rc) return rc;
     uint64_t both[24];
