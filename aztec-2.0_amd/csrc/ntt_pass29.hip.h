@@ -143,16 +143,6 @@ template <int LOGR, int T> __device__ __forceinline__ void p29_compute(Fr29 (&x)
     }
 }
 
-// padded slot of register j of a thread whose register 0 sits at in-tile position (pb, c): registers are 2^(F + LOGW) elements apart; where that is a
-// multiple of 16 the padding (two slots per sixteen) is a constant per register and the slot is base + j * step -- ONE address register and immediate
-// offsets for the eight accesses (the compiler does not see that floor((q + 16 k) / 16) = floor(q / 16) + k and keeps eight addresses alive)
-template <int F, int LOGW> __device__ __forceinline__ int p29_reg_slot(int base_slot, int pb, int c, int j)
-{
-    constexpr int STRIDE = 1 << (F + LOGW);
-    if constexpr (STRIDE % 16 == 0) return base_slot + j * (STRIDE + (STRIDE >> 4) * 2);
-    else return p8_addr(pb | (j << F), c, LOGW);
-}
-
 // x: the 8 elements of step T (in place) -> the 8 elements of step T + 1.  Every value that crosses is a valid step input (V < 3, limbs below
 // 2^29 + 8): a product, or a reduced register 0.
 template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29_exchange(Fr29 (&x)[8], uint4* buf, uint32_t* buf8)
@@ -170,7 +160,7 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     if (T > 0) __syncthreads(); // everybody has taken limbs 4..7 of the previous exchange out of the buffer
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int a = p29_reg_slot<F0, LOGW>(s0, pb0, c0, j);
+        const int a = p8_reg_slot<F0, LOGW>(s0, pb0, c0, j);
         buf[a] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
         buf8[a] = x[j].v[8];
     }
@@ -179,17 +169,17 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     uint32_t top[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int a = p29_reg_slot<F1, LOGW>(s1, pb1, c1, j);
+        const int a = p8_reg_slot<F1, LOGW>(s1, pb1, c1, j);
         lo[j] = buf[a];
         top[j] = buf8[a];
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; j++) buf[p29_reg_slot<F0, LOGW>(s0, pb0, c0, j)] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
+    for (int j = 0; j < 8; j++) buf[p8_reg_slot<F0, LOGW>(s0, pb0, c0, j)] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint4 h = buf[p29_reg_slot<F1, LOGW>(s1, pb1, c1, j)];
+        const uint4 h = buf[p8_reg_slot<F1, LOGW>(s1, pb1, c1, j)];
         x[j].v[0] = lo[j].x; x[j].v[1] = lo[j].y; x[j].v[2] = lo[j].z; x[j].v[3] = lo[j].w;
         x[j].v[4] = h.x; x[j].v[5] = h.y; x[j].v[6] = h.z; x[j].v[7] = h.w;
         x[j].v[8] = top[j];

@@ -25,6 +25,15 @@ __device__ __forceinline__ int p8_addr(int p, int c, int logW) // padded LDS slo
     const int q = (p << logW) + c;
     return q + ((q >> 4) << 1);
 }
+// padded slot of register j of a thread whose register 0 sits at slot base_slot = p8_addr(pb, c): registers are 2^(F + LOGW) elements apart; where
+// that is a multiple of 16 the padding is a constant per register and the slot is base + j * step -- ONE address register and immediate offsets for
+// the eight accesses (r5: the compiler does not see that floor((q + 16 k) / 16) = floor(q / 16) + k and keeps eight addresses alive)
+template <int F, int LOGW> __device__ __forceinline__ int p8_reg_slot(int base_slot, int pb, int c, int j)
+{
+    constexpr int STRIDE = 1 << (F + LOGW);
+    if constexpr (STRIDE % 16 == 0) return base_slot + j * (STRIDE + (STRIDE >> 4) * 2);
+    else return p8_addr(pb | (j << F), c, LOGW);
+}
 __device__ __forceinline__ Fr p8_lds_load(const uint4* plo, const uint4* phi, int a)
 {
     const uint4 l = plo[a], h = phi[a];
@@ -139,6 +148,7 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
     }
     const int qlo = q & ((1 << F) - 1);
     const int pbase = ((q >> F) << (F + 3)) | qlo; // field bits zero
+    const int slot0 = p8_addr(pbase, c, LOGW);
     // ---- fetch
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -158,7 +168,7 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
             g = (((((d1_0 + c) << logRestCount) + rest)) << LOGR) + pj;
             x[j] = fe_load<FrP>(p.in + g);
         } else {
-            x[j] = p8_lds_load(plo, phi, p8_addr(pj, c, LOGW));
+            x[j] = p8_lds_load(plo, phi, p8_reg_slot<F, LOGW>(slot0, pbase, c, j));
         }
     }
     // ---- butterfly on the top S bits of the field
@@ -191,7 +201,7 @@ __device__ __forceinline__ void p8_step(Fr (&x)[8], const PassParams& p, uint4* 
     for (int j = 0; j < 8; j++) {
         const int pj = pbase | (j << F);
         if (!LAST) {
-            p8_lds_store(plo, phi, p8_addr(pj, c, LOGW), x[j]);
+            p8_lds_store(plo, phi, p8_reg_slot<F, LOGW>(slot0, pbase, c, j), x[j]);
         } else {
             Fr v = x[j];
             if (have_outmul) v = fe_mul(v, outmul[j]); // inter-pass twiddle (column pass) / post-scale table (row pass), fetched steps ago
@@ -316,20 +326,21 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p8s
     int c0, pb0, ql0, c1, pb1, ql1;
     p8s_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
     p8s_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
+    const int s0 = p8_addr(pb0, c0, LOGW), s1 = p8_addr(pb1, c1, LOGW);
     if (T > 0) __syncthreads(); // everybody has taken the high halves of the previous exchange out of the buffer
 #pragma unroll
-    for (int j = 0; j < 8; j++) buf[p8_addr(pb0 | (j << F0), c0, LOGW)] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
+    for (int j = 0; j < 8; j++) buf[p8_reg_slot<F0, LOGW>(s0, pb0, c0, j)] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
     __syncthreads();
     uint4 lo[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) lo[j] = buf[p8_addr(pb1 | (j << F1), c1, LOGW)];
+    for (int j = 0; j < 8; j++) lo[j] = buf[p8_reg_slot<F1, LOGW>(s1, pb1, c1, j)];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; j++) buf[p8_addr(pb0 | (j << F0), c0, LOGW)] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
+    for (int j = 0; j < 8; j++) buf[p8_reg_slot<F0, LOGW>(s0, pb0, c0, j)] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint4 h = buf[p8_addr(pb1 | (j << F1), c1, LOGW)];
+        const uint4 h = buf[p8_reg_slot<F1, LOGW>(s1, pb1, c1, j)];
         x[j].v[0] = lo[j].x; x[j].v[1] = lo[j].y; x[j].v[2] = lo[j].z; x[j].v[3] = lo[j].w;
         x[j].v[4] = h.x; x[j].v[5] = h.y; x[j].v[6] = h.z; x[j].v[7] = h.w;
     }
