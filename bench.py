@@ -312,6 +312,15 @@ def main():
         raise SystemExit(2)
 
     import torch
+    # Fewer devices than ranks on this node (a launcher started N ranks on a box with fewer GPUs): every rank sees the same counts and leaves
+    # before any rendezvous, rank 0 with a line that says why -- not a rank waiting in init_process_group for one that died in set_device.
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    ndev = torch.cuda.device_count()
+    if not one_device and world > 1 and ndev < local_world:
+        if rank == 0:
+            emit_error(args, world, "%d GPU(s) visible, %d ranks on this node (BBG_DIST_ONE_DEVICE=1 rehearses the N-rank path on one device)" % (ndev, local_world),
+                       visible_devices=ndev)
+        raise SystemExit(3)
     import __graft_entry__ as ge
     pkg = ge.load_package()
     import importlib

@@ -160,6 +160,15 @@ def test_bench_launches_its_own_ranks_and_always_leaves_a_line():
         # rank 1 never answers, rank 0 dies: after the grace period the parent stops rank 1 (SIGKILL to the group it started) and reports
         rc, line, el = run(["--gpus", "2"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="1", BBG_BENCH_GRACE_S="2")
         assert rc != 0 and "rank 0 exited with code 1" in line["error"] and line["exit_codes"] == [1, -9] and el < 60, (line, el)
+    if not torch.cuda.is_available():
+        # started by a launcher (WORLD_SIZE set) on a node with fewer devices than ranks: every rank leaves before any rendezvous, rank 0 with a line
+        for rank in (0, 1):
+            r = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-config5"], env=dict(base, WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", RANK=str(rank),
+                               LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+            assert r.returncode == 3 and len(lines) == (1 if rank == 0 else 0), (rank, r.returncode, lines)
+            if rank == 0:
+                assert "ranks on this node" in json.loads(lines[0])["error"]
     # nobody answers at all: the hard limit
     rc, line, el = run(["--gpus", "2", "--no-config5"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="0", BBG_BENCH_LAUNCH_TIMEOUT="4",
                        BBG_BENCH_GRACE_S="1")
