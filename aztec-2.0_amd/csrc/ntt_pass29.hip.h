@@ -22,9 +22,13 @@ namespace bbg {
 #ifndef BBG_NTT29_EXCH1
 #define BBG_NTT29_EXCH1 0
 #endif
-template <int TL> constexpr size_t p29_lds_bytes()
+#ifndef BBG_NTT29_EXCH1_MIN_LOGR
+#define BBG_NTT29_EXCH1_MIN_LOGR 0 // with BBG_NTT29_EXCH1: only the kernels of at least this log-radix (those that run two blocks per CU anyway)
+#endif
+constexpr bool p29_exch1(int logR) { return BBG_NTT29_EXCH1 && logR >= BBG_NTT29_EXCH1_MIN_LOGR; }
+template <int TL, int LOGR> constexpr size_t p29_lds_bytes()
 {
-    return BBG_NTT29_EXCH1 ? ((size_t)36 << TL) + NTT29_TABLE_WORDS * 4 : (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_TABLE_WORDS * 4;
+    return p29_exch1(LOGR) ? ((size_t)36 << TL) + NTT29_TABLE_WORDS * 4 : (size_t)p8_plane<TL>() * 16 + (size_t)p8_plane<TL>() * 4 + NTT29_TABLE_WORDS * 4;
 }
 __device__ __forceinline__ int p29_slot(int p, int c, int logW) // swizzled slot of tile element (p, c): a bijection of [0, tile)
 {
@@ -199,9 +203,10 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     p29_coords<LOGR, ROW, T, TL>(threadIdx.x, c0, pb0, ql0);
     p29_coords<LOGR, ROW, T + 1, TL>(threadIdx.x, c1, pb1, ql1);
     if (T > 0) __syncthreads(); // everybody has read the previous exchange's elements
+    const int e0 = p29_slot(pb0, c0, LOGW), e1 = p29_slot(pb1, c1, LOGW);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int a = p29_slot(pb0 | (j << F0), c0, LOGW);
+        const int a = ((1 << (F0 + LOGW)) % 128 == 0) ? e0 + (j << (F0 + LOGW)) : p29_slot(pb0 | (j << F0), c0, LOGW); // the swizzle sees bits 3..6 only
         lo[a] = make_uint4(x[j].v[0], x[j].v[1], x[j].v[2], x[j].v[3]);
         hi[a] = make_uint4(x[j].v[4], x[j].v[5], x[j].v[6], x[j].v[7]);
         top[a] = x[j].v[8];
@@ -209,7 +214,7 @@ template <int LOGR, bool ROW, int T, int TL> __device__ __forceinline__ void p29
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int a = p29_slot(pb1 | (j << F1), c1, LOGW);
+        const int a = ((1 << (F1 + LOGW)) % 128 == 0) ? e1 + (j << (F1 + LOGW)) : p29_slot(pb1 | (j << F1), c1, LOGW);
         const uint4 l = lo[a], h = hi[a];
         x[j].v[0] = l.x; x[j].v[1] = l.y; x[j].v[2] = l.z; x[j].v[3] = l.w;
         x[j].v[4] = h.x; x[j].v[5] = h.y; x[j].v[6] = h.z; x[j].v[7] = h.w;
@@ -228,18 +233,16 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
 {
     extern __shared__ uint4 lds[];
     BBG_NTT_SELECT_BATCH(p);
-#if BBG_NTT29_EXCH1
-    uint4* buf = lds;                  // limbs 0..3
-    uint4* bufhi = lds + (1 << TL);    // limbs 4..7
-    uint32_t* buf8 = reinterpret_cast<uint32_t*>(lds + (2 << TL)); // limb 8
-    uint32_t* red = buf8 + (1 << TL);
-#define P29_EXCHANGE(T) p29_exchange1<LOGR, ROW, T, TL>(x, buf, bufhi, buf8)
-#else
-    uint4* buf = lds;
-    uint32_t* buf8 = reinterpret_cast<uint32_t*>(lds + p8_plane<TL>());
-    uint32_t* red = buf8 + p8_plane<TL>(); // 16-byte aligned: p8_plane is a multiple of 4
-#define P29_EXCHANGE(T) p29_exchange<LOGR, ROW, T, TL>(x, buf, buf8)
-#endif
+    constexpr bool EX1 = p29_exch1(LOGR);
+    uint4* buf = lds;                                                                      // limbs 0..3 (single round) / the plane buffer
+    uint4* bufhi = lds + (1 << TL);                                                        // limbs 4..7 (single round only)
+    uint32_t* buf8 = reinterpret_cast<uint32_t*>(lds + (EX1 ? (2 << TL) : p8_plane<TL>())); // limb 8
+    uint32_t* red = buf8 + (EX1 ? (1 << TL) : p8_plane<TL>());                             // 16-byte aligned either way
+#define P29_EXCHANGE(T)                                                                      \
+    do {                                                                                   \
+        if constexpr (EX1) p29_exchange1<LOGR, ROW, T, TL>(x, buf, bufhi, buf8);           \
+        else p29_exchange<LOGR, ROW, T, TL>(x, buf, buf8);                                 \
+    } while (0)
     constexpr int NSTEPS = (LOGR + 2) / 3;
     constexpr int LOGW = TL - LOGR;
     if (threadIdx.x < NTT29_RED_ROWS) ntt29_fill_reduce_table(red, threadIdx.x);
@@ -374,14 +377,15 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
 
 template <int LOGR, int TL = P8_TILE_LOG> static void p29_launch(const PassParams& p, size_t tiles, hipStream_t st)
 {
-    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass29<LOGR, true, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
-    else hipLaunchKernelGGL((k_ntt_pass29<LOGR, false, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), p29_lds_bytes<TL>(), st, p);
+    constexpr size_t lds = p29_lds_bytes<TL, LOGR>();
+    if (p.row_pass) hipLaunchKernelGGL((k_ntt_pass29<LOGR, true, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), lds, st, p);
+    else hipLaunchKernelGGL((k_ntt_pass29<LOGR, false, TL>), dim3((unsigned)tiles, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(1 << (TL - 3)), lds, st, p);
 }
 template <int LOGR, int TL = P8_TILE_LOG> static hipError_t p29_attr()
 {
-    hipError_t e = hipFuncSetAttribute((const void*)k_ntt_pass29<LOGR, true, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p29_lds_bytes<TL>());
+    hipError_t e = hipFuncSetAttribute((const void*)k_ntt_pass29<LOGR, true, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p29_lds_bytes<TL, LOGR>()));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_ntt_pass29<LOGR, false, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p29_lds_bytes<TL>());
+    return hipFuncSetAttribute((const void*)k_ntt_pass29<LOGR, false, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p29_lds_bytes<TL, LOGR>()));
 }
 
 } // namespace bbg
