@@ -43,7 +43,7 @@ static std::mutex g_srs_mu;
 static std::set<bbg_srs*> g_live_srs;
 int permutation_grand_product(bbg_ctx* ctx, const void* const* d_wires, const void* const* d_sigmas, unsigned log2n, const uint64_t* challenges,
                               void* d_z, hipStream_t st);
-int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
+int poly_lincomb(bbg_ctx* ctx, const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
 int quotient_widget(bbg_ctx* ctx, int widget, const void* const* d_polys, unsigned log2_large, const uint64_t* challenges, void* d_quotient,
                     uint64_t* alpha_out, hipStream_t st);
 int msm_windows_for(int c);
@@ -145,6 +145,7 @@ void bbg_destroy(bbg_ctx* ctx)
         for (auto e : kv.second.stop) (void)hipEventDestroy(e);
     }
     for (auto& kv : ctx->dpv_consts) (void)hipFree(kv.second);
+    for (auto& kv : ctx->dpv_tables) (void)hipFree(kv.second);
     if (ctx->ntt_scratch) (void)hipFree(ctx->ntt_scratch);
     if (ctx->quot_setup) (void)hipFree(ctx->quot_setup);
     if (ctx->gp_totals) (void)hipFree(ctx->gp_totals);
@@ -265,6 +266,16 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         ctx->prover_early_cosets = value != 0;
         return BBG_OK;
     }
+    if (!strcmp(key, "poly_limbs29")) {
+        if (value != 0 && value != 1) { set_error("poly_limbs29: 0 or 1"); return BBG_E_INVALID; }
+        ctx->poly_limbs29 = (int)value;
+        return BBG_OK;
+    }
+    if (!strcmp(key, "prover_fused_divide")) {
+        if (value != 0 && value != 1) { set_error("prover_fused_divide: 0 or 1"); return BBG_E_INVALID; }
+        ctx->prover_fused_divide = (int)value;
+        return BBG_OK;
+    }
     if (!strcmp(key, "prover_tail_window")) {
         if (value != 0 && msm_width_slot((int)value) < 0) { set_error("prover_tail_window: 0 or a compiled window width"); return BBG_E_INVALID; }
         ctx->prover_tail_window = (int)value;
@@ -357,6 +368,7 @@ int bbg_memory_report(bbg_ctx* ctx, bbg_memory_info* out)
         out->ntt_tables += kv.second.bytes;
         out->ntt_domains++;
     }
+    for (const auto& kv : ctx->dpv_tables) out->ntt_tables += (size_t)32 << ((kv.first >> 8) & 0xff); // poly_dpv_table: one Fr per target-domain point
     out->msm_arena = ctx->msm.bytes;
     out->scratch = ctx->ntt_scratch_bytes + ctx->staging_bytes + ctx->poly_scratch_bytes + ctx->gp_totals_bytes + ctx->quot_setup_bytes +
                    ctx->dpv_consts.size() * (size_t)DPV_CONSTS_BYTES;
@@ -379,6 +391,8 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
         ctx->domains.clear();
         for (auto& kv : ctx->dpv_consts) (void)hipFree(kv.second);
         ctx->dpv_consts.clear();
+        for (auto& kv : ctx->dpv_tables) (void)hipFree(kv.second);
+        ctx->dpv_tables.clear();
         auto drop = [](void** buf, size_t* bytes) {
             if (*buf) (void)hipFree(*buf);
             *buf = nullptr;
@@ -976,7 +990,7 @@ int bbg_poly_linear_combination_device(bbg_ctx* ctx, const void* const* d_polys,
 {
     CHECK_CTX(ctx);
     std::lock_guard<std::mutex> lk(ctx->mu);
-    return poly_lincomb(d_polys, scalars, count, d_base, d_out, n, ctx->stream);
+    return poly_lincomb(ctx, d_polys, scalars, count, d_base, d_out, n, ctx->stream);
 }
 
 int bbg_permutation_grand_product_device(bbg_ctx* ctx, const void* const d_wires[4], const void* const d_sigmas[4], unsigned log2n,

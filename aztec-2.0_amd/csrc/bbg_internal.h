@@ -119,10 +119,13 @@ struct bbg_ctx {
     bool msm_accumulate_quad = true; // option "msm_accumulate_quad": small MSMs accumulate with four threads per lane segment (0 = one, A/B)
     bool msm_reduce_low_priority = true; // auxiliary stream created with the lowest priority (option "msm_reduce_priority" = 0 undoes it)
     std::map<uint32_t, void*> dpv_consts; // poly.hip: Z*_H division constants per (src, target, roots cut)
+    std::map<uint32_t, void*> dpv_tables; // poly.hip: the Z*_H divisor per target-domain point, same key (poly_dpv_table; the prover's round 4)
     void* gp_totals = nullptr;  // quotient.hip: grand-product thread totals
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    int poly_limbs29 = 1;            // option "poly_limbs29": linear combinations and evaluations of coefficient arrays on 9 x 29-bit limbs, four terms per reduction (poly29.hip.h); 0 = the 32-bit kernels (A/B)
+    int prover_fused_divide = 1;     // option "prover_fused_divide": round 4 divides by Z*_H inside the coset iFFT's first load (poly_dpv_table + ntt_coset_ifft_scaled) instead of a pass of its own; 0 = the separate pass (A/B)
     int prover_tail_window = 0;      // option "prover_tail_window" (A/B): window width of the commitments whose reduce phase ends a round (rounds 4 and 6: the host waits for them with the chip idle) -- fewer buckets, shorter tail, more windows; 0 = the automatic width
     bool prover_ntt_batch = true;    // option "prover_ntt_batch": the wires' iFFTs (round 1) and 4n coset forms of circuits up to 2^17 gates go through ONE launch set each (grid.y = wires) instead of one per wire (A/B)
     int prover_fail_round = 0;       // option "prover_fail_round" (tests only): the next bbg_prover_round<k> returns BBG_E_HIP once -- how the shim's fallback to the reference body is exercised
@@ -178,6 +181,10 @@ int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generat
             hipStream_t stream);
 int ntt_ifft_to(bbg_ctx* ctx, const void* d_in, void* d_out, unsigned log2n, hipStream_t stream);
 int ntt_ifft_to_batch(bbg_ctx* ctx, int count, const void* const* d_in, void* const* d_out, unsigned log2n, hipStream_t stream);
+constexpr int BBG_E_NOFUSE = -100; // internal: this domain's plan has no fused load; never returned through the C ABI
+// coset iFFT of a[i] * scale[i] (scale: 2^log2n Montgomery-form values), the product taken as the first pass loads a[i]; BBG_E_NOFUSE
+// when the domain's plan has no fused load (single-pass domains) -- the caller scales first and calls ntt_run
+int ntt_coset_ifft_scaled(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, const void* d_scale, hipStream_t stream);
 int ntt_coset_extend_batch(bbg_ctx* ctx, int count, const void* const* d_in, size_t n_in, void* const* d_out, unsigned log2n, hipStream_t stream);
 void ntt_free_domain(NttDomain& d);
 int ntt_coset_extend(bbg_ctx* ctx, const void* d_in, size_t n_in, void* d_out, unsigned log2n, hipStream_t stream);
@@ -190,6 +197,8 @@ int poly_binop(int op, const void* a, const void* b, void* r, size_t n, hipStrea
 int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* z, uint64_t* out, hipStream_t st);
 int poly_kate_opening(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, uint64_t* f_out, hipStream_t st);
 int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t roots_cut, hipStream_t st);
+// the divisor as a per-point table (cached per context); *table stays valid until bbg_memory_trim / bbg_destroy
+int poly_dpv_table(bbg_ctx* ctx, unsigned log2_src, unsigned log2_target, size_t roots_cut, const void** table, hipStream_t st);
 int ntt_scale_powers(bbg_ctx* ctx, void* d_a, size_t count, const uint64_t* start, const uint64_t* base, hipStream_t stream);
 int ntt_scale_geometric(bbg_ctx* ctx, void* d_a, size_t count, unsigned log2n, int which_base, uint64_t step, uint64_t e0, int mul_inv_log2,
                         hipStream_t st);

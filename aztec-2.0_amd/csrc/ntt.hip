@@ -854,6 +854,16 @@ int ntt_coset_extend_batch(bbg_ctx* ctx, int count, const void* const* d_in, siz
     return BBG_OK;
 }
 
+int ntt_coset_ifft_scaled(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, const void* d_scale, hipStream_t st)
+{
+    if (!d_coeffs || !d_scale || log2n > 28) { set_error("ntt_coset_ifft_scaled: bad argument"); return BBG_E_INVALID; }
+    NttDomain* dp = nullptr;
+    int rc = build_domain(ctx, log2n, &dp);
+    if (rc) return rc;
+    if (!can_fuse(*dp)) return BBG_E_NOFUSE;
+    return ntt_core(ctx, *dp, (Fr*)d_coeffs, (Fr*)d_coeffs, 1, (const Fr*)dp->coset_inv, st, (const Fr*)d_scale, (size_t)1 << log2n);
+}
+
 int ntt_run(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant,
             hipStream_t st)
 {

@@ -57,24 +57,7 @@ __global__ void __launch_bounds__(256) k_poly_lincomb(LinCombArgs a, const Fr* _
         fe_store<FrP>(out + i, acc);
     }
 }
-int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st)
-{
-    if (count > (size_t)LC_MAX) { set_error("bbg_poly_linear_combination_device: at most 32 terms per call"); return BBG_E_INVALID; }
-    if ((count && (!d_polys || !scalars)) || !d_out) { set_error("bbg_poly_linear_combination_device: null argument"); return BBG_E_INVALID; }
-    if (n == 0) return BBG_OK;
-    LinCombArgs a;
-    a.count = (int)count;
-    for (size_t k = 0; k < count; k++) {
-        if (!d_polys[k]) { set_error("bbg_poly_linear_combination_device: null polynomial"); return BBG_E_INVALID; }
-        a.polys[k] = (const Fr*)d_polys[k];
-        memcpy(&a.scalars[k], scalars + 4 * k, 32);
-    }
-    int grid = grid_for(n, 256);
-    if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(k_poly_lincomb, dim3(grid), dim3(256), 0, st, a, (const Fr*)d_base, (Fr*)d_out, n);
-    BBG_HIP(hipGetLastError());
-    return BBG_OK;
-}
+// (poly_lincomb, the host side, follows the kernels of poly29.hip.h below)
 
 // ---------------------------------------------------------------------------------------------- shared pieces
 constexpr int PV_E = 16;     // consecutive coefficients per thread (Kate quotient, division by Z*_H)
@@ -87,6 +70,7 @@ struct PolyScratch {
     Fr result;     // F(z)
     Fr tmp[8];
     Fr ztid[256];  // z^t, t < 256
+    Fr zmult[16];  // 32 z^(256 e), e < 16, canonical: the multipliers of chunk_eval29 (poly29.hip.h)
 };
 constexpr int DPV_MAX_EXT = 16, DPV_MAX_CUT = 8;
 struct DpvConsts {
@@ -176,7 +160,18 @@ static H mul(const H& a, const H& b) // a b / 2^256 mod p, canonical; a, b < 2^2
 struct Pow2Arg {
     Fr z;
     Fr pow2z[48];
+    Fr zmult[16];
 };
+// 32 a mod p, canonical, of a canonical a: five modular doublings (a < p < 2^254: 2 a fits the words)
+static hostfr::H times32(hostfr::H a)
+{
+    for (int d = 0; d < 5; d++) {
+        for (int i = 3; i > 0; i--) a.v[i] = (a.v[i] << 1) | (a.v[i - 1] >> 63);
+        a.v[0] <<= 1;
+        a = hostfr::canon(a);
+    }
+    return a;
+}
 static Pow2Arg host_pow2(const uint64_t* z_limbs, const uint64_t* mul_root) // mul_root (canonical, Montgomery form) or null
 {
     hostfr::H a;
@@ -189,9 +184,19 @@ static Pow2Arg host_pow2(const uint64_t* z_limbs, const uint64_t* mul_root) // m
     }
     Pow2Arg t;
     memcpy(&t.z, &a, 32);
+    hostfr::H z256 = a;
     for (int i = 0; i < 48; i++) {
         memcpy(&t.pow2z[i], &a, 32);
+        if (i == 8) z256 = a;
         a = hostfr::mul(a, a);
+    }
+    // 32 z^(256 e): e = 0 is 32 in Montgomery form = 32 * (2^256 mod p); FrP::ONE holds the latter
+    hostfr::H one;
+    memcpy(&one, FrP::ONE, 32);
+    hostfr::H m = times32(hostfr::canon(one));
+    for (int e = 0; e < 16; e++) {
+        memcpy(&t.zmult[e], &m, 32);
+        m = hostfr::mul(m, z256);
     }
     return t;
 }
@@ -199,6 +204,7 @@ __global__ void __launch_bounds__(256) k_poly_pow2(PolyScratch* s, const Pow2Arg
 {
     if (threadIdx.x == 0) s->z = t.z;
     if (threadIdx.x < 48) s->pow2z[threadIdx.x] = t.pow2z[threadIdx.x];
+    if (threadIdx.x < 16) s->zmult[threadIdx.x] = t.zmult[threadIdx.x];
     s->ztid[threadIdx.x] = fe_reduce_once(pow_from_table(t.pow2z, (uint64_t)threadIdx.x));
 }
 // LDS tree sum of one field element per thread (256 threads); result valid in thread 0
@@ -228,7 +234,7 @@ __device__ __forceinline__ Fr slice_horner(const Fr* __restrict__ c, size_t i0, 
 // ---------------------------------------------------------------------------------------------- evaluate
 // A block owns EV_CHUNK consecutive coefficients; lane t takes c[base + t + 256 e], e < 16 -- every load instruction of a wave
 // reads 2 KiB of consecutive memory -- and sums them by Horner in z^256; the lane results are weighted by z^t (table) and
-// tree-summed, the block result by z^base.  One product per coefficient: multiplier and HBM are balanced.
+// tree-summed; the block results are weighted by z^base where they are added up (k_eval_final / k_multi_eval_final).  One product per coefficient: multiplier and HBM are balanced.
 __device__ __forceinline__ Fr chunk_eval(const Fr* __restrict__ c, size_t n, size_t base, const PolyScratch* ps, Fr* sm)
 {
     const int tid = threadIdx.x;
@@ -241,9 +247,8 @@ __device__ __forceinline__ Fr chunk_eval(const Fr* __restrict__ c, size_t n, siz
         if (i < n) s = fe_add(s, fe_load<FrP>(c + i));
     }
     s = fe_mul(s, ps->ztid[tid]);
-    s = block_sum(s, sm);
-    if (tid == 0) s = fe_mul(s, pow_from_table(ps->pow2z, base));
-    return s;
+    return block_sum(s, sm); // without z^base: the final kernels weight the blocks' sums, all at once, instead of one lane's chain of products per block
+
 }
 __global__ void __launch_bounds__(256) k_eval_partial(const Fr* __restrict__ c, size_t n, const PolyScratch* ps, Fr* partials)
 {
@@ -251,11 +256,11 @@ __global__ void __launch_bounds__(256) k_eval_partial(const Fr* __restrict__ c, 
     const Fr s = chunk_eval(c, n, (size_t)blockIdx.x * EV_CHUNK, ps, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-__global__ void __launch_bounds__(256) k_eval_final(const Fr* __restrict__ partials, size_t count, Fr* result)
+__global__ void __launch_bounds__(256) k_eval_final(const Fr* __restrict__ partials, size_t count, const PolyScratch* ps, Fr* result)
 {
     __shared__ Fr sm[128];
     Fr s = Fr::zero();
-    for (size_t i = threadIdx.x; i < count; i += 256) s = fe_add(s, partials[i]);
+    for (size_t i = threadIdx.x; i < count; i += 256) s = fe_add(s, fe_mul(partials[i], pow_from_table(ps->pow2z, i * EV_CHUNK)));
     s = block_sum(s, sm);
     if (threadIdx.x == 0) *result = fe_reduce_once(s);
 }
@@ -278,15 +283,52 @@ __global__ void __launch_bounds__(256) k_multi_eval_partial(MultiEvalArgs a, con
     const Fr s = chunk_eval(a.poly[k], a.len[k], base, ps + a.point[k], sm);
     if (threadIdx.x == 0) partials[k * a.stride + blockIdx.x] = s;
 }
-__global__ void __launch_bounds__(256) k_multi_eval_final(const Fr* __restrict__ partials, size_t stride, Fr* results)
+__global__ void __launch_bounds__(256) k_multi_eval_final(MultiEvalArgs a, const Fr* __restrict__ partials, const PolyScratch* ps, Fr* results)
 {
     __shared__ Fr sm[128];
-    const Fr* p = partials + (size_t)blockIdx.x * stride;
+    const Fr* p = partials + (size_t)blockIdx.x * a.stride;
+    const Fr* pow2z = ps[a.point[blockIdx.x]].pow2z;
+    const size_t blocks = (a.len[blockIdx.x] + EV_CHUNK - 1) / EV_CHUNK; // the partial sums beyond the polynomial's own blocks are zero
     Fr s = Fr::zero();
-    for (size_t i = threadIdx.x; i < stride; i += 256) s = fe_add(s, p[i]);
+    for (size_t i = threadIdx.x; i < blocks; i += 256) s = fe_add(s, fe_mul(p[i], pow_from_table(pow2z, i * EV_CHUNK)));
     s = block_sum(s, sm);
     if (threadIdx.x == 0) results[blockIdx.x] = fe_reduce_once(s);
 }
+
+} // namespace bbg
+#include "poly29.hip.h"
+namespace bbg {
+static void poly_lincomb_launch(bool limbs29, int grid, const LinCombArgs& a, const Fr* base, Fr* out, size_t n, hipStream_t st)
+{
+    if (limbs29) hipLaunchKernelGGL(p29::k_poly_lincomb29, dim3(grid), dim3(256), 0, st, a, base, out, n);
+    else hipLaunchKernelGGL(k_poly_lincomb, dim3(grid), dim3(256), 0, st, a, base, out, n);
+}
+int poly_lincomb(bbg_ctx* ctx, const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st)
+{
+    if (count > (size_t)LC_MAX) { set_error("bbg_poly_linear_combination_device: at most 32 terms per call"); return BBG_E_INVALID; }
+    if ((count && (!d_polys || !scalars)) || !d_out) { set_error("bbg_poly_linear_combination_device: null argument"); return BBG_E_INVALID; }
+    if (n == 0) return BBG_OK;
+    LinCombArgs a;
+    a.count = (int)count;
+    for (size_t k = 0; k < count; k++) {
+        if (!d_polys[k]) { set_error("bbg_poly_linear_combination_device: null polynomial"); return BBG_E_INVALID; }
+        a.polys[k] = (const Fr*)d_polys[k];
+        memcpy(&a.scalars[k], scalars + 4 * k, 32);
+        if (ctx->poly_limbs29) { // k_poly_lincomb29 takes 32 c_k, canonical (poly29.hip.h: Mult)
+            hostfr::H c;
+            memcpy(&c, scalars + 4 * k, 32);
+            c = times32(hostfr::canon(c));
+            memcpy(&a.scalars[k], &c, 32);
+        }
+    }
+    int grid = grid_for(n, 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (ctx->poly_limbs29 && grid > 1024) grid = 1024; // four blocks per CU, each element loop amortising the block's table and multiplier set-up
+    poly_lincomb_launch(ctx->poly_limbs29 != 0, grid, a, (const Fr*)d_base, (Fr*)d_out, n, st);
+    BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
 
 static Fr fr_from_host(const uint64_t* limbs)
 {
@@ -305,11 +347,12 @@ static int poly_setup(bbg_ctx* ctx, size_t n, const uint64_t* z, PolyHeader** hd
 }
 
 // F(z) into *d_result (device), asynchronous
-static void eval_async(const Fr* d_coeffs, size_t n, const PolyScratch* ps, Fr* partials, Fr* d_result, hipStream_t st)
+static void eval_async(bbg_ctx* ctx, const Fr* d_coeffs, size_t n, const PolyScratch* ps, Fr* partials, Fr* d_result, hipStream_t st)
 {
     const size_t blocks = (n + EV_CHUNK - 1) / EV_CHUNK;
-    hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, st, d_coeffs, n, ps, partials);
-    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, (const Fr*)partials, blocks ? blocks : 1, d_result);
+    if (ctx->poly_limbs29) hipLaunchKernelGGL(p29::k_eval_partial29, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, st, d_coeffs, n, ps, partials);
+    else hipLaunchKernelGGL(k_eval_partial, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, st, d_coeffs, n, ps, partials);
+    hipLaunchKernelGGL(k_eval_final, dim3(1), dim3(256), 0, st, (const Fr*)partials, blocks ? blocks : 1, ps, d_result);
 }
 
 int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* z, uint64_t* out, hipStream_t st)
@@ -320,7 +363,7 @@ int poly_evaluate(bbg_ctx* ctx, const void* d_coeffs, size_t n, const uint64_t* 
     size_t nblocks;
     int rc = poly_setup(ctx, n ? n : 1, z, &hdr, &partials, &nblocks, st);
     if (rc) return rc;
-    eval_async((const Fr*)d_coeffs, n, &hdr->ps[0], partials, &hdr->ps[0].result, st);
+    eval_async(ctx, (const Fr*)d_coeffs, n, &hdr->ps[0], partials, &hdr->ps[0].result, st);
     BBG_HIP(hipMemcpyAsync(out, &hdr->ps[0].result, 32, hipMemcpyDeviceToHost, st));
     BBG_HIP(hipStreamSynchronize(st));
     return BBG_OK;
@@ -358,8 +401,9 @@ int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* 
     if (rc) return rc;
     hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[0], host_pow2(zeta, nullptr));
     hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &hdr->ps[1], host_pow2(zeta, root));
-    hipLaunchKernelGGL(k_multi_eval_partial, dim3((unsigned)a.stride, (unsigned)count), dim3(256), 0, st, a, (const PolyScratch*)hdr->ps, partials);
-    hipLaunchKernelGGL(k_multi_eval_final, dim3((unsigned)count), dim3(256), 0, st, (const Fr*)partials, a.stride, hdr->results);
+    if (ctx->poly_limbs29) hipLaunchKernelGGL(p29::k_multi_eval_partial29, dim3((unsigned)a.stride, (unsigned)count), dim3(256), 0, st, a, (const PolyScratch*)hdr->ps, partials);
+    else hipLaunchKernelGGL(k_multi_eval_partial, dim3((unsigned)a.stride, (unsigned)count), dim3(256), 0, st, a, (const PolyScratch*)hdr->ps, partials);
+    hipLaunchKernelGGL(k_multi_eval_final, dim3((unsigned)count), dim3(256), 0, st, a, (const Fr*)partials, (const PolyScratch*)hdr->ps, hdr->results);
     BBG_HIP(hipGetLastError());
     *d_results = hdr->results;
     return BBG_OK;
@@ -464,7 +508,7 @@ int poly_kate_opening_async(bbg_ctx* ctx, const void* d_src, void* d_dest, size_
     PolyScratch* ps = &hdr->ps[0];
     Fr* carry = partials + nblocks + 1;
     // F(z)
-    eval_async((const Fr*)d_src, n, ps, partials, &ps->result, st);
+    eval_async(ctx, (const Fr*)d_src, n, ps, partials, &ps->result, st);
     if (d_f) BBG_HIP(hipMemcpyAsync(d_f, &ps->result, 32, hipMemcpyDeviceToDevice, st));
     // W(X)
     hipLaunchKernelGGL(k_kate_block_totals, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, n, ps, partials);
@@ -520,42 +564,92 @@ __global__ void __launch_bounds__(256) k_dpv_apply(Fr* evals, size_t n, const Dp
         x = fe_mul(x, w);
     }
 }
-int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t roots_cut, hipStream_t st)
+// the Z*_H division constants of (source domain, target domain, roots cut): `ext` inversions (0.34 ms of single-lane latency), computed once
+// per context and kept
+static int dpv_constants(bbg_ctx* ctx, unsigned log2_src, unsigned log2_target, size_t roots_cut, DpvConsts** out, void** target_consts, hipStream_t st)
 {
-    if (!d_evals || log2_target < log2_src || log2_target > 28 || log2_target - log2_src > 4 || roots_cut > DPV_MAX_CUT) {
+    if (log2_target < log2_src || log2_target > 28 || log2_target - log2_src > 4 || roots_cut > DPV_MAX_CUT) {
         set_error("bbg_divide_by_pseudo_vanishing: need src <= target <= 2^28, target/src <= 16, roots_cut <= 8");
         return BBG_E_INVALID;
     }
-    void *csrc, *ctgt, *cext;
+    void *csrc, *cext;
     int rc = ntt_domain_consts(ctx, log2_src, &csrc);
-    if (!rc) rc = ntt_domain_consts(ctx, log2_target, &ctgt);
+    if (!rc) rc = ntt_domain_consts(ctx, log2_target, target_consts);
     if (!rc) rc = ntt_domain_consts(ctx, log2_target - log2_src, &cext);
     if (rc) return rc;
-    // The constants depend on (source domain, target domain, roots cut) only and cost `ext` Fermat inversions (0.34 ms of single-lane
-    // latency in the middle of every proof's round 4): computed once per context and kept.
     const uint32_t key = (log2_src << 16) | (log2_target << 8) | (uint32_t)roots_cut;
     const int ext = 1 << (log2_target - log2_src);
-    const size_t n = (size_t)1 << log2_target;
-    DpvConsts* dc = nullptr;
     auto it = ctx->dpv_consts.find(key);
     if (it != ctx->dpv_consts.end()) {
-        dc = (DpvConsts*)it->second;
-    } else {
-        // built on the stream of THIS call and completed before the pointer is published: a later call on any other stream can use the
-        // cached constants without an ordering of its own, and a failed set-up leaves no entry behind (one-off, once per key)
-        BBG_HIP(hipMalloc((void**)&dc, sizeof(DpvConsts)));
-        hipLaunchKernelGGL(k_dpv_setup, dim3(1), dim3(64), 0, st, dc, (const DomainConsts*)csrc, (const DomainConsts*)cext, (int)log2_src, ext, (int)roots_cut);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) {
-            (void)hipFree(dc);
-            return hip_fail(e, "k_dpv_setup", __FILE__, __LINE__);
-        }
-        ctx->dpv_consts[key] = dc;
+        *out = (DpvConsts*)it->second;
+        return BBG_OK;
     }
+    // built on the stream of THIS call and completed before the pointer is published: a later call on any other stream can use the
+    // cached constants without an ordering of its own, and a failed set-up leaves no entry behind (one-off, once per key)
+    DpvConsts* dc = nullptr;
+    BBG_HIP(hipMalloc((void**)&dc, sizeof(DpvConsts)));
+    hipLaunchKernelGGL(k_dpv_setup, dim3(1), dim3(64), 0, st, dc, (const DomainConsts*)csrc, (const DomainConsts*)cext, (int)log2_src, ext, (int)roots_cut);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(dc);
+        return hip_fail(e, "k_dpv_setup", __FILE__, __LINE__);
+    }
+    ctx->dpv_consts[key] = dc;
+    *out = dc;
+    return BBG_OK;
+}
+int poly_divide_pseudo_vanishing(bbg_ctx* ctx, void* d_evals, unsigned log2_src, unsigned log2_target, size_t roots_cut, hipStream_t st)
+{
+    if (!d_evals) { set_error("bbg_divide_by_pseudo_vanishing: null evaluations"); return BBG_E_INVALID; }
+    DpvConsts* dc = nullptr;
+    void* ctgt = nullptr;
+    int rc = dpv_constants(ctx, log2_src, log2_target, roots_cut, &dc, &ctgt, st);
+    if (rc) return rc;
+    const int ext = 1 << (log2_target - log2_src);
+    const size_t n = (size_t)1 << log2_target;
     hipLaunchKernelGGL(k_dpv_apply, dim3(grid_for((n + PV_E - 1) / PV_E, 256)), dim3(256), 0, st, (Fr*)d_evals, n, dc, (const DomainConsts*)ctgt, ext - 1,
                        (int)roots_cut);
     BBG_HIP(hipGetLastError());
+    return BBG_OK;
+}
+
+// The divisor itself as a table: entry i = inv_sub[i mod ext] * prod_k (g w^i + numer_k), what k_dpv_apply multiplies evaluation i by -- the
+// kernel run over an array of ones.  A prover divides the quotient's 4n evaluations and then takes them through a coset iFFT; with the table
+// the division rides on the transform's first load (ntt_coset_ifft_scaled) instead of a read-modify-write pass of its own: 2^22 evaluations,
+// 0.28 ms -> one more product per element inside an issue-bound pass.  32 bytes per evaluation (128 MiB for a 2^20-gate circuit), per
+// (source, target, cut), kept for the life of the context like the twiddle tables; bbg_memory_trim releases it.
+__global__ void __launch_bounds__(256) k_fill_one(Fr* out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) fe_store<FrP>(out + i, Fr::one());
+}
+int poly_dpv_table(bbg_ctx* ctx, unsigned log2_src, unsigned log2_target, size_t roots_cut, const void** table, hipStream_t st)
+{
+    const uint32_t key = (log2_src << 16) | (log2_target << 8) | (uint32_t)roots_cut;
+    auto it = ctx->dpv_tables.find(key);
+    if (it != ctx->dpv_tables.end()) {
+        *table = it->second;
+        return BBG_OK;
+    }
+    DpvConsts* dc = nullptr;
+    void* ctgt = nullptr;
+    int rc = dpv_constants(ctx, log2_src, log2_target, roots_cut, &dc, &ctgt, st);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log2_target;
+    Fr* t = nullptr;
+    BBG_HIP(hipMalloc((void**)&t, n * sizeof(Fr)));
+    hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, st, t, n);
+    hipLaunchKernelGGL(k_dpv_apply, dim3(grid_for((n + PV_E - 1) / PV_E, 256)), dim3(256), 0, st, t, n, dc, (const DomainConsts*)ctgt,
+                       (1 << (log2_target - log2_src)) - 1, (int)roots_cut);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st); // complete before the pointer is published (see dpv_constants)
+    if (e != hipSuccess) {
+        (void)hipFree(t);
+        return hip_fail(e, "poly_dpv_table", __FILE__, __LINE__);
+    }
+    ctx->dpv_tables[key] = t;
+    *table = t;
     return BBG_OK;
 }
 

@@ -31,7 +31,7 @@ int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const vo
 int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* lens, const int* shifted, size_t count, unsigned log2n,
                         const uint64_t* zeta, void** d_results, hipStream_t st);
 int poly_kate_opening_async(bbg_ctx* ctx, const void* d_src, void* d_dest, size_t n, const uint64_t* z, void* d_f, hipStream_t st);
-int poly_lincomb(const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
+int poly_lincomb(bbg_ctx* ctx, const void* const* d_polys, const uint64_t* scalars, size_t count, const void* d_base, void* d_out, size_t n, hipStream_t st);
 
 // out[j] = *c, j < count
 __global__ void k_fill_const(Fr* out, const Fr* c, size_t count)
@@ -515,8 +515,22 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
     const int* widgets = p->flavour == BBG_FLAVOUR_TURBO ? TURBO : p->flavour == BBG_FLAVOUR_MIMC ? MIMC : STANDARD;
     const int widget_count = p->flavour == BBG_FLAVOUR_TURBO ? 5 : p->flavour == BBG_FLAVOUR_MIMC ? 3 : 2;
     int rc = quotient_widgets_chain(p->ctx, widgets, widget_count, polys, p->log2n + 2, ch, p->quotient, nullptr, st);
-    if (!rc) rc = poly_divide_pseudo_vanishing(p->ctx, p->quotient, p->log2n, p->log2n + 2, 4, st);
-    if (!rc) rc = ntt_run(p->ctx, p->quotient, p->log2n + 2, BBG_COSET_IFFT, 0, nullptr, st);
+    // divide by Z*_H and back to coefficients (prover.cpp:337-341): the divisor is a fixed function of the point, so it is a table the
+    // coset iFFT multiplies by as it first loads each evaluation -- no read-modify-write pass of 4n evaluations for the division
+    bool divided = false;
+    if (!rc && p->ctx->prover_fused_divide) {
+        const void* divisor = nullptr;
+        rc = poly_dpv_table(p->ctx, p->log2n, p->log2n + 2, 4, &divisor, st);
+        if (!rc) {
+            rc = ntt_coset_ifft_scaled(p->ctx, p->quotient, p->log2n + 2, divisor, st);
+            if (rc == BBG_E_NOFUSE) rc = BBG_OK; // a single-pass domain: the separate pass below
+            else divided = true;
+        }
+    }
+    if (!rc && !divided) {
+        rc = poly_divide_pseudo_vanishing(p->ctx, p->quotient, p->log2n, p->log2n + 2, 4, st);
+        if (!rc) rc = ntt_run(p->ctx, p->quotient, p->log2n + 2, BBG_COSET_IFFT, 0, nullptr, st);
+    }
     // T_1 .. T_width: n coefficients each; t_high of StandardPLONK has n + 1 (compute_quotient_pre_commitment, prover.cpp:117-137)
     if (!rc) {
         const void* parts[4];
@@ -570,7 +584,7 @@ int bbg_prover_linearise(bbg_prover* p, size_t count, const int* ids, const uint
         int rc = coeff_poly(p, ids[k], &ptrs[k], &len);
         if (rc) return rc;
     }
-    int rc = poly_lincomb(ptrs, scalars, count, nullptr, p->linear, p->n, st);
+    int rc = poly_lincomb(p->ctx, ptrs, scalars, count, nullptr, p->linear, p->n, st);
     if (rc) return rc;
     const void* lin = p->linear;
     const size_t len = p->n;
@@ -608,7 +622,7 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
         if (rc) return rc;
     }
     // F(X) = t_low(X) + sum_k scalar_k P_k(X)   (kate_commitment_scheme.cpp:216-222)
-    int rc = poly_lincomb(ptrs, scalars_zeta, count_zeta, p->quotient, p->tmp, n, st);
+    int rc = poly_lincomb(p->ctx, ptrs, scalars_zeta, count_zeta, p->quotient, p->tmp, n, st);
     if (rc) return rc;
     size_t f_len = n;
     if (p->width == 3) { // F[n] = zeta^(2n) t[3n]: the opening polynomial of StandardPLONK has n + 1 coefficients (:196-205, :42)
@@ -625,7 +639,7 @@ int bbg_prover_round6(bbg_prover* p, size_t count_zeta, const int* ids_zeta, con
         rc = coeff_poly(p, ids_omega[k], &ptrs[k], &len);
         if (rc) return rc;
     }
-    rc = poly_lincomb(ptrs, scalars_omega, count_omega, nullptr, p->tmp, n, st);
+    rc = poly_lincomb(p->ctx, ptrs, scalars_omega, count_omega, nullptr, p->tmp, n, st);
     if (!rc) rc = poly_kate_opening_async(p->ctx, p->tmp, p->opening[1], n, zeta_omega, nullptr, st);
     if (!rc && !together) rc = msm_run(p->ctx, p->srs->s, p->opening[1], 0, n, (char*)p->d_jac + 96, st);
     if (!rc && together) {

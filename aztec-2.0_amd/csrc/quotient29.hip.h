@@ -244,13 +244,16 @@ template <int WIDTH> __global__ void __launch_bounds__(256, BBG_Q29_OCC_PERM) k_
     fill_table(red);
     __syncthreads();
     const QuotientSetup& s = *a.s;
-    const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * PERM_CH;
+    // a block covers 256 * PERM_CH consecutive points, 256 at a time: the lanes of a wave read consecutive 32-byte values of each of the
+    // thirteen arrays (whole cache lines per instruction), a thread's next point is 256 further on and its beta g w^i is w^256 times the last
+    const uint32_t i0 = blockIdx.x * (256u * PERM_CH) + threadIdx.x;
     if (i0 > a.mask) return;
     Fr rb = fe_mul(s.beta_g, pow_from_table(a.dc->pow2_root, (uint64_t)i0)); // beta * g * w^i (words: [0, 2p))
-    const Fr root = a.dc->root;
+    const Fr root = a.dc->pow2_root[8];                                      // w^256
 #pragma unroll 1
     for (int e = 0; e < PERM_CH; e++) {
-        const uint32_t i = i0 + e, ish = (i + 4) & a.mask;
+        const uint32_t i = i0 + e * 256u, ish = (i + 4) & a.mask;
+        if (i > a.mask) break;
         const auto rb1 = ld<1>(rb);
         // factors of the numerator w_k + gamma + beta K_k X and of the denominator w_k + gamma + beta sigma_k: the first of each product
         // chain in class 0, the others in class 1 (a class-0 running product times a class-1 factor stays in class 0)

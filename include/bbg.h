@@ -374,6 +374,10 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
  * "msm_limbs29" (1 = the bucket accumulation's field arithmetic on 9 x 29-bit limbs, default; 0 = on 8 x 32-bit limbs, A/B),
  * "msm_acc_waves" (0 = automatic; N > 0 = lane segments per SIMD lane of the bucket accumulation, A/B), "msm_reduce_priority" (1 = low-priority reduce streams, default), "msm_upload_pieces" (1..4, default 1: pieces the host scalars of bbg_msm travel in),
  * "quotient_fuse" (1 = arithmetic + range + logic widgets of a chain in one pass, default),
+ * "poly_limbs29" (1 = bbg_poly_linear_combination*, bbg_poly_evaluate* and the prover's evaluations / linearisation / opening sums on 9 x 29-bit limbs
+ * with four terms per reduction, default; 0 = on 8 x 32-bit limbs, A/B),
+ * "prover_fused_divide" (1 = a bbg_prover's round 4 divides the quotient by Z*_H inside the coset iFFT's first load, from a per-point divisor table
+ * kept per context -- 32 bytes per point of the 4n domain, counted under ntt_tables -- default; 0 = a pass of its own, A/B),
  * "prover_tail_window" (A/B: window width of the commitments that end prover rounds 4 and 6, 0 = automatic, default; measured: no width beats it),
  * "prover_ntt_batch" (1 = the wires' iFFTs of round 1 and their 4n coset forms go through ONE launch set each -- grid.y = wires -- for circuits up to
  * 2^17 gates, where a single transform has at most 128 tiles for 256 CUs, default; 0 = one launch set per wire, A/B),

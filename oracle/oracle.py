@@ -532,6 +532,7 @@ class RefProver:
         L.refp_wrap_in_progress.restype = sz
         L.refp_construct_proof_rounds.argtypes = [vp, vp, vp]; L.refp_construct_proof_rounds.restype = ctypes.c_double
         L.refp_wrap_fail_round.argtypes = [cint]; L.refp_wrap_fail_round.restype = cint
+        L.refp_shim_option.argtypes = [ctypes.c_char_p, ctypes.c_long]; L.refp_shim_option.restype = cint
         L.refp_key_selector_scale3.argtypes = [vp, ctypes.c_char_p]; L.refp_key_selector_scale3.restype = cint
         L.refp_reset.argtypes = [vp]
         L.refp_new_flavour.argtypes = [cint, sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new_flavour.restype = vp
@@ -653,6 +654,11 @@ class RefProver:
     def wrap_reuploads(self):
         """Keys uploaded again because a cached proving key's host polynomials had changed."""
         return int(self.lib.refp_wrap_reuploads())
+
+    def shim_option(self, key, value):
+        """bbg_set_option on the context the linked shim proves with"""
+        if self.lib.refp_shim_option(key.encode(), int(value)) != 0:
+            raise RuntimeError(f"refp_shim_option({key}): refused, or not a shim-linked build")
 
     def wrap_fail_round(self, rnd):
         """The next resident prover round `rnd` fails once (library option prover_fail_round, tests only)."""

@@ -752,6 +752,12 @@ int refp_wrap_fail_round(int round)
     if (!bbg_shim_context || !bbg_set_option) return -1;
     return bbg_set_option(bbg_shim_context(), "prover_fail_round", round);
 }
+// any integer option of the library, on the context the shim proves with (A/B legs of the parity tests)
+int refp_shim_option(const char* key, long value)
+{
+    if (!bbg_shim_context || !bbg_set_option) return -1;
+    return bbg_set_option(bbg_shim_context(), key, value);
+}
 // What a host that rewrites a proving key AFTER proving with it does: selector `label` *= 3 in coefficient form, and its 4n coset form
 // recomputed from the new coefficients by the calls compute_proving_key makes (composer_base.cpp:200-210) -- in place, same buffers.
 int refp_key_selector_scale3(void* h, const char* label)

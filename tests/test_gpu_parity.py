@@ -937,6 +937,49 @@ def test_poly_linear_combination(pkg, oracle, bbg):
         bbg.poly_linear_combination_device([dev[0].data_ptr()] * 33, pkg.synthetic_scalars(1, 33), None, out.data_ptr(), n)
 
 
+@pytest.mark.parametrize("limbs29", [1, 0])
+def test_poly_linear_combination_every_term_count(pkg, oracle, bbg, limbs29):
+    """The 29-bit linear combination sums four terms per reduction with a tail of one to three (poly29.hip.h; option poly_limbs29, 0 = the
+    32-bit kernel): every tail length, the 32-term maximum, with and without a base, over inputs that include the largest canonical value
+    p - 1 and COARSE residues p + x (a device array may hold any representative below 2p) -- against the oracle's field operations.  The
+    evaluations (one and several polynomials) run under the same option at ragged lengths."""
+    import torch
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    n = 777
+    limbs = lambda v: [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    polys = [pkg.synthetic_scalars(800 + j, n) for j in range(32)]
+    for j, pl in enumerate(polys):
+        pl[j] = limbs(P - 1)                                  # canonical extreme (the arrays are R-form words: any value below p is one)
+        x = int.from_bytes(pl[j + 40].tobytes(), "little")
+        if x + P < (1 << 256) and x < P:
+            pl[j + 40] = limbs(x + P)                         # the same element, coarse representative
+    scal = pkg.synthetic_scalars(801, 32)
+    scal[5] = limbs(P - 1)
+    base = pkg.synthetic_scalars(802, n)
+    dev = [torch.from_numpy(p.view(np.int64).reshape(-1)).cuda() for p in polys]
+    dbase = torch.from_numpy(base.view(np.int64).reshape(-1)).cuda()
+    out = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+    bbg.set_option("poly_limbs29", limbs29)
+    try:
+        for k in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 25, 32):
+            for with_base in (True, False):
+                want = oracle.canon(0, base) if with_base else oracle.canon(0, np.zeros((n, 4), dtype=np.uint64))
+                for j in range(k):
+                    want = oracle.fe_add(0, want, oracle.fe_mul(0, oracle.canon(0, polys[j]), np.tile(scal[j], (n, 1))))
+                bbg.poly_linear_combination_device([d.data_ptr() for d in dev[:k]], scal[:k], dbase.data_ptr() if with_base else None, out.data_ptr(), n)
+                bbg.sync()
+                got = out.cpu().numpy().view(np.uint64).reshape(-1, 4)
+                assert np.array_equal(oracle.canon(0, got), want), (k, with_base)
+        kc = pkg.synthetic_scalars(803, 1)[0]
+        for m in (1, 255, 256, 257, 4095, 4096, 4097, 12289, 70001):
+            a_np = pkg.synthetic_scalars(804 + m % 89, m)
+            a_np[m // 2] = limbs(P - 1)
+            a = torch.from_numpy(a_np.view(np.int64).reshape(-1)).cuda()
+            assert np.array_equal(bbg.poly_evaluate_device(a.data_ptr(), m, kc), oracle.poly_eval(oracle.canon(0, a_np), kc)), m
+    finally:
+        bbg.set_option("poly_limbs29", 1)
+
+
 def test_round_kernel_error_paths(pkg, bbg):
     import torch
     buf = torch.zeros(64 * 4, dtype=torch.int64, device="cuda")
@@ -1542,6 +1585,33 @@ def test_resident_prover_with_every_turbo_widget_active(pkg, oracle, bbg, log2_g
     B.free()
 
 
+@pytest.mark.parametrize("flavour,log2_gates", [(0, 8), (0, 13), (1, 13), (3, 14)])
+def test_resident_prover_divides_the_quotient_either_way(pkg, oracle, bbg, flavour, log2_gates):
+    """Round 4 divides the quotient's 4n evaluations by Z*_H (prover.cpp:337, polynomial_arithmetic.cpp:680-720) either inside the
+    coset iFFT's first load, from a per-point divisor table (option prover_fused_divide = 1, the default -- the legs of every other
+    prover test), or in a pass of its own (0): the same proof bytes as the reference CPU prover both ways (n = 2^8: the 4n domain is a
+    single-pass transform with no fused load, the separate pass runs under either setting)."""
+    from oracle.oracle import RefProver, prover_available, PROVER_GPU_SO
+    if not prover_available() or not os.path.exists(PROVER_GPU_SO):
+        pytest.skip("oracle/_ref/libbbprover_gpu.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << log2_gates) + 2)
+    A = RefProver(1 << log2_gates, 41 + flavour, pts, x, flavour=flavour)
+    proof_cpu, blind = A.prove_recording()
+    assert A.verify() == 1
+    proofs = {}
+    for fused in (0, 1, 0):
+        B = RefProver(1 << log2_gates, 41 + flavour, pts, x, gpu_linked=True, flavour=flavour)
+        B.shim_option("prover_fused_divide", fused)
+        try:
+            proofs[fused], _ = B.prove_resident(blind)
+            assert B.verify() == 1
+        finally:
+            B.shim_option("prover_fused_divide", 1)
+            B.free()
+        assert proofs[fused] == proof_cpu, f"fused_divide = {fused}: proof differs from the reference CPU proof (flavour {flavour}, n = {A.n})"
+    A.free()
+
+
 @pytest.mark.parametrize("flavour", [0, 1, 2, 3, 4])
 def test_reference_provers_linked_against_shim(pkg, oracle, bbg, flavour):
     """INTEGRATION.md 2a for both composers: TurboComposer::create_prover (turbo_composer.cpp:727) and
@@ -1982,6 +2052,37 @@ def test_quotient_fused_widgets_equal_separate(pkg, bbg):
     assert np.array_equal(fused32, fused) and np.array_equal(separate32, fused)
     lib.bbg_prover_destroy(h)
     srs.free()
+
+
+def test_prover_round4_divisor_table_accounting(pkg):
+    """The per-point Z*_H divisor table of round 4 (option prover_fused_divide, poly.hip poly_dpv_table): on a context of its own, the
+    quotient commitments T_i are the same with the division inside the coset iFFT's load and in a pass of its own; the table -- 32 bytes
+    per point of the 4n domain -- is counted under ntt_tables once, reused by the next proof, and released by bbg_memory_trim."""
+    ctx = pkg.Bbg(0)
+    lib = ctx.lib
+    lg, n = 12, 1 << 12
+    srs = ctx.srs_synth_hashed(5, n)
+    gens = np.stack([ctx.field_op(0, 5, np.array([[k, 0, 0, 0]], dtype=np.uint64))[0] for k in (5, 5, 6, 7)])
+    h = ctypes.c_void_p()
+    assert lib.bbg_prover_create(ctx.ctx, srs.handle, lg, 4, gens.ctypes.data, ctypes.byref(h)) == 0
+    for pid in range(5, 20):
+        assert lib.bbg_prover_set_key_poly(h, pid, 0, pkg.synthetic_scalars(500 + pid, n).ctypes.data) == 0
+    assert lib.bbg_prover_finalize_key(h) == 0
+    ctx.set_option("prover_fused_divide", 0)
+    separate = _prover_rounds_1_to_4(pkg, ctx, lib, h, n)
+    before = ctx.memory_report()["ntt_tables"]
+    ctx.set_option("prover_fused_divide", 1)
+    fused = _prover_rounds_1_to_4(pkg, ctx, lib, h, n)
+    assert np.array_equal(fused, separate)
+    after = ctx.memory_report()["ntt_tables"]
+    assert after - before == 32 * 4 * n
+    assert np.array_equal(_prover_rounds_1_to_4(pkg, ctx, lib, h, n, seed=3), _prover_rounds_1_to_4(pkg, ctx, lib, h, n, seed=3))
+    assert ctx.memory_report()["ntt_tables"] == after
+    lib.bbg_prover_destroy(h)
+    ctx.memory_trim(tables=True)
+    assert ctx.memory_report()["ntt_tables"] == 0
+    srs.free()
+    ctx.close()
 
 
 def test_prover_keeps_its_srs_alive(pkg, bbg):
