@@ -638,7 +638,12 @@ int poly_dpv_table(bbg_ctx* ctx, unsigned log2_src, unsigned log2_target, size_t
     if (rc) return rc;
     const size_t n = (size_t)1 << log2_target;
     Fr* t = nullptr;
-    BBG_HIP(hipMalloc((void**)&t, n * sizeof(Fr)));
+    const hipError_t me = hipMalloc((void**)&t, n * sizeof(Fr));
+    if (me == hipErrorOutOfMemory) { // not an error of the proof: the caller divides in a pass of its own
+        (void)hipGetLastError();
+        return BBG_E_NOMEM;
+    }
+    BBG_HIP(me);
     hipLaunchKernelGGL(k_fill_one, dim3(grid_for(n, 256)), dim3(256), 0, st, t, n);
     hipLaunchKernelGGL(k_dpv_apply, dim3(grid_for((n + PV_E - 1) / PV_E, 256)), dim3(256), 0, st, t, n, dc, (const DomainConsts*)ctgt,
                        (1 << (log2_target - log2_src)) - 1, (int)roots_cut);

@@ -521,7 +521,8 @@ int bbg_prover_round4(bbg_prover* p, const uint64_t alpha[4], const uint64_t pub
     if (!rc && p->ctx->prover_fused_divide) {
         const void* divisor = nullptr;
         rc = poly_dpv_table(p->ctx, p->log2n, p->log2n + 2, 4, &divisor, st);
-        if (!rc) {
+        if (rc == BBG_E_NOMEM) rc = BBG_OK; // no room for the table (32 bytes per point of the 4n domain): the separate pass below
+        else if (!rc) {
             rc = ntt_coset_ifft_scaled(p->ctx, p->quotient, p->log2n + 2, divisor, st);
             if (rc == BBG_E_NOFUSE) rc = BBG_OK; // a single-pass domain: the separate pass below
             else divided = true;
