@@ -60,8 +60,11 @@ __global__ void __launch_bounds__(256) k_poly_lincomb(LinCombArgs a, const Fr* _
 // (poly_lincomb, the host side, follows the kernels of poly29.hip.h below)
 
 // ---------------------------------------------------------------------------------------------- shared pieces
-constexpr int PV_E = 16;     // consecutive coefficients per thread (Kate quotient, division by Z*_H)
-constexpr int PV_LOG_E = 4;
+constexpr int PV_E = 16;     // consecutive evaluations per thread of the division by Z*_H
+// Consecutive coefficients per thread of the Kate quotient, 2^LOG_E: 16 from 2^19 coefficients up, 8 from 2^17, 4 below -- a 2^16-coefficient
+// polynomial in slices of 16 is 64 waves for 1 024 SIMDs, each with a chain of 16 + 16 dependent products (r5: rounds 6 of a 2^16-gate proof
+// 0.747 -> 0.697 ms with slices of 4; at 2^20 the shorter slices LOSE, 92 -> 110 / 158 us per quotient: twice / four times the scan work)
+static int kate_log_e(size_t n) { return n >= ((size_t)1 << 19) ? 4 : n >= ((size_t)1 << 17) ? 3 : 2; }
 constexpr int EV_CHUNK = 4096; // coefficients per block of the evaluation kernels (256 threads x 16, lane-interleaved)
 constexpr int MEV_MAX = 32;    // polynomials per multi-evaluation call
 struct PolyScratch {
@@ -220,11 +223,11 @@ __device__ Fr block_sum(Fr v, Fr* sm)
     return v;
 }
 // S = sum_{e < E} c[i0 + e] z^e  (Horner from the top of the slice; coefficients beyond n count as zero)
-__device__ __forceinline__ Fr slice_horner(const Fr* __restrict__ c, size_t i0, size_t n, const Fr& z)
+template <int E> __device__ __forceinline__ Fr slice_horner(const Fr* __restrict__ c, size_t i0, size_t n, const Fr& z)
 {
     Fr s = Fr::zero();
 #pragma unroll 4
-    for (int e = PV_E - 1; e >= 0; e--) {
+    for (int e = E - 1; e >= 0; e--) {
         s = fe_mul(s, z);
         if (i0 + e < n) s = fe_add(s, fe_load<FrP>(c + i0 + e));
     }
@@ -339,7 +342,8 @@ static Fr fr_from_host(const uint64_t* limbs)
 static int poly_setup(bbg_ctx* ctx, size_t n, const uint64_t* z, PolyHeader** hdr, Fr** partials, size_t* nblocks, hipStream_t st)
 {
     // partial sums: one per EV_CHUNK coefficients (evaluation) and one per 256 slices (Kate block totals + carries)
-    *nblocks = ((n + PV_E - 1) / PV_E + 255) / 256;
+    const size_t slice = (size_t)1 << kate_log_e(n);
+    *nblocks = ((n + slice - 1) / slice + 255) / 256;
     int rc = poly_scratch(ctx, 2 * (*nblocks + 1), hdr, partials);
     if (rc) return rc;
     hipLaunchKernelGGL(k_poly_pow2, dim3(1), dim3(256), 0, st, &(*hdr)->ps[0], host_pow2(z, nullptr));
@@ -414,18 +418,19 @@ int poly_multi_evaluate(bbg_ctx* ctx, const void* const* d_polys, const size_t* 
 // same polynomial W(X) = (F(X) - F(z)) / (X - z) has the closed form  w_i = sum_{j > i} f_j z^(j-i-1)  (synthetic division
 // from the top), which is a suffix scan: T_t = S_t + z^E T_{t+1} over the per-thread slice sums S_t, first inside a
 // block (Hillis-Steele with multipliers z^(E 2^k)), then across blocks; each thread then unrolls its slice downwards.
-__global__ void __launch_bounds__(256) k_kate_block_totals(const Fr* __restrict__ f, size_t n, const PolyScratch* ps, Fr* totals)
+template <int LOG_E> __global__ void __launch_bounds__(256) k_kate_block_totals(const Fr* __restrict__ f, size_t n, const PolyScratch* ps, Fr* totals)
 {
+    constexpr int E = 1 << LOG_E;
     __shared__ Fr sm[128];
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t i0 = t * PV_E;
+    const size_t i0 = t * E;
     Fr s = Fr::zero();
-    if (i0 < n) s = fe_mul(slice_horner(f, i0, n, ps->pow2z[0]), pow_from_table(ps->pow2z, (uint64_t)threadIdx.x * PV_E));
+    if (i0 < n) s = fe_mul(slice_horner<E>(f, i0, n, ps->pow2z[0]), pow_from_table(ps->pow2z, (uint64_t)threadIdx.x * E));
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) totals[blockIdx.x] = s; // suffix evaluation of the block's 4096 coefficients from its first one
+    if (threadIdx.x == 0) totals[blockIdx.x] = s; // suffix evaluation of the block's B = 256 E coefficients from its first one
 }
-// carry[b] = sum_{u > b} totals[u] z^(4096 (u - b - 1))   (one block, blocks processed from the top in rounds of 256)
-__global__ void __launch_bounds__(256) k_kate_block_scan(const Fr* __restrict__ totals, size_t nblocks, const PolyScratch* ps, Fr* carry)
+// carry[b] = sum_{u > b} totals[u] z^(B (u - b - 1))   (one block, blocks processed from the top in rounds of 256)
+template <int LOG_E> __global__ void __launch_bounds__(256) k_kate_block_scan(const Fr* __restrict__ totals, size_t nblocks, const PolyScratch* ps, Fr* carry)
 {
     __shared__ Fr sm[256];
     __shared__ Fr incoming;
@@ -436,21 +441,21 @@ __global__ void __launch_bounds__(256) k_kate_block_scan(const Fr* __restrict__ 
     for (size_t r = rounds; r-- > 0;) {
         const size_t b = r * 256 + tid;
         Fr v = b < nblocks ? totals[b] : Fr::zero();
-        // inclusive suffix scan inside the round: G_b = v_b + z^4096 G_{b+1}
+        // inclusive suffix scan inside the round: G_b = v_b + z^B G_{b+1}
         sm[tid] = v;
         __syncthreads();
         for (int k = 0; k < 8; k++) {
             const int d = 1 << k;
             Fr add = Fr::zero();
-            if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[12 + k]);
+            if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[8 + LOG_E + k]);
             __syncthreads();
             v = fe_add(v, add);
             sm[tid] = v;
             __syncthreads();
         }
-        // plus the carry from the rounds above: z^(4096 (256 - tid)) * incoming
+        // plus the carry from the rounds above: z^(B (256 - tid)) * incoming
         const Fr inc = incoming;
-        Fr g = fe_add(v, fe_mul(inc, pow_from_table(ps->pow2z, (uint64_t)(256 - tid) << 12)));
+        Fr g = fe_add(v, fe_mul(inc, pow_from_table(ps->pow2z, (uint64_t)(256 - tid) << (8 + LOG_E))));
         // carry INTO block b is the suffix starting at block b+1
         __syncthreads();
         sm[tid] = g;
@@ -461,20 +466,21 @@ __global__ void __launch_bounds__(256) k_kate_block_scan(const Fr* __restrict__ 
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256) k_kate_finish(const Fr* __restrict__ f, Fr* dest, size_t n, const PolyScratch* ps, const Fr* __restrict__ carry)
+template <int LOG_E> __global__ void __launch_bounds__(256) k_kate_finish(const Fr* __restrict__ f, Fr* dest, size_t n, const PolyScratch* ps, const Fr* __restrict__ carry)
 {
+    constexpr int E = 1 << LOG_E;
     __shared__ Fr sm[256];
     const int tid = threadIdx.x;
     const size_t t = (size_t)blockIdx.x * 256 + tid;
-    const size_t i0 = t * PV_E;
+    const size_t i0 = t * E;
     const Fr z = ps->pow2z[0];
-    Fr v = i0 < n ? slice_horner(f, i0, n, z) : Fr::zero();
+    Fr v = i0 < n ? slice_horner<E>(f, i0, n, z) : Fr::zero();
     sm[tid] = v;
     __syncthreads();
     for (int k = 0; k < 8; k++) { // T_t = S_t + z^E T_{t+1} within the block
         const int d = 1 << k;
         Fr add = Fr::zero();
-        if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[PV_LOG_E + k]);
+        if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[LOG_E + k]);
         __syncthreads();
         v = fe_add(v, add);
         sm[tid] = v;
@@ -483,10 +489,10 @@ __global__ void __launch_bounds__(256) k_kate_finish(const Fr* __restrict__ f, F
     if (i0 >= n) return;
     // suffix evaluation starting at the NEXT slice: in-block part + the blocks above
     Fr T = (tid + 1 < 256) ? sm[tid + 1] : Fr::zero();
-    T = fe_add(T, fe_mul(carry[blockIdx.x], pow_from_table(ps->pow2z, (uint64_t)(255 - tid) * PV_E)));
+    T = fe_add(T, fe_mul(carry[blockIdx.x], pow_from_table(ps->pow2z, (uint64_t)(255 - tid) * E)));
     // w_{i0+E-1} = T ; w_{i-1} = f_i + z w_i
     Fr w = T;
-    for (int e = PV_E - 1; e >= 0; e--) {
+    for (int e = E - 1; e >= 0; e--) {
         const size_t i = i0 + e;
         if (i < n) {
             fe_store<FrP>(dest + i, fe_reduce_once(w));
@@ -511,9 +517,19 @@ int poly_kate_opening_async(bbg_ctx* ctx, const void* d_src, void* d_dest, size_
     eval_async(ctx, (const Fr*)d_src, n, ps, partials, &ps->result, st);
     if (d_f) BBG_HIP(hipMemcpyAsync(d_f, &ps->result, 32, hipMemcpyDeviceToDevice, st));
     // W(X)
-    hipLaunchKernelGGL(k_kate_block_totals, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, n, ps, partials);
-    hipLaunchKernelGGL(k_kate_block_scan, dim3(1), dim3(256), 0, st, partials, nblocks, ps, carry);
-    hipLaunchKernelGGL(k_kate_finish, dim3((unsigned)nblocks), dim3(256), 0, st, (const Fr*)d_src, (Fr*)d_dest, n, ps, carry);
+    const Fr* src = (const Fr*)d_src;
+    Fr* dest = (Fr*)d_dest;
+    const dim3 g((unsigned)nblocks), one(1), b(256);
+#define BBG_KATE(L)                                                                                \
+    hipLaunchKernelGGL(k_kate_block_totals<L>, g, b, 0, st, src, n, (const PolyScratch*)ps, partials);     \
+    hipLaunchKernelGGL(k_kate_block_scan<L>, one, b, 0, st, (const Fr*)partials, nblocks, (const PolyScratch*)ps, carry); \
+    hipLaunchKernelGGL(k_kate_finish<L>, g, b, 0, st, src, dest, n, (const PolyScratch*)ps, (const Fr*)carry);
+    switch (kate_log_e(n)) {
+    case 2: BBG_KATE(2) break;
+    case 3: BBG_KATE(3) break;
+    default: BBG_KATE(4) break;
+    }
+#undef BBG_KATE
     BBG_HIP(hipGetLastError());
     return BBG_OK;
 }

@@ -461,7 +461,9 @@ namespace bbg {
 //   k_gp_invert : one lane: (prod_all D)^-1  (a dependency chain -- 0.32 ms as a^(p-2), r4: binary extended Euclid --: the prover overlaps it with
 //                 the wires' coset FFTs)
 //   k_gp_apply  : z[j+1] *= (prefix of earlier blocks) * sd[j] * (suffix of later blocks) * inverse
-constexpr int GP_E = 4, GP_BLOCK_ROWS = 256 * GP_E;
+// Rows per thread of k_gp_terms: 4 from 2^18 rows up (fewer block totals, shorter scans per row), 1 below -- a 2^16-row grand product with four
+// rows per thread is 256 waves for 1 024 SIMDs, each with a chain of 4 x 15 + 24 dependent products (r5)
+static int gp_rows_per_thread(size_t n) { return n >= ((size_t)1 << 18) ? 4 : 1; }
 __device__ inline Fr fr_inverse(const Fr& a) { return fe_inverse_gcd<FrP, true>(a); } // field.hip.h: binary extended Euclid on the scalar unit (one lane, one input), canonical result
 struct GpArgs {
     const Fr* w[4];
@@ -470,14 +472,15 @@ struct GpArgs {
     Fr* sd;     // n entries: in-block exclusive suffix products of D
     Fr* bt;     // block tables: [0, B) N totals -> exclusive prefixes; [B, 2B) D totals -> exclusive suffixes; [2B] total of D; [2B+1] its inverse
     size_t n, nblocks;
+    size_t block_rows; // 256 x rows per thread
     const QuotientSetup* s; // beta, gamma, k1..k3
     const DomainConsts* dc; // small (n) domain
 };
-template <int WIDTH> __global__ void __launch_bounds__(256) k_gp_terms(GpArgs a)
+template <int WIDTH, int GP_E> __global__ void __launch_bounds__(256) k_gp_terms(GpArgs a)
 {
     __shared__ Fr smn[256], smd[256];
     const int tid = threadIdx.x;
-    const size_t j0 = (size_t)blockIdx.x * GP_BLOCK_ROWS + (size_t)tid * GP_E;
+    const size_t j0 = (size_t)blockIdx.x * (256 * GP_E) + (size_t)tid * GP_E;
     const QuotientSetup& s = *a.s;
     Fr num[GP_E], den[GP_E];
     Fr rb = fe_mul(s.beta, pow_from_table(a.dc->pow2_root, (uint64_t)j0)); // beta * w^j
@@ -598,7 +601,7 @@ __global__ void __launch_bounds__(256) k_gp_apply(GpArgs a)
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // row j -> z[j+1]
     if (j == 0) fe_store<FrP>(a.z, Fr::one());
     if (j + 1 >= a.n) return;
-    const size_t b = j / GP_BLOCK_ROWS;
+    const size_t b = j / a.block_rows;
     // per-block factor: (N of earlier blocks) * (D of later blocks) / (all D); 2 products per row is cheaper than another kernel
     const Fr f = fe_mul(fe_mul(fe_load<FrP>(a.bt + b), fe_load<FrP>(a.bt + a.nblocks + b)), fe_load<FrP>(a.bt + 2 * a.nblocks + 1));
     fe_store<FrP>(a.z + j + 1, fe_mul(fe_mul(fe_load<FrP>(a.z + j + 1), fe_load<FrP>(a.sd + j)), f));
@@ -630,7 +633,8 @@ static int gp_fill(bbg_ctx* ctx, int width, const void* const* d_wires, const vo
         a.sigma[k] = k < width ? (const Fr*)d_sigmas[k] : nullptr;
     }
     a.n = (size_t)1 << log2n;
-    a.nblocks = (a.n + GP_BLOCK_ROWS - 1) / GP_BLOCK_ROWS;
+    a.block_rows = (size_t)256 * gp_rows_per_thread(a.n);
+    a.nblocks = (a.n + a.block_rows - 1) / a.block_rows;
     int rc = ensure_buffer(&ctx->gp_totals, &ctx->gp_totals_bytes, (a.n + 2 * a.nblocks + 2) * sizeof(Fr));
     if (rc) return rc;
     a.sd = (Fr*)ctx->gp_totals;
@@ -662,8 +666,14 @@ int permutation_grand_product_begin(bbg_ctx* ctx, int width, const void* const* 
     hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, (QuotientSetup*)a.s, ch, (const Fr*)nullptr);
     {
         ProfScope ps(ctx, "grand_product", st);
-        if (width == 4) hipLaunchKernelGGL(k_gp_terms<4>, dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_gp_terms<3>, dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
+        const dim3 g((unsigned)a.nblocks), b(256);
+        if (a.block_rows == 256) {
+            if (width == 4) hipLaunchKernelGGL((k_gp_terms<4, 1>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((k_gp_terms<3, 1>), g, b, 0, st, a);
+        } else {
+            if (width == 4) hipLaunchKernelGGL((k_gp_terms<4, 4>), g, b, 0, st, a);
+            else hipLaunchKernelGGL((k_gp_terms<3, 4>), g, b, 0, st, a);
+        }
         hipLaunchKernelGGL(k_gp_blocks, dim3(1), dim3(256), 0, st, a.bt, a.nblocks);
     }
     if (inv_stream != st) {
@@ -720,8 +730,14 @@ static int launch_widget(bbg_ctx* ctx, int widget, const QuotientArgs& a, size_t
     ProfScope ps(ctx, "quotient_widget", st);
     if (ctx->quotient_limbs29) { // the 29-bit-limb kernels of quotient29.hip.h
         switch (widget) {
-        case 0: hipLaunchKernelGGL(q29::k_quotient29_permutation<4>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
-        case 5: hipLaunchKernelGGL(q29::k_quotient29_permutation<3>, dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a); break;
+        case 0:
+            if (m < ((size_t)1 << 20)) hipLaunchKernelGGL((q29::k_quotient29_permutation<4, 1>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((q29::k_quotient29_permutation<4, PERM_CH>), dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a);
+            break;
+        case 5:
+            if (m < ((size_t)1 << 20)) hipLaunchKernelGGL((q29::k_quotient29_permutation<3, 1>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((q29::k_quotient29_permutation<3, PERM_CH>), dim3((unsigned)((m / PERM_CH + 255) / 256)), dim3(256), 0, st, a);
+            break;
         case 2:
             hipLaunchKernelGGL(q29::k_quotient29_turbo_fixed_base_linear, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);
             hipLaunchKernelGGL(q29::k_quotient29_turbo_fixed_base_gate, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a);

@@ -238,20 +238,22 @@ __global__ void __launch_bounds__(256, BBG_Q29_OCC_FBG) k_quotient29_turbo_fixed
 }
 
 // permutation argument (k_quotient_permutation): ASSIGNS the quotient
-template <int WIDTH> __global__ void __launch_bounds__(256, BBG_Q29_OCC_PERM) k_quotient29_permutation(QuotientArgs a)
+// CH points per thread: PERM_CH from 2^20 points up; 1 below (a 2^18-point domain at four points per thread is one wave per SIMD with a chain of
+// 4 x 22 products; the chip has the lanes for a thread per point, and beta g w^i from the table costs what three more points would)
+template <int WIDTH, int CH> __global__ void __launch_bounds__(256, BBG_Q29_OCC_PERM) k_quotient29_permutation(QuotientArgs a)
 {
     __shared__ uint32_t red[NTT29_TABLE_WORDS];
     fill_table(red);
     __syncthreads();
     const QuotientSetup& s = *a.s;
-    // a block covers 256 * PERM_CH consecutive points, 256 at a time: the lanes of a wave read consecutive 32-byte values of each of the
+    // a block covers 256 * CH consecutive points, 256 at a time: the lanes of a wave read consecutive 32-byte values of each of the
     // thirteen arrays (whole cache lines per instruction), a thread's next point is 256 further on and its beta g w^i is w^256 times the last
-    const uint32_t i0 = blockIdx.x * (256u * PERM_CH) + threadIdx.x;
+    const uint32_t i0 = blockIdx.x * (256u * CH) + threadIdx.x;
     if (i0 > a.mask) return;
     Fr rb = fe_mul(s.beta_g, pow_from_table(a.dc->pow2_root, (uint64_t)i0)); // beta * g * w^i (words: [0, 2p))
     const Fr root = a.dc->pow2_root[8];                                      // w^256
 #pragma unroll 1
-    for (int e = 0; e < PERM_CH; e++) {
+    for (int e = 0; e < CH; e++) {
         const uint32_t i = i0 + e * 256u, ish = (i + 4) & a.mask;
         if (i > a.mask) break;
         const auto rb1 = ld<1>(rb);
