@@ -263,7 +263,13 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         return BBG_OK;
     }
     if (!strcmp(key, "prover_early_cosets")) {
-        ctx->prover_early_cosets = value != 0;
+        if (value < -1 || value > 1) { set_error("prover_early_cosets: -1 (automatic), 0 or 1"); return BBG_E_INVALID; }
+        ctx->prover_early_cosets = (int)value;
+        return BBG_OK;
+    }
+    if (!strcmp(key, "quotient_setup_plan")) {
+        if (value != 0 && value != 1) { set_error("quotient_setup_plan: 0 or 1"); return BBG_E_INVALID; }
+        ctx->quotient_setup_plan = (int)value;
         return BBG_OK;
     }
     if (!strcmp(key, "poly_limbs29")) {

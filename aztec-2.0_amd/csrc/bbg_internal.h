@@ -124,12 +124,13 @@ struct bbg_ctx {
     size_t gp_totals_bytes = 0;
     void* quot_setup = nullptr; // quotient.hip: derived challenges / constants
     size_t quot_setup_bytes = 0;
+    int quotient_setup_plan = 1;     // option "quotient_setup_plan": the widgets' set-up blocks by the lanes of one wave side by side (quotient.hip k_quotient_setup_plan); 0 = the one-lane chain (A/B)
     int poly_limbs29 = 1;            // option "poly_limbs29": linear combinations and evaluations of coefficient arrays on 9 x 29-bit limbs, four terms per reduction (poly29.hip.h); 0 = the 32-bit kernels (A/B)
     int prover_fused_divide = 1;     // option "prover_fused_divide": round 4 divides by Z*_H inside the coset iFFT's first load (poly_dpv_table + ntt_coset_ifft_scaled) instead of a pass of its own; 0 = the separate pass (A/B)
     int prover_tail_window = 0;      // option "prover_tail_window" (A/B): window width of the commitments whose reduce phase ends a round (rounds 4 and 6: the host waits for them with the chip idle) -- fewer buckets, shorter tail, more windows; 0 = the automatic width
     bool prover_ntt_batch = true;    // option "prover_ntt_batch": the wires' iFFTs (round 1) and 4n coset forms of circuits up to 2^17 gates go through ONE launch set each (grid.y = wires) instead of one per wire (A/B)
     int prover_fail_round = 0;       // option "prover_fail_round" (tests only): the next bbg_prover_round<k> returns BBG_E_HIP once -- how the shim's fallback to the reference body is exercised
-    bool prover_early_cosets = true; // option "prover_early_cosets": the wires' 4n coset forms are queued behind round 1's last commitment (beside its reduce phase) instead of in front of round 3's grand product
+    int prover_early_cosets = -1; // -1 = from 2^18 gates (default), 0 = never, 1 = always. option "prover_early_cosets": the wires' 4n coset forms are queued behind round 1's last commitment (beside its reduce phase) instead of in front of round 3's grand product
     int prover_msm_batch = 4; // option "prover_msm_batch": commitments of a prover round per launch set (0 / 1 = one each; prover.hip commit())
     bool quotient_limbs29 = true; // option "quotient_limbs29": permutation / fixed-base / fused arithmetic + range + logic widgets on lazily reduced 29-bit limbs (quotient29.hip.h; 0 = the 32-bit kernels, A/B)
     bool quotient_fuse = true; // option "quotient_fuse": arithmetic + range + logic widgets of a chain in one pass over the wires (0 = one kernel each, A/B)

@@ -444,7 +444,8 @@ template <int LOG_E> __global__ void __launch_bounds__(256) k_kate_block_scan(co
         // inclusive suffix scan inside the round: G_b = v_b + z^B G_{b+1}
         sm[tid] = v;
         __syncthreads();
-        for (int k = 0; k < 8; k++) {
+        const size_t live = nblocks - r * 256 < 256 ? nblocks - r * 256 : 256; // totals of this round; the rest are zeros: steps beyond them add nothing
+        for (int k = 0; k < 8 && ((size_t)1 << k) < live; k++) {
             const int d = 1 << k;
             Fr add = Fr::zero();
             if (tid + d < 256) add = fe_mul(sm[tid + d], ps->pow2z[8 + LOG_E + k]);

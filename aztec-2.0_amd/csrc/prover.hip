@@ -436,8 +436,11 @@ int bbg_prover_round1(bbg_prover* p, const uint64_t* const* wires_lagrange, uint
     }
     // The wires' values on the 4n coset (the FFT work items of round 3, prover.cpp:255-264) depend on nothing but the wires: queued here they
     // run beside the last commitment's accumulation and fill its reduce phase -- a chain of short kernels that leaves most of the chip idle at
-    // the end of the round -- instead of standing in front of round 3's grand product.
-    if (p->ctx->prover_early_cosets) {
+    // the end of the round -- instead of standing in front of round 3's grand product.  From 2^18 gates (option -1, automatic): below, the
+    // transforms beside the reduce chain slow that chain by more than they take in front of round 3, where they hide the grand product's
+    // single inversion (r5: a 2^16-gate proof 3.59 -> 3.51 ms, 2^17 5.13 -> 5.00; 2^18 and 2^19 level; 2^20 24.13 against 24.23 in front of round 3)
+    const int early = p->ctx->prover_early_cosets;
+    if (early > 0 || (early < 0 && p->log2n >= 18)) {
         int rc = wires_to_coset(p, st);
         if (rc) return rc;
         p->wire_cosets_seq = p->proof_seq;

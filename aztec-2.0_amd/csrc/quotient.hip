@@ -121,6 +121,121 @@ struct WidgetChain {
     int count;
     int widget[8];
 };
+// The same blocks with the lanes of one wave working side by side (r5).  Every value of the chain is alpha_base^(4^j) * alpha^e with (j, e)
+// known to the HOST from the widget list alone -- a permutation widget hands on base^4, the others base * alpha^r (update_alpha,
+// transition_widget.hpp:88-94) -- so block w's eight powers base_w * alpha^k are eight independent lanes: a shared table alpha^(2^b), one
+// power from it, one product.  The serial kernel above is a chain of ~ 90 dependent products on one lane (59 us: 3 % of a 2^12-gate proof);
+// here the longest chain is the table's squarings + one lane's power + two squarings: ~ 14 products.
+struct WidgetPlan {
+    int count;
+    uint32_t widgets; // 4 bits per block: the widget
+    uint32_t c4;      // 4 bits per block: j, the block's base is alpha_base^(4^j) * alpha^e
+    uint64_t e[2];    // 16 bits per block: e
+    int table_bits;   // alpha^(2^b) for b < table_bits (>= 2) covers every e + 7
+    int max_c4;
+};
+constexpr int PLAN_MAX_C4 = 4, PLAN_MAX_BITS = 16;
+__global__ void __launch_bounds__(64) k_quotient_setup_plan(QuotientSetup* setups, QuotientChallenges in, WidgetPlan plan)
+{
+    __shared__ Fr T[PLAN_MAX_BITS];  // alpha^(2^b)
+    __shared__ Fr C[PLAN_MAX_C4 + 1]; // alpha_base^(4^j)
+    const int lane = threadIdx.x;
+    const Fr alpha = in.v[1];
+    { // the same chains on every lane (uniform: no divergence), stored once
+        Fr t = alpha;
+        for (int b = 0; b < plan.table_bits; b++) {
+            if (lane == 0) T[b] = t;
+            t = fe_sqr(t);
+        }
+        Fr c = in.v[0];
+        for (int j = 0; j <= plan.max_c4; j++) {
+            if (lane == 0) C[j] = c;
+            if (j < plan.max_c4) c = fe_sqr(fe_sqr(c));
+        }
+    }
+    __syncthreads();
+    const int w = lane >> 3, k = lane & 7;
+    if (w >= plan.count) return;
+    QuotientSetup* s = setups + w;
+    const uint32_t e = (uint32_t)((w < 4 ? plan.e[0] >> (16 * w) : plan.e[1] >> (16 * (w - 4))) & 0xffff);
+    const Fr v = fe_mul(C[(plan.c4 >> (4 * w)) & 15], pow_from_table(T, (uint64_t)(e + k))); // base_w * alpha^k
+    if (k < 7) s->ap[k] = v;
+    switch (k) {
+    case 0: {
+        const Fr sq = fe_sqr(v);
+        s->alpha_base_sqr = sq;
+        const Fr q = fe_sqr(sq); // permutation: alpha_base^4 (permutation_widget_impl.hpp:419)
+        s->alpha_out[0] = q;
+        s->alpha_out[5] = q;
+        break;
+    }
+    case 1: {
+        s->alpha_out[6] = v; // standard arithmetic: 1 relation
+        s->alpha2 = T[1];
+        const Fr a3 = fe_mul(T[1], alpha);
+        s->alpha3x2 = fe_add(a3, a3);
+        break;
+    }
+    case 2:
+        s->alpha_out[1] = v; // arithmetic: 2 relations
+        s->alpha_out[7] = v; // MiMC: 2
+        s->beta_g = fe_mul(in.v[2], in.v[5]);
+        break;
+    case 3:
+        s->alpha = alpha;
+        s->beta = in.v[2];
+        s->gamma = in.v[3];
+        s->delta = in.v[4];
+        break;
+    case 4:
+        s->alpha_out[3] = v; // range: 4 relations
+        s->alpha_out[4] = v; // logic: 4
+        break;
+    case 5:
+        s->k1 = in.v[6];
+        s->k2 = in.v[7];
+        s->k3 = in.v[8];
+        s->one = Fr::one();
+        break;
+    case 6:
+        s->c2 = fr_small(2);
+        s->c3 = fr_small(3);
+        s->c6 = fr_small(6);
+        s->c7 = fr_small(7);
+        s->c17 = fr_small(17);
+        s->c81 = fr_small(81);
+        s->c83 = fr_small(83);
+        break;
+    default:
+        s->alpha_out[2] = v; // fixed base: 7 relations
+        break;
+    }
+}
+// (j, e) of every block of a widget list; false when a value leaves the plan's fields (the serial kernel then)
+static bool widget_plan(const int* widgets, int count, WidgetPlan& plan)
+{
+    static const int RELATIONS[WIDGET_COUNT] = { 0, 2, 7, 4, 4, 0, 1, 2 }; // alpha_out = base * alpha^r; widgets 0 and 5 hand on base^4
+    memset(&plan, 0, sizeof(plan));
+    plan.count = count;
+    uint64_t e = 0;
+    int j = 0, bits = 2;
+    for (int w = 0; w < count; w++) {
+        if (j > PLAN_MAX_C4 || e + 7 >= ((uint64_t)1 << PLAN_MAX_BITS)) return false;
+        plan.widgets |= (uint32_t)widgets[w] << (4 * w);
+        plan.c4 |= (uint32_t)j << (4 * w);
+        plan.e[w >> 2] |= e << (16 * (w & 3));
+        while ((e + 7) >> bits) bits++;
+        if (j > plan.max_c4) plan.max_c4 = j;
+        if (widgets[w] == 0 || widgets[w] == 5) {
+            j++;
+            e *= 4;
+        } else {
+            e += (uint64_t)RELATIONS[widgets[w]];
+        }
+    }
+    plan.table_bits = bits;
+    return count <= 8;
+}
 __global__ void k_quotient_setup_chain(QuotientSetup* setups, QuotientChallenges in, WidgetChain chain)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -476,6 +591,15 @@ struct GpArgs {
     const QuotientSetup* s; // beta, gamma, k1..k3
     const DomainConsts* dc; // small (n) domain
 };
+__global__ void k_gp_setup(QuotientSetup* s, QuotientChallenges in)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    s->beta = in.v[2];
+    s->gamma = in.v[3];
+    s->k1 = in.v[6];
+    s->k2 = in.v[7];
+    s->k3 = in.v[8];
+}
 template <int WIDTH, int GP_E> __global__ void __launch_bounds__(256) k_gp_terms(GpArgs a)
 {
     __shared__ Fr smn[256], smd[256];
@@ -564,7 +688,8 @@ __global__ void __launch_bounds__(256) k_gp_blocks(Fr* bt, size_t B)
     smn[tid] = vn;
     smd[tid] = vd;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
+    const int active = (int)((B + per - 1) / per); // threads that hold totals; the others hold ones: a scan step beyond them changes nothing
+    for (int d = 1; d < active; d <<= 1) {
         Fr xn = vn, xd = vd;
         if (tid >= d) xn = fe_mul(smn[tid - d], vn);
         if (tid + d < 256) xd = fe_mul(vd, smd[tid + d]);
@@ -657,13 +782,14 @@ int permutation_grand_product_begin(bbg_ctx* ctx, int width, const void* const* 
     GpArgs a;
     int rc = gp_fill(ctx, width, d_wires, d_sigmas, log2n, d_z, a);
     if (rc) return rc;
-    // same set-up kernel as the widgets: slots alpha_base, alpha, delta, g are unused here (zeros)
+    // the widgets' set-up block, of which the grand product reads beta, gamma, k1 .. k3 only: stored as they are (r5: the widgets' set-up
+    // kernel ran here, 30 products on one lane -- 19 us -- to derive powers of an alpha this round does not have)
     QuotientChallenges ch;
     memset(&ch, 0, sizeof(ch));
     memcpy(&ch.v[2], challenges, 32);          // beta
     memcpy(&ch.v[3], challenges + 4, 32);      // gamma
     memcpy(&ch.v[6], challenges + 8, 3 * 32);  // k1..k3
-    hipLaunchKernelGGL(k_quotient_setup, dim3(1), dim3(64), 0, st, (QuotientSetup*)a.s, ch, (const Fr*)nullptr);
+    hipLaunchKernelGGL(k_gp_setup, dim3(1), dim3(64), 0, st, (QuotientSetup*)a.s, ch);
     {
         ProfScope ps(ctx, "grand_product", st);
         const dim3 g((unsigned)a.nblocks), b(256);
@@ -809,10 +935,15 @@ int quotient_widgets_chain(bbg_ctx* ctx, const int* widgets, int count, const vo
     // them may run in any order and share passes: arithmetic + range + logic of a TurboPLONK chain go through the data once
     int pos_arith = -1, pos_range = -1, pos_logic = -1;
     {
-        WidgetChain chain;
-        chain.count = count;
-        for (int w = 0; w < 8; w++) chain.widget[w] = w < count ? widgets[w] : 0;
-        hipLaunchKernelGGL(k_quotient_setup_chain, dim3(1), dim3(64), 0, st, setups, ch, chain);
+        WidgetPlan plan;
+        if (ctx->quotient_setup_plan && widget_plan(widgets, count, plan)) {
+            hipLaunchKernelGGL(k_quotient_setup_plan, dim3(1), dim3(64), 0, st, setups, ch, plan);
+        } else {
+            WidgetChain chain;
+            chain.count = count;
+            for (int w = 0; w < 8; w++) chain.widget[w] = w < count ? widgets[w] : 0;
+            hipLaunchKernelGGL(k_quotient_setup_chain, dim3(1), dim3(64), 0, st, setups, ch, chain);
+        }
     }
     for (int w = 0; w < count; w++) {
         if (widgets[w] == 1 && pos_arith < 0) pos_arith = w;

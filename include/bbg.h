@@ -374,6 +374,8 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
  * "msm_limbs29" (1 = the bucket accumulation's field arithmetic on 9 x 29-bit limbs, default; 0 = on 8 x 32-bit limbs, A/B),
  * "msm_acc_waves" (0 = automatic; N > 0 = lane segments per SIMD lane of the bucket accumulation, A/B), "msm_reduce_priority" (1 = low-priority reduce streams, default), "msm_upload_pieces" (1..4, default 1: pieces the host scalars of bbg_msm travel in),
  * "quotient_fuse" (1 = arithmetic + range + logic widgets of a chain in one pass, default),
+ * "quotient_setup_plan" (1 = the challenge powers of a widget chain's set-up blocks are computed by the lanes of one wave side by side, default; 0 = one
+ * lane's chain of products, A/B),
  * "poly_limbs29" (1 = bbg_poly_linear_combination*, bbg_poly_evaluate* and the prover's evaluations / linearisation / opening sums on 9 x 29-bit limbs
  * with four terms per reduction, default; 0 = on 8 x 32-bit limbs, A/B),
  * "prover_fused_divide" (1 = a bbg_prover's round 4 divides the quotient by Z*_H inside the coset iFFT's first load, from a per-point divisor table
@@ -381,8 +383,8 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
  * "prover_tail_window" (A/B: window width of the commitments that end prover rounds 4 and 6, 0 = automatic, default; measured: no width beats it),
  * "prover_ntt_batch" (1 = the wires' iFFTs of round 1 and their 4n coset forms go through ONE launch set each -- grid.y = wires -- for circuits up to
  * 2^17 gates, where a single transform has at most 128 tiles for 256 CUs, default; 0 = one launch set per wire, A/B),
- * "prover_early_cosets" (1 = a bbg_prover queues the wires' 4n coset forms behind round 1's last commitment, beside its reduce phase, default; 0 = in
- * front of round 3's grand product, A/B),
+ * "prover_early_cosets" (1 = a bbg_prover queues the wires' 4n coset forms behind round 1's last commitment, beside its reduce phase; 0 = in
+ * front of round 3's grand product; -1 = the first from 2^18 gates, the second below, default),
  * "quotient_limbs29" (1 = the quotient widgets on lazily reduced 9 x 29-bit limbs with sums of products sharing one reduction, default; 0 = on 8 x 32-bit limbs, A/B),
  * "ntt_kernel" (2 = register-resident radix-8 passes, default; 1 = radix-2 in LDS),
  * "ntt_max_logr8" (6..11, max log-radix per radix-8 pass, default 10), "ntt_big_tile" (0 / 1 / 2: 4096-element tiles for 2^21 [default] / also 2^22),

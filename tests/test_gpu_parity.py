@@ -1090,14 +1090,15 @@ def _run_gpu_widgets(pkg, bbg, polys, log2_large, ch9, alpha0, widgets=(0, 1, 2,
         yield alpha_base, quot.cpu().numpy().view(np.uint64).reshape(-1, 4)
 
 
-@pytest.mark.parametrize("limbs29,coarse", [(1, False), (1, True), (0, False)])
+@pytest.mark.parametrize("limbs29,coarse,plan", [(1, False, 1), (1, True, 1), (0, False, 1), (1, False, 0)])
 @pytest.mark.parametrize("log2_large", [3, 5, 8, 13])
-def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large, limbs29, coarse):
+def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large, limbs29, coarse, plan):
     """All eight widgets against the oracle's restatement (itself pinned by the reference goldens / live reference proofs) on arbitrary
     challenge values -- public_input_delta, g, k1..k3 are NOT the transcript / field constants here -- and on the smallest legal domain.
     limbs29: the kernels on lazily reduced 29-bit limbs (quotient29.hip.h, default) or the 32-bit ones.  coarse: every input polynomial is
     handed over as x + p (the upper half of the [0, 2p) range the prover's coset FFTs fill): the largest values the compile-time bounds of
-    the 29-bit kernels are priced for."""
+    the 29-bit kernels are priced for.  plan: the set-up block's challenge powers by the lanes of a wave side by side (option
+    quotient_setup_plan, default) or by one lane's chain of products -- the alpha_base every widget hands on is checked either way."""
     m = 1 << log2_large
     polys = [pkg.synthetic_scalars(5000 + 31 * log2_large + k, m) for k in range(23)]
     ch9 = pkg.synthetic_scalars(6000 + log2_large, 9)
@@ -1116,6 +1117,7 @@ def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large, limbs29, coars
             return out
         gpu_polys = [plus_p(p) for p in polys]
     bbg.set_option("quotient_limbs29", limbs29)
+    bbg.set_option("quotient_setup_plan", plan)
     try:
         for widget, (alpha_out, q) in zip(order, _run_gpu_widgets(pkg, bbg, gpu_polys, log2_large, ch9, ch9[0], order)):
             ch = ch9.copy()
@@ -1126,6 +1128,7 @@ def test_quotient_widgets_vs_oracle(pkg, oracle, bbg, log2_large, limbs29, coars
             assert (q[:, 3] <= np.uint64(0x60c89ce5c2634053)).all(), widget  # every stored residue below 2p (top word of 2p = 0x60c89ce5c2634053)
     finally:
         bbg.set_option("quotient_limbs29", 1)
+        bbg.set_option("quotient_setup_plan", 1)
 
 
 def test_quotient_widgets_vs_reference_golden(pkg, oracle, bbg):
@@ -1602,11 +1605,15 @@ def test_resident_prover_divides_the_quotient_either_way(pkg, oracle, bbg, flavo
     for fused in (0, 1, 0):
         B = RefProver(1 << log2_gates, 41 + flavour, pts, x, gpu_linked=True, flavour=flavour)
         B.shim_option("prover_fused_divide", fused)
+        B.shim_option("quotient_setup_plan", fused)  # with it the one-lane chain of the widgets' set-up blocks (default: a wave's lanes side by side)
+        B.shim_option("prover_early_cosets", fused)  # and the wires' coset forms in front of round 3 / behind round 1 (default: by circuit size)
         try:
             proofs[fused], _ = B.prove_resident(blind)
             assert B.verify() == 1
         finally:
             B.shim_option("prover_fused_divide", 1)
+            B.shim_option("quotient_setup_plan", 1)
+            B.shim_option("prover_early_cosets", -1)
             B.free()
         assert proofs[fused] == proof_cpu, f"fused_divide = {fused}: proof differs from the reference CPU proof (flavour {flavour}, n = {A.n})"
     A.free()
