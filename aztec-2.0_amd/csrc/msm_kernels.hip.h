@@ -653,21 +653,82 @@ __device__ __forceinline__ void redo_push(const RedoQueue& rq, uint32_t b)
     if (atomicExch(rq.flags + (b - 1), 1u) == 0) rq.list[atomicAdd(rq.count, 1u)] = b;
 }
 
+// Finished runs are not converted where they end (some lane of a wave ends a run in most iterations: the ~270 instructions of the R'-form ->
+// R-form step and the store would be issued for a handful of active lanes nearly every time): a lane whose run ends PARKS the raw 4 x 9 limbs
+// and the destination in a per-wave LDS queue and goes on; when the queue cannot take the next round of runs -- and once at the end of the
+// segment -- the WHOLE wave converts and stores one queued run per lane (acc29_drain).  A segment's first entry starts its first run without an
+// addition (all lanes: no selects), its last run goes out from registers with every lane active.
+constexpr int ACC29_QCAP = 64; // queue entries per wave = lanes of one drain
+struct Acc29Queue {
+    uint4 limbs[9][ACC29_QCAP]; // planes: x 0-3, x 4-7, y 0-3, y 4-7, zz 0-3, zz 4-7, zzz 0-3, zzz 4-7, limb 8 of x | y | zz | zzz
+    uint4 meta[ACC29_QCAP];     // destination (64-bit address) | bucket number | 1 = the run holds points at infinity only
+};
+__device__ __forceinline__ void acc29_park(Acc29Queue& qu, uint32_t slot, const Xyzz29& a, Xyzz* dst, uint32_t bucket, bool empty)
+{
+    qu.limbs[0][slot] = make_uint4(a.x.v[0], a.x.v[1], a.x.v[2], a.x.v[3]);
+    qu.limbs[1][slot] = make_uint4(a.x.v[4], a.x.v[5], a.x.v[6], a.x.v[7]);
+    qu.limbs[2][slot] = make_uint4(a.y.v[0], a.y.v[1], a.y.v[2], a.y.v[3]);
+    qu.limbs[3][slot] = make_uint4(a.y.v[4], a.y.v[5], a.y.v[6], a.y.v[7]);
+    qu.limbs[4][slot] = make_uint4(a.zz.v[0], a.zz.v[1], a.zz.v[2], a.zz.v[3]);
+    qu.limbs[5][slot] = make_uint4(a.zz.v[4], a.zz.v[5], a.zz.v[6], a.zz.v[7]);
+    qu.limbs[6][slot] = make_uint4(a.zzz.v[0], a.zzz.v[1], a.zzz.v[2], a.zzz.v[3]);
+    qu.limbs[7][slot] = make_uint4(a.zzz.v[4], a.zzz.v[5], a.zzz.v[6], a.zzz.v[7]);
+    qu.limbs[8][slot] = make_uint4(a.x.v[8], a.y.v[8], a.zz.v[8], a.zzz.v[8]);
+    const uint64_t d = reinterpret_cast<uint64_t>(dst);
+    qu.meta[slot] = make_uint4((uint32_t)d, (uint32_t)(d >> 32), bucket, empty ? 1u : 0u);
+}
+__device__ __forceinline__ Fq29 acc29_coord(const uint4& lo, const uint4& hi, uint32_t top)
+{
+    Fq29 r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    r.v[8] = top;
+    return r;
+}
+// lanes [0, count) of the wave: one queued run each -> R-form words at its destination; a run that met P = +-acc (ZZ = 0 mod p) queues its bucket
+__device__ __forceinline__ void acc29_drain(const Acc29Queue& qu, uint32_t count, const uint32_t* div32, const RedoQueue& redo)
+{
+    const uint32_t l = threadIdx.x & 63;
+    if (l < count) {
+        const uint4 m = qu.meta[l];
+        const uint4 top = qu.limbs[8][l];
+        char* dst = reinterpret_cast<char*>((uint64_t)m.x | ((uint64_t)m.y << 32));
+        const bool empty = m.w != 0;
+        Fq o = f29_div32_to_fe(acc29_coord(qu.limbs[4][l], qu.limbs[5][l], top.z), div32);
+        const bool bad = fe_is_zero(o) && !empty;
+        if (empty) o = Fq::zero();
+        fe_store<FqP>(dst + 64, o);
+        o = f29_div32_to_fe(acc29_coord(qu.limbs[0][l], qu.limbs[1][l], top.x), div32);
+        if (empty) o = Fq::zero();
+        fe_store<FqP>(dst, o);
+        o = f29_div32_to_fe(acc29_coord(qu.limbs[2][l], qu.limbs[3][l], top.y), div32);
+        if (empty) o = Fq::zero();
+        fe_store<FqP>(dst + 32, o);
+        o = f29_div32_to_fe(acc29_coord(qu.limbs[6][l], qu.limbs[7][l], top.w), div32);
+        if (empty) o = Fq::zero();
+        fe_store<FqP>(dst + 96, o);
+        if (bad) redo_push(redo, m.z);
+    }
+}
+
 template <int C> __global__ void __launch_bounds__(256)
 k_accumulate29(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ offsets, const Affine* __restrict__ table,
                size_t n_srs, uint32_t seg, Xyzz* head, Xyzz* tail, Xyzz* buckets, RedoQueue redo, uint32_t nb)
 {
     const uint32_t MSM_BUCKETS = nb; // sets x 2^(C-1): every MSM of the batch has its own bucket set
     __shared__ __attribute__((aligned(16))) uint32_t div32[32 * DIV32_ROW]; // multiples of p for the R'-form -> R-form step at the end of a run
+    __shared__ Acc29Queue queues[4];
     if (threadIdx.x < 32) f29_fill_div32_table<FqP>(div32, threadIdx.x);
     __syncthreads();
+    Acc29Queue& qu = queues[threadIdx.x >> 6];
     const uint32_t total = offsets[MSM_BUCKETS + 1];
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t base = offsets[1];
     const uint64_t s64 = (uint64_t)base + (uint64_t)lane * seg;
-    if (s64 >= total) return;
-    const uint32_t s = (uint32_t)s64;
-    const uint32_t e = (total - s > seg) ? s + seg : total;
+    const bool active = s64 < total;
+    if (__ballot(active) == 0) return; // whole waves leave; a partly filled wave keeps its idle lanes for the drains
+    const uint32_t s = active ? (uint32_t)s64 : total - 1; // idle lanes: valid addresses, no iterations
+    const uint32_t len = !active ? 0u : (total - s > seg) ? seg : total - s;
     uint32_t lo = 1, hi = MSM_BUCKETS;
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) >> 1;
@@ -675,23 +736,32 @@ k_accumulate29(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ o
         else hi = mid - 1;
     }
     uint32_t cur = lo;
-    uint32_t cur_end = offsets[cur + 1];
-    bool first_run = true, empty = true;
-    Xyzz29 acc;
-#pragma unroll
-    for (int i = 0; i < 9; i++) acc.x.v[i] = acc.y.v[i] = acc.zz.v[i] = acc.zzz.v[i] = 0;
-    // the sum of a finished run -> head[lane] (the segment's first run), buckets[b - 1] (a run inside the segment) or tail[lane]
-    auto emit = [&](Xyzz* dst) {
-        Xyzz out;
-        if (empty) out = xyzz_inf(); // only points at infinity
-        else if (!xyzz29_finish(acc, out, div32)) redo_push(redo, cur);
-        xyzz_store(dst, out);
-    };
+    uint32_t cur_end = offsets[cur + 1]; // > s: no run ends at the segment's first entry
+    bool first_run = true;
     uint32_t v = vals[s];
     Affine p = load_entry_point<C>(table, n_srs, v);
-    for (uint32_t q = s; q < e; q++) {
-        if (q == cur_end) { // the run of bucket `cur` ended inside this segment
-            emit(first_run ? head + lane : buckets + (cur - 1));
+    // the first entry starts the first run
+    bool empty = aff_is_inf(p);
+    Xyzz29 acc = xyzz29_from_affine(aff29_from_table(p, (v >> 31) != 0));
+    if (len > 1) {
+        v = vals[s + 1];
+        p = load_entry_point<C>(table, n_srs, v);
+    }
+    const uint64_t below = (1ull << (threadIdx.x & 63)) - 1;
+    uint32_t parked = 0; // wave-uniform: runs waiting in the queue
+    for (uint32_t it = 1;; it++) {
+        const uint32_t q = s + it;
+        const bool last = it >= seg; // wave-uniform
+        const bool ends = !last && it < len && q == cur_end; // the run of bucket `cur` ended inside this segment
+        const uint64_t enders = __ballot(ends);
+        const uint32_t ne = (uint32_t)__popcll(enders);
+        if (last || parked + ne > (uint32_t)ACC29_QCAP) {
+            acc29_drain(qu, parked, div32, redo);
+            parked = 0;
+            if (last) break;
+        }
+        if (ends) {
+            acc29_park(qu, parked + (uint32_t)__popcll(enders & below), acc, first_run ? head + lane : buckets + (cur - 1), cur, empty);
             first_run = false;
             empty = true;
             do {
@@ -699,27 +769,36 @@ k_accumulate29(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ o
                 cur_end = offsets[cur + 1];
             } while (cur_end <= q); // skip empty buckets
         }
-        const uint32_t vc = v;
-        const Affine pc = p;
-        if (q + 1 < e) { // software prefetch of the next gather
-            v = vals[q + 1];
-            p = load_entry_point<C>(table, n_srs, v);
-        }
-        if (!aff_is_inf(pc)) {
-            const Aff29 pt = aff29_from_table(pc, (vc >> 31) != 0);
-            const Xyzz29 sum = xyzz29_madd(acc, pt);
-            const Xyzz29 start = xyzz29_from_affine(pt);
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                acc.x.v[i] = empty ? start.x.v[i] : sum.x.v[i];
-                acc.y.v[i] = empty ? start.y.v[i] : sum.y.v[i];
-                acc.zz.v[i] = empty ? start.zz.v[i] : sum.zz.v[i];
-                acc.zzz.v[i] = empty ? start.zzz.v[i] : sum.zzz.v[i];
+        parked += ne;
+        if (it < len) {
+            const uint32_t vc = v;
+            const Affine pc = p;
+            if (it + 1 < len) { // software prefetch of the next gather
+                v = vals[q + 1];
+                p = load_entry_point<C>(table, n_srs, v);
             }
-            empty = false;
+            if (!aff_is_inf(pc)) {
+                const Aff29 pt = aff29_from_table(pc, (vc >> 31) != 0);
+                const Xyzz29 sum = xyzz29_madd(acc, pt);
+                const Xyzz29 start = xyzz29_from_affine(pt);
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    acc.x.v[i] = empty ? start.x.v[i] : sum.x.v[i];
+                    acc.y.v[i] = empty ? start.y.v[i] : sum.y.v[i];
+                    acc.zz.v[i] = empty ? start.zz.v[i] : sum.zz.v[i];
+                    acc.zzz.v[i] = empty ? start.zzz.v[i] : sum.zzz.v[i];
+                }
+                empty = false;
+            }
         }
     }
-    emit(first_run ? head + lane : tail + lane);
+    // the segment's last run, straight from registers
+    if (active) {
+        Xyzz out;
+        if (empty) out = xyzz_inf(); // only points at infinity
+        else if (!xyzz29_finish(acc, out, div32)) redo_push(redo, cur);
+        xyzz_store(first_run ? head + lane : tail + lane, out);
+    }
 }
 
 // one block per queued bucket: the bucket's sum from its entries, complete formulas (grid-stride over the queue; empty in all but degenerate inputs)

@@ -2134,12 +2134,51 @@ class _Multi:
             self.h = None
 
 
+def _spread(pkg, G):
+    """Devices of a G-context group: context g on device g mod bbg_device_count().  On this pool's one-GPU boxes that is [0] * G (every
+    context on device 0, the form these tests have always run in); on a node with 2 / 4 / 8 GPUs the SAME tests put one context per GPU, so
+    the peer copies cross devices (hipMemcpyPeerAsync over xGMI, cross-device event waits) with no other change."""
+    count = pkg.load_library().bbg_device_count()
+    assert count >= 1
+    return [g % count for g in range(G)]
+
+
+def _distinct(pkg, limit=8):
+    """The largest power-of-two group of DISTINCT devices (RCCL needs one device per rank): [0] on a one-GPU box, [0 .. 7] on a full node."""
+    count = pkg.load_library().bbg_device_count()
+    G = 1
+    while G * 2 <= min(limit, count):
+        G *= 2
+    return list(range(G))
+
+
+def _shards_to_devices(a, devs):
+    """Residue class g of `a` on the device of context g (int64 view of the 4 x u64 limbs)."""
+    import torch
+    G = len(devs)
+    out = [torch.from_numpy(np.ascontiguousarray(a[g::G]).view(np.int64).reshape(-1)).to(f"cuda:{devs[g]}") for g in range(G)]
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    return out
+
+
+def _gather_shards(shards, n, G):
+    """Natural-order result from the resident form: shard r holds G runs, run t = A[t*m + r*len ...) (bbg_multi_ntt_device)."""
+    m, length = n // G, n // G // G
+    got = np.zeros((n, 4), dtype=np.uint64)
+    for r in range(G):
+        o = shards[r].cpu().numpy().view(np.uint64).reshape(G, length, 4) if G > 1 else shards[r].cpu().numpy().view(np.uint64).reshape(1, n, 4)
+        for t in range(G):
+            got[t * m + r * length: t * m + (r + 1) * length] = o[t]
+    return got
+
+
 @pytest.mark.parametrize("G", [1, 2, 3, 4, 8])
 def test_multi_msm_point_range_shards(pkg, oracle, bbg, golden, G):
-    """bbg_multi_msm with G contexts (all on device 0 here; one per GPU on a node): point-range shards + the g1 sum of the 96-byte
-    partials reproduce the single-context MSM, the oracle, the reference's recorded results, (from, range) sub-ranges that straddle
-    shard boundaries, and the empty MSM."""
-    M = _Multi(pkg, [0] * G)
+    """bbg_multi_msm with G contexts (context g on device g mod the device count: all on device 0 on a one-GPU box, one per GPU on a
+    node): point-range shards + the g1 sum of the 96-byte partials reproduce the single-context MSM, the oracle, the reference's recorded
+    results, (from, range) sub-ranges that straddle shard boundaries, and the empty MSM."""
+    M = _Multi(pkg, _spread(pkg, G))
     try:
         n = 1 << 16
         M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, 0xBB254, n))
@@ -2177,8 +2216,8 @@ def test_multi_msm_point_range_shards(pkg, oracle, bbg, golden, G):
 def test_multi_ntt_all_to_all(pkg, oracle, bbg, G, lg):
     """bbg_multi_ntt (host form) and bbg_multi_ntt_device (resident residue-class shards, peer-copy all-to-all, size-G DFT) for
     fft / ifft / coset_fft / coset_ifft against the oracle's whole transform."""
-    import torch
-    M = _Multi(pkg, [0] * G)
+    devs = _spread(pkg, G)
+    M = _Multi(pkg, devs)
     try:
         n = 1 << lg
         a = pkg.synthetic_scalars(3100 + lg + G, n)
@@ -2187,47 +2226,68 @@ def test_multi_ntt_all_to_all(pkg, oracle, bbg, G, lg):
             buf = a.copy()
             M.ck(M.lib.bbg_multi_ntt(M.h, buf.ctypes.data, lg, op))
             assert np.array_equal(oracle.canon(0, buf), want), (G, lg, op, "host form")
-            # resident form: shard g = residue class g; result in G runs per shard
-            m, length = n // G, n // G // G
-            shards = [torch.from_numpy(np.ascontiguousarray(a[g::G]).view(np.int64).reshape(-1)).cuda() for g in range(G)]
-            torch.cuda.synchronize()
+            # resident form: shard g = residue class g on context g's device; result in G runs per shard
+            shards = _shards_to_devices(a, devs)
             ptrs = (ctypes.c_void_p * G)(*[t.data_ptr() for t in shards])
             M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, op))
             M.ck(M.lib.bbg_multi_sync(M.h))
-            got = np.zeros((n, 4), dtype=np.uint64)
-            for r in range(G):
-                o = shards[r].cpu().numpy().view(np.uint64).reshape(G, length, 4) if G > 1 else shards[r].cpu().numpy().view(np.uint64).reshape(1, n, 4)
-                for t in range(G):
-                    got[t * m + r * length: t * m + (r + 1) * length] = o[t]
-            assert np.array_equal(oracle.canon(0, got), want), (G, lg, op, "resident form")
+            assert np.array_equal(oracle.canon(0, _gather_shards(shards, n, G)), want), (G, lg, op, "resident form")
         with pytest.raises(pkg.BbgError):
             M.ck(M.lib.bbg_multi_ntt(M.h, a.ctypes.data, lg, 4))  # only the four whole-domain transforms
     finally:
         M.close()
 
 
-def test_multi_msm_2_24_eight_shards_vs_reference(pkg, oracle, bbg):
-    """BASELINE config 5's MSM through the in-library split: G = 8 contexts (one per GPU on a node; all on device 0 here), 2^21-point
-    SRS shards, bbg_multi_msm over the 2^24 scalars of tests/golden/msm24.json -- equal to the REFERENCE's own sharded composition
-    (sixteen pippenger_unsafe + g1 sum, pippenger.cpp:27-31, c_bind.cpp:31-46) -- and a (from, range) call that straddles shards."""
+def _msm24_golden():
     with open(os.path.join(os.path.dirname(__file__), "golden", "msm24.json")) as f:
-        G24 = json.load(f)
+        return json.load(f)
+
+
+def _multi_msm_2_24(pkg, oracle, M, G24, straddle):
+    """The 2^24-term MSM of tests/golden/msm24.json through group M against the REFERENCE's own sharded composition (sixteen
+    pippenger_unsafe + g1 sum, pippenger.cpp:27-31, c_bind.cpp:31-46); `straddle`: also reference shards 3..4 as ONE (from, range) call."""
     n = 1 << G24["log2n"]
-    M = _Multi(pkg, [0] * 8)
-    try:
-        M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, G24["srs_seed"], n))
-        assert M.lib.bbg_multi_srs_num_points(M.h) == n
-        sc = pkg.synthetic_scalars(G24["scalar_seed"], n)
-        out = np.zeros(12, dtype=np.uint64)
-        M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
-        assert np.array_equal(oracle.jac_to_affine(out), unhex(G24["result"], 8)[0]), "G = 8 sharded 2^24 MSM differs from the reference"
-        # reference shards 3..4 as ONE call: crosses the boundary between contexts 1 and 2 (2^21 points each)
+    M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, G24["srs_seed"], n))
+    assert M.lib.bbg_multi_srs_num_points(M.h) == n
+    sc = pkg.synthetic_scalars(G24["scalar_seed"], n)
+    out = np.zeros(12, dtype=np.uint64)
+    M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
+    assert np.array_equal(oracle.jac_to_affine(out), unhex(G24["result"], 8)[0]), "sharded 2^24 MSM differs from the reference"
+    if straddle:
         recs = G24["shards"][3:5]
         lo, cnt = recs[0]["from"], recs[0]["n"] + recs[1]["n"]
         part = np.ascontiguousarray(sc[lo: lo + cnt])
         M.ck(M.lib.bbg_multi_msm(M.h, part.ctypes.data, lo, cnt, out.ctypes.data))
         want = oracle.g1_add(unhex(recs[0]["result"], 8)[0], unhex(recs[1]["result"], 8)[0])
         assert np.array_equal(oracle.jac_to_affine(out), want)
+
+
+def _multi_ntt_2_24(pkg, oracle, M, devs, ops=None):
+    """bbg_multi_ntt_device at 2^24 through group M (contexts on `devs`) against the REFERENCE digests of the whole transform."""
+    lg = 24
+    n = 1 << lg
+    G = len(devs)
+    recs = [r for r in _ntt_large_golden() if r["log2n"] == lg and (ops is None or r["op"] in ops)]
+    assert recs
+    a = pkg.synthetic_scalars(900 + lg, n)
+    for rec in recs:
+        shards = _shards_to_devices(a, devs)
+        ptrs = (ctypes.c_void_p * G)(*[t.data_ptr() for t in shards])
+        M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, rec["op"]))
+        M.ck(M.lib.bbg_multi_sync(M.h))
+        got = oracle.canon(0, _gather_shards(shards, n, G))
+        for i, want in rec["spots"].items():
+            assert np.array_equal(got[int(i)], unhex(want)[0]), (G, rec["op"], "spot", i)
+        assert sha(got) == rec["sha256"], (G, rec["op"])
+
+
+def test_multi_msm_2_24_eight_shards_vs_reference(pkg, oracle, bbg):
+    """BASELINE config 5's MSM through the in-library split: G = 8 contexts (context g on device g mod the device count: one per GPU on an
+    8-GPU node, all on device 0 on a one-GPU box), 2^21-point SRS shards, bbg_multi_msm over the 2^24 scalars of tests/golden/msm24.json
+    -- equal to the REFERENCE's own sharded composition -- and a (from, range) call that straddles the shards of contexts 1 and 2."""
+    M = _Multi(pkg, _spread(pkg, 8))
+    try:
+        _multi_msm_2_24(pkg, oracle, M, _msm24_golden(), straddle=True)
     finally:
         M.close()
 
@@ -2235,41 +2295,45 @@ def test_multi_msm_2_24_eight_shards_vs_reference(pkg, oracle, bbg):
 @pytest.mark.parametrize("G", [8, 2])
 def test_multi_ntt_2_24_vs_reference(pkg, oracle, bbg, G):
     """BASELINE config 5's transform through the in-library split (residue-class shards, all-to-all, size-G DFT) at 2^24 for fft / ifft /
-    coset_fft / coset_ifft against the REFERENCE digests of the whole transform (tests/golden/ntt_large.json)."""
-    import torch
-    lg = 24
-    n = 1 << lg
-    recs = [r for r in _ntt_large_golden() if r["log2n"] == lg]
-    a = pkg.synthetic_scalars(900 + lg, n)
-    M = _Multi(pkg, [0] * G)
+    coset_fft / coset_ifft against the REFERENCE digests of the whole transform (tests/golden/ntt_large.json).  Context g on device
+    g mod the device count (peer copies cross devices wherever the box has more than one)."""
+    devs = _spread(pkg, G)
+    M = _Multi(pkg, devs)
     try:
-        m, length = n // G, n // G // G
-        for rec in recs:
-            shards = [torch.from_numpy(np.ascontiguousarray(a[g::G]).view(np.int64).reshape(-1)).cuda() for g in range(G)]
-            torch.cuda.synchronize()
-            ptrs = (ctypes.c_void_p * G)(*[t.data_ptr() for t in shards])
-            M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, rec["op"]))
-            M.ck(M.lib.bbg_multi_sync(M.h))
-            got = np.zeros((n, 4), dtype=np.uint64)
-            for r in range(G):
-                o = shards[r].cpu().numpy().view(np.uint64).reshape(G, length, 4)
-                for t in range(G):
-                    got[t * m + r * length: t * m + (r + 1) * length] = o[t]
-            got = oracle.canon(0, got)
-            for i, want in rec["spots"].items():
-                assert np.array_equal(got[int(i)], unhex(want)[0]), (G, rec["op"], "spot", i)
-            assert sha(got) == rec["sha256"], (G, rec["op"])
+        _multi_ntt_2_24(pkg, oracle, M, devs)
+    finally:
+        M.close()
+
+
+def test_multi_config5_over_rccl_on_distinct_devices(pkg, oracle, bbg):
+    """BASELINE config 5 through the RCCL exchange (ncclCommInitAll over the group, ncclAllGather of the 96-byte partials, grouped
+    ncclSend / ncclRecv all-to-all) on the largest power-of-two group of DISTINCT devices the box has -- 8 ranks on a full node, where this
+    is the first place ncclCommInitAll(N > 1) and the inter-device all-to-all run; a group of one on this pool's boxes (rank 0 exchanging
+    with itself: the same calls) -- and the same group through peer copies.  2^24-term MSM against the reference's result, 2^24 fft and
+    coset_fft against the reference's digests."""
+    devs = _distinct(pkg)
+    M = _Multi(pkg, devs)
+    try:
+        assert M.lib.bbg_multi_count(M.h) == len(devs)
+        G24 = _msm24_golden()
+        for exchange in (1, 0):
+            M.ck(M.lib.bbg_multi_set_option(M.h, b"exchange", exchange))
+            _multi_msm_2_24(pkg, oracle, M, G24, straddle=False)
+            _multi_ntt_2_24(pkg, oracle, M, devs, ops=(FFT, COSET_FFT) if exchange == 0 else None)
     finally:
         M.close()
 
 
 def test_multi_rccl_exchange_backend(pkg, oracle, bbg):
     """bbg_multi_set_option("exchange", 1): the C++ RCCL back end (ncclCommInitAll, ncclAllGather of the 96-byte partials + group sum,
-    grouped ncclSend / ncclRecv for the all-to-all).  One GPU here, so the group has ONE context: with RCCL selected even that group goes
-    through the exchange (all-gather of one partial; every chunk sent to and received from rank 0 = itself), which exercises every RCCL
-    call the multi-GPU path makes.  Results against the oracle, and equal to the peer-copy back end.  Duplicate devices are refused."""
+    grouped ncclSend / ncclRecv for the all-to-all) over the largest power-of-two group of DISTINCT devices (_distinct: 8 ranks on a full
+    node).  On a one-GPU box the group has ONE context: with RCCL selected even that group goes through the exchange (all-gather of one
+    partial; every chunk sent to and received from rank 0 = itself), which exercises every RCCL call the multi-GPU path makes.  Results
+    against the oracle, and equal to the peer-copy back end.  Duplicate devices are refused."""
     import torch
-    M = _Multi(pkg, [0])
+    devs = _distinct(pkg)
+    Gd = len(devs)
+    M = _Multi(pkg, devs)
     try:
         n = 1 << 14
         M.ck(M.lib.bbg_multi_srs_synth_hashed(M.h, 0xBB254, n))
@@ -2290,12 +2354,11 @@ def test_multi_rccl_exchange_backend(pkg, oracle, bbg):
             buf = a.copy()
             M.ck(M.lib.bbg_multi_ntt(M.h, buf.ctypes.data, lg, op))
             assert np.array_equal(oracle.canon(0, buf), oracle.ntt(a, op)), op
-            shard = torch.from_numpy(a.view(np.int64).reshape(-1).copy()).cuda()
-            torch.cuda.synchronize()
-            ptrs = (ctypes.c_void_p * 1)(shard.data_ptr())
+            shards = _shards_to_devices(a, devs)
+            ptrs = (ctypes.c_void_p * Gd)(*[t.data_ptr() for t in shards])
             M.ck(M.lib.bbg_multi_ntt_device(M.h, ptrs, lg, op))
             M.ck(M.lib.bbg_multi_sync(M.h))
-            assert np.array_equal(oracle.canon(0, shard.cpu().numpy().view(np.uint64).reshape(-1, 4)), oracle.ntt(a, op)), op
+            assert np.array_equal(oracle.canon(0, _gather_shards(shards, 1 << lg, Gd)), oracle.ntt(a, op)), op
         M.ck(M.lib.bbg_multi_set_option(M.h, b"exchange", 0))
         M.ck(M.lib.bbg_multi_msm(M.h, sc.ctypes.data, 0, n, out.ctypes.data))
         assert np.array_equal(oracle.jac_to_affine(out), peer)
