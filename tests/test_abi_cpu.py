@@ -173,3 +173,49 @@ def test_bench_launches_its_own_ranks_and_always_leaves_a_line():
     rc, line, el = run(["--gpus", "2", "--no-config5"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="0", BBG_BENCH_LAUNCH_TIMEOUT="4",
                        BBG_BENCH_GRACE_S="1")
     assert rc != 0 and line["value"] is None and line["error"] and el < 60, (line, el)
+
+
+def test_bench_promotes_the_strong_scaling_workload_at_n_gt_1():
+    """bench.py --gpus N (N > 1): the line's headline is BASELINE config 5 -- ONE 2^24 MSM + ONE 2^24 coset NTT per step sharded over the N GPUs,
+    `scaling: "strong"` -- and the per-GPU 2^20 step (near-linear by construction: every rank owns its own points) moves under
+    extra.weak_scaling_step; at N = 1 the headline stays BASELINE.json's metric and the same series' first point is `strong_scaling`.
+    Checked on bench.promote_config5 with a recorded-shape line (no GPU); the one-device rehearsal under -m gpu checks the real line.
+    Reference precedent for the split: ecc/curves/bn254/scalar_multiplication/c_bind.cpp:31-46."""
+    import argparse
+    import copy
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(config5_log2n=24, log2n=20, steps=20, warmup=3)
+    base = {"metric": "BN254 G1 MSM Mscalar-mults/s (+ Fr NTT Gfield-ops/s in extra) at n=2^20", "value": 2900.0, "unit": "Mscalar-mults/s", "n_gpus": 4,
+            "steps": 20, "warmup": 3, "ms_per_step": 1.45, "scaling": "weak",
+            "config": {"workload": "per GPU and step: ...", "log2n": 20, "sharding": "point-range", "exchange": "RCCL (torch.distributed nccl)"},
+            "roofline": {"kernel": "k_accumulate29", "frac": 0.012}, "extra": {}}
+    c5 = {"n_gpus": 4, "msm_ms": 5.2, "ntt_ms": 0.6, "bit_exact_vs_reference": {"msm": True, "ntt": True},
+          "exchange": {"msm": "all_gather 4 x 96 B", "ntt": "all_to_all 96.0 MiB per rank"},
+          "timed": {"steps": 20, "warmup": 3, "blocks_ms": [120.0, 118.0, 119.0], "ms_per_step": 5.95, "value_mscalar_per_s": 2819.7,
+                    "ntt_gfield_ops_per_s": 101.5, "per_rank": {"points": 1 << 22, "msm_window_bits": 20, "msm_windows": 13,
+                                                                "accumulate_avg_launch_ms": 3.9, "phase_ms_per_step": {}}}}
+
+    class FakeDist:
+        def get_world_size(self): return 4
+        def get_backend(self): return "nccl"
+    out = copy.deepcopy(base)
+    bench.promote_config5(out, c5, args, 4, FakeDist(), False)
+    assert out["scaling"] == "strong" and out["value"] == 2819.7 and out["ms_per_step"] == 5.95
+    assert "config 5" in out["metric"] and "BASELINE config 5" in out["config"]["workload"] and out["config"]["log2n"] == 24
+    assert "nccl" in out["config"]["exchange"] and out["config"]["exchange"].endswith(": 4")
+    assert out["strong_scaling"]["value"] == out["value"] and out["strong_scaling"]["n_gpus"] == 4
+    weak = out["extra"]["weak_scaling_step"]
+    assert weak["value"] == 2900.0 and weak["scaling"] == "weak" and weak["roofline"]["frac"] == 0.012
+    r = out["roofline"]
+    assert r["algorithmic_bytes"] == 96.0 * (1 << 22) and abs(r["achieved"] - 96.0 * (1 << 22) / 3.9e-3 / 1e9) < 0.01 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # N = 1: nothing is promoted, the series' first point is recorded
+    one = copy.deepcopy(base)
+    one["n_gpus"] = 1
+    bench.promote_config5(one, dict(c5, n_gpus=1), args, 1, None, False)
+    assert one["scaling"] == "weak" and one["value"] == 2900.0 and one["strong_scaling"]["n_gpus"] == 1 and "weak_scaling_step" not in one["extra"]
+    # an extra that failed (guarded() returned an error) leaves the line as it was
+    bad = copy.deepcopy(base)
+    bench.promote_config5(bad, {"error": "timeout after 600 s"}, args, 4, FakeDist(), False)
+    assert bad == base
