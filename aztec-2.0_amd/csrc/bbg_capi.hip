@@ -292,6 +292,10 @@ int bbg_set_option(bbg_ctx* ctx, const char* key, long value)
         return BBG_OK;
     }
     if (!strcmp(key, "prover_fail_round")) { // tests only: the next call of this prover round (1, 3, 4, 5, 6) fails once, as a device error would
+        // fault injection is not an option of a production process: it exists only where the environment asked for test hooks when the
+        // process started (BBG_TEST_HOOKS=1, read once) -- a stray option string cannot make a proof fail (round-5 advisor finding)
+        static const bool hooks = [] { const char* e = getenv("BBG_TEST_HOOKS"); return e && e[0] == '1' && e[1] == 0; }();
+        if (!hooks) { set_error("bbg_set_option: prover_fail_round is a test hook (start the process with BBG_TEST_HOOKS=1)"); return BBG_E_INVALID; }
         ctx->prover_fail_round = (int)value;
         return BBG_OK;
     }

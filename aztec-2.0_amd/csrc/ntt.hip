@@ -753,7 +753,12 @@ static int ntt_core(bbg_ctx* ctx, NttDomain& d, const Fr* in, Fr* out, int inver
         if (post) hipLaunchKernelGGL(k_scale_table, dim3(1), dim3(64), 0, st, out, post, (size_t)1);
         return BBG_OK;
     }
-    if (d.passes == 1) return launch_pass(ctx, d, 0, inverse, in, out, post, st);
+    if (d.passes == 1) {
+        // a single-pass plan has no fused pre-scale and no zero-extended input: callers ask can_fuse() first; one that did not gets an error,
+        // not an unscaled transform that reads past in_count
+        if (pre != nullptr || in_count != ~(size_t)0) { set_error("ntt_core: this plan does not fuse a pre-scale table or a zero-extended input (can_fuse)"); return BBG_E_INVALID; }
+        return launch_pass(ctx, d, 0, inverse, in, out, post, st);
+    }
     int rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, n * sizeof(Fr));
     if (rc) return rc;
     Fr* scratch = (Fr*)ctx->ntt_scratch;
@@ -772,7 +777,10 @@ static int ntt_core_batch(bbg_ctx* ctx, NttDomain& d, int count, const Fr* const
     if (count == 1) return ntt_core(ctx, d, in[0], out[0], inverse, post, st, pre, pre_count, in_count);
     if (count < 1 || count > 4 || d.log2n == 0) { set_error("ntt_core_batch: 1 .. 4 transforms of a domain of at least two points"); return BBG_E_INVALID; }
     const size_t n = (size_t)1 << d.log2n;
-    if (d.passes == 1) return launch_pass(ctx, d, 0, inverse, nullptr, nullptr, post, st, nullptr, 0, ~(size_t)0, count, in, out);
+    if (d.passes == 1) {
+        if (pre != nullptr || in_count != ~(size_t)0) { set_error("ntt_core_batch: this plan does not fuse a pre-scale table or a zero-extended input (can_fuse)"); return BBG_E_INVALID; }
+        return launch_pass(ctx, d, 0, inverse, nullptr, nullptr, post, st, nullptr, 0, ~(size_t)0, count, in, out);
+    }
     int rc = ensure_buffer(&ctx->ntt_scratch, &ctx->ntt_scratch_bytes, (size_t)count * n * sizeof(Fr));
     if (rc) return rc;
     Fr* scratch[4] = { nullptr, nullptr, nullptr, nullptr };

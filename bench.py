@@ -344,7 +344,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     one_device = os.environ.get("BBG_DIST_ONE_DEVICE") == "1"  # rehearsal: every rank on device 0, gloo + host staging (parallel.HostStagedDist)
-    if os.environ.get("BBG_BENCH_TEST_HANG_RANK") == str(rank) and world > 1:  # tests only: a rank that never answers (the launcher's limits)
+    # tests only, and only where the environment asked for test hooks (BBG_TEST_HOOKS=1): a rank that never answers (the launcher's limits)
+    if os.environ.get("BBG_TEST_HOOKS") == "1" and os.environ.get("BBG_BENCH_TEST_HANG_RANK") == str(rank) and world > 1:
         time.sleep(3600)
     if one_device:
         local_rank = 0
@@ -598,6 +599,23 @@ def main():
         if "error" not in extra["host_path"] and "link_only_ms" in rp:  # the unmodified prover through the link-time shim (cpu_baseline.real_prover)
             extra["host_path"]["shim_linked_proof_ms"] = {"log2_gates": rp["log2_gates"], "msm_fft_wrapped_only": rp["link_only_ms"],
                                                           "construct_proof_wrapped_too": rp["wrapped_zero_edits_ms"], "reference_cpu": rp["cpu_ms"]}
+        # "scalar H2D copy and result D2H INCLUDED for the drop-in path, and also reported device-resident".  `value` is the
+        # device-resident figure; this object is the other one, in one place: what a caller of the reference signatures gets.
+        hp = extra["host_path"]
+        if "error" not in hp:
+            extra["dropin"] = {
+                "what": "the drop-in boundary's own numbers: host buffers in (pageable memory, PCIe) and out, one blocking call each -- what "
+                        "pippenger_unsafe() / ifft() / coset_fft() cost a host that links the shim; `value` above is the same MSM with scalars resident in HBM",
+                "msm_ms": hp["bbg_msm_ms"], "msm_mscalar_per_s": hp["msm_mscalar_per_s"], "log2n": lg,
+                "msm_vs_device_resident_step": round(hp["msm_mscalar_per_s"] / value, 3) if value else None,
+                "ifft_ms": hp["bbg_ntt_ifft_ms"], "coset_fft_n_to_4n_ms": hp["bbg_coset_fft_extend_4n_ms"],
+                # a whole proof at the two boundaries a host can link (INTEGRATION.md 2a / 2a'), measured in this run at the size cpu_baseline.real_prover ran ...
+                "proof_ms_this_run": hp.get("shim_linked_proof_ms"),
+                # ... and at BASELINE config 4's size as recorded on this hardware (2^20 gates takes a minute of circuit construction per run)
+                "proof_ms_2^20_gates_recorded": {"msm_fft_entry_points_wrapped_only": 1011.4, "construct_proof_wrapped_too": 27.23, "reference_cpu": 4802.6, "host_threads": 64,
+                                                  "source": "profiles/r04_real_prover.txt (same hardware, round 4; python bench.py --real-prover-log2 20 re-measures)"},
+                "prover_shaped_resident_ms": (extra.get("prover_shaped") or {}).get("proof_ms"),
+            }
     # ---- BASELINE config 5: ONE 2^24 MSM + ONE 2^24 coset NTT over the N GPUs (strong scaling: total work fixed as N grows)
     if not args.no_config5 and not stuck:
         srs.free()

@@ -534,6 +534,8 @@ class RefProver:
         L.refp_wrap_fail_round.argtypes = [cint]; L.refp_wrap_fail_round.restype = cint
         L.refp_shim_option.argtypes = [ctypes.c_char_p, ctypes.c_long]; L.refp_shim_option.restype = cint
         L.refp_key_selector_scale3.argtypes = [vp, ctypes.c_char_p]; L.refp_key_selector_scale3.restype = cint
+        if hasattr(L, "refp_key_selector_poke"):
+            L.refp_key_selector_poke.argtypes = [vp, ctypes.c_char_p, sz]; L.refp_key_selector_poke.restype = cint
         L.refp_reset.argtypes = [vp]
         L.refp_new_flavour.argtypes = [cint, sz, ctypes.c_uint64, vp, sz, vp]; L.refp_new_flavour.restype = vp
         L.refp_program_width.argtypes = [vp]; L.refp_program_width.restype = sz
@@ -669,6 +671,11 @@ class RefProver:
         """Rewrites selector `label` of this session's proving key in place (coefficients * 3, 4n coset form recomputed)."""
         if self.lib.refp_key_selector_scale3(self.h, label.encode()) != 0:
             raise RuntimeError("refp_key_selector_scale3 failed")
+
+    def key_selector_poke(self, label, index):
+        """ONE coefficient of selector `label` of this session's proving key += 1 (4n coset form recomputed)."""
+        if self.lib.refp_key_selector_poke(self.h, label.encode(), int(index)) != 0:
+            raise RuntimeError("refp_key_selector_poke failed")
 
     def resident_key_create(self):
         """bbg_shim::ResidentKey for this circuit's proving key (shim-linked build only); seconds."""

@@ -778,6 +778,26 @@ int refp_key_selector_scale3(void* h, const char* label)
     }
 }
 
+// The smallest rewrite a host can make: ONE coefficient of selector `label` (coefficient form) += 1, its 4n coset form recomputed as above.
+// `index` is chosen by the test to be a row the wrap's sampled fingerprint does not look at (shim/bbg_prover_wrap.cpp: key_fingerprint).
+int refp_key_selector_poke(void* h, const char* label, size_t index)
+{
+    try {
+        auto p = ((Session*)h)->view();
+        auto& key = *p.key;
+        polynomial& poly = key.constraint_selectors.at(label);
+        if (index >= key.n) return -2;
+        poly[index] += fr(1);
+        polynomial poly_fft(poly, key.n * 4 + 4);
+        poly_fft.coset_fft(key.large_domain);
+        polynomial& dst = key.constraint_selector_ffts.at(std::string(label) + "_fft");
+        for (size_t i = 0; i < key.n * 4 + 4 && i < dst.get_max_size(); i++) dst[i] = poly_fft[i];
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
 // io::read_transcript_g1 (srs/io.cpp:134-162), the reference's own transcript reader: out = degree x 8 limbs
 int refio_read_transcript_g1(const char* dir, size_t degree, uint64_t* out)
 {

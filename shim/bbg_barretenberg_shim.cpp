@@ -35,12 +35,14 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 #include <ecc/curves/bn254/scalar_multiplication/scalar_multiplication.hpp>
 #include <polynomials/evaluation_domain.hpp>
 #include <polynomials/polynomial_arithmetic.hpp>
 
 #include "../include/bbg.h"
+#include "bbg_shim_verify.hpp"
 
 namespace {
 using barretenberg::evaluation_domain;
@@ -57,6 +59,12 @@ using barretenberg::scalar_multiplication::pippenger_runtime_state;
 //               caller guarantees readable right now -- freed or unmapped memory is never probed) still matches; at most
 //               MAX_IMPLICIT of them are kept (least recently used goes first), and tables below MIN_CACHED_POINTS -- the
 //               verifier's per-proof element table, verifier.cpp:165-170 -- are uploaded, used and freed within the call.
+// The samples are only the quick look that spares a GPU call over an obviously dead entry.  What makes a cached table SAFE (round 6,
+// bbg_shim_verify.hpp): every entry keeps a 64-bit hash of each of its points, taken when the device copy was made, and every MSM over a
+// cached entry -- registered or implicit -- re-hashes ALL the points of the range it passes on host threads while the GPU computes; the
+// result is returned only if every point still hashes to what was recorded, otherwise the entry is dropped, the table uploaded again and
+// the MSM repeated.  One rewritten point anywhere in the range can therefore not produce a commitment over the stale copy.
+// (BBG_SHIM_VERIFY=sample: samples only, for hosts whose tables are immutable.)
 struct ShimState {
     static constexpr size_t MAX_IMPLICIT = 4, MIN_CACHED_POINTS = 4096, SAMPLES = 1024;
     std::mutex mu;
@@ -67,7 +75,36 @@ struct ShimState {
         bbg_srs* srs = nullptr;
         bool registered = false;
         uint64_t last_use = 0;
-        std::vector<std::pair<size_t, g1::affine_element>> samples; // implicit entries only
+        std::vector<std::pair<size_t, g1::affine_element>> samples; // the quick look
+        std::vector<uint64_t> point_hash;                           // full mode: one hash per point, of the memory the device copy was made from
+        static uint64_t hash_point(const g1::affine_element* base, size_t i)
+        {
+            return bbg_shim_verify::hash_words(reinterpret_cast<const uint64_t*>(&base[2 * i]), sizeof(g1::affine_element) / 8, (uint64_t)i);
+        }
+        void take_hashes()
+        {
+            point_hash.resize(n);
+            constexpr size_t CH = 4096;
+            bbg_shim_verify::parallel_chunks((n + CH - 1) / CH, [&](size_t k) {
+                for (size_t i = k * CH, e = std::min(n, i + CH); i < e; i++) point_hash[i] = hash_point(base, i);
+            });
+        }
+        // every point of [from, from + count) -- memory the current call passes -- still hashes to what was recorded
+        bool range_verifies(size_t from, size_t count) const
+        {
+            if (point_hash.size() != n || from > n || count > n - from) return false;
+            constexpr size_t CH = 4096;
+            std::atomic<bool> ok{ true };
+            bbg_shim_verify::parallel_chunks((count + CH - 1) / CH, [&](size_t k) {
+                if (!ok.load(std::memory_order_relaxed)) return;
+                for (size_t i = from + k * CH, e = std::min(from + count, i + CH); i < e; i++)
+                    if (hash_point(base, i) != point_hash[i]) {
+                        ok.store(false, std::memory_order_relaxed);
+                        return;
+                    }
+            });
+            return ok.load();
+        }
         // true iff at least one sample lies in [from, from + count) and all of those match the host table
         bool range_still_matches(size_t from, size_t count) const
         {
@@ -166,7 +203,27 @@ void take_samples(ShimState::Entry& e)
     const size_t step = e.n > ShimState::SAMPLES ? e.n / ShimState::SAMPLES : 1;
     for (size_t i = 0; i < e.n; i += step) e.samples.emplace_back(i, e.base[2 * i]);
     e.samples.emplace_back(e.n - 1, e.base[2 * (e.n - 1)]);
+    if (bbg_shim_verify::full_mode()) e.take_hashes();
 }
+// The full check of one call's range, on a host thread of its own (which fans out) while the GPU works on the call; joined before the call
+// returns -- also when the call throws.
+struct RangeCheck {
+    std::thread th;
+    bool ok = true;
+    void start(const ShimState::Entry& e, size_t from, size_t count)
+    {
+        th = std::thread([this, &e, from, count]() { ok = e.range_verifies(from, count); });
+    }
+    bool finish()
+    {
+        if (th.joinable()) th.join();
+        return ok;
+    }
+    ~RangeCheck()
+    {
+        if (th.joinable()) th.join();
+    }
+};
 // every cached entry whose host range overlaps [table, table + 2 num_points) except the one AT `table`: the caller vouches that this
 // memory holds its table now, so whatever else was remembered there is dead (a table freed without the unregister hook)
 void drop_overlapping(const g1::affine_element* table, size_t num_points)
@@ -187,7 +244,9 @@ bbg_srs* register_table(const g1::affine_element* table, size_t num_points)
     drop_overlapping(table, num_points);
     auto it = s.tables.find(table);
     if (it != s.tables.end()) {
-        if (it->second.registered && it->second.n >= num_points && it->second.range_still_matches(0, num_points)) return it->second.srs;
+        if (it->second.registered && it->second.n >= num_points && it->second.range_still_matches(0, num_points) &&
+            (!bbg_shim_verify::full_mode() || it->second.range_verifies(0, num_points)))
+            return it->second.srs;
         drop(it); // an implicit entry at this address, a shorter registration, or other contents than were registered: replace
     }
     ShimState::Entry e;
@@ -200,10 +259,11 @@ bbg_srs* register_table(const g1::affine_element* table, size_t num_points)
     return s.tables[table].srs;
 }
 // Device SRS for an MSM over points[0 .. 2 num_points); *from = index of points[0] in it; *transient = the caller frees it after use.
-bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t& from, bool& transient)
+bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t& from, bool& transient, bool& fresh)
 {
     ShimState& s = state();
     transient = false;
+    fresh = false; // true: the entry was uploaded (and hashed) inside this call
     auto it = containing(points);
     bool registered_but_short = false;
     if (it != s.tables.end()) {
@@ -242,8 +302,10 @@ bbg_srs* lookup_srs(const g1::affine_element* points, size_t num_points, size_t&
     e.last_use = ++s.clock;
     take_samples(e);
     s.tables[points] = std::move(e);
+    fresh = true;
     return s.tables[points].srs;
 }
+uint64_t g_stale_tables = 0; // cached tables found rewritten by the full check and uploaded again (bbg_shim_stale_tables)
 g1::element msm(fr* scalars, g1::affine_element* points, size_t n)
 {
     std::lock_guard<std::mutex> lk(state().mu);
@@ -253,29 +315,42 @@ g1::element msm(fr* scalars, g1::affine_element* points, size_t n)
         out.self_set_infinity();
         return out;
     }
-    size_t from = 0;
-    bool transient = false;
-    bbg_srs* srs = lookup_srs(points, n, from, transient);
-    if (!transient) {
-        bbg_multi* group = device_group();
-        if (group && n >= state().multi_min) { // large MSM over a cached table: every GPU of the group takes a point range
-            ShimState& s = state();
-            auto it = containing(points);
-            const ShimState::Entry& e = it->second;
-            if (s.multi_table != e.base || s.multi_points != e.n) {
-                if (bbg_multi_srs_register(group, reinterpret_cast<const uint64_t*>(e.base), e.n, sizeof(g1::affine_element) * 2) != BBG_OK)
-                    fail("bbg_multi_srs_register");
-                s.multi_table = e.base;
-                s.multi_points = e.n;
+    // at most two passes: the second only after the full check found the cached copy stale -- it uploads (fresh) and needs no check
+    for (int pass = 0;; pass++) {
+        size_t from = 0;
+        bool transient = false, fresh = false;
+        bbg_srs* srs = lookup_srs(points, n, from, transient, fresh);
+        RangeCheck check; // joined when it goes out of scope, whatever happens below
+        if (!transient && !fresh && bbg_shim_verify::full_mode()) check.start(containing(points)->second, from, n);
+        bool done = false;
+        if (!transient) {
+            bbg_multi* group = device_group();
+            if (group && n >= state().multi_min) { // large MSM over a cached table: every GPU of the group takes a point range
+                ShimState& s = state();
+                auto it = containing(points);
+                const ShimState::Entry& e = it->second;
+                if (s.multi_table != e.base || s.multi_points != e.n) {
+                    if (bbg_multi_srs_register(group, reinterpret_cast<const uint64_t*>(e.base), e.n, sizeof(g1::affine_element) * 2) != BBG_OK)
+                        fail("bbg_multi_srs_register");
+                    s.multi_table = e.base;
+                    s.multi_points = e.n;
+                }
+                if (bbg_multi_msm(group, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out)) != BBG_OK) fail("bbg_multi_msm");
+                done = true;
             }
-            if (bbg_multi_msm(group, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out)) != BBG_OK) fail("bbg_multi_msm");
-            return out;
         }
+        if (!done) {
+            const int rc = bbg_msm(context(), srs, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out));
+            if (transient) bbg_srs_free(srs);
+            if (rc != BBG_OK) fail("bbg_msm");
+        }
+        if (check.finish()) return out;
+        // the host table is not what the device copy was made from: forget the copy and compute the MSM again over the memory as it is now
+        if (pass > 0) throw std::runtime_error("bbg_shim: a point table keeps changing while it is used");
+        g_stale_tables++;
+        auto it = containing(points);
+        if (it != state().tables.end()) drop(it);
     }
-    const int rc = bbg_msm(context(), srs, reinterpret_cast<const uint64_t*>(scalars), from, n, reinterpret_cast<uint64_t*>(&out));
-    if (transient) bbg_srs_free(srs);
-    if (rc != BBG_OK) fail("bbg_msm");
-    return out;
 }
 void ntt(fr* coeffs, const evaluation_domain& d, int op, const fr* constant)
 {
@@ -316,6 +391,12 @@ extern "C" bbg_srs* bbg_shim_srs_for(const void* endo_table, size_t num_points)
 {
     std::lock_guard<std::mutex> lk(state().mu);
     return register_table(static_cast<const g1::affine_element*>(endo_table), num_points);
+}
+// cached tables the full content check found rewritten and uploaded again (tests; BBG_SHIM_VERIFY=sample never counts)
+extern "C" uint64_t bbg_shim_stale_tables(void)
+{
+    std::lock_guard<std::mutex> lk(state().mu);
+    return g_stale_tables;
 }
 // number of cached device tables (tests: bounded cache, transient tables not retained)
 extern "C" size_t bbg_shim_cached_tables(void)

@@ -28,11 +28,14 @@
 // caller's source (the parity tests replay the scalars a reference proof drew and compare the proofs byte for byte).
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "bbg_resident_prover.hpp"
+#include "bbg_shim_verify.hpp"
 
 namespace {
 using bbg_shim::ResidentKey;
@@ -43,7 +46,8 @@ struct ResidentCache {
         std::shared_ptr<ResidentKey> rk; // shared with a round-by-round proof in progress: an eviction cannot pull the key from under it
         size_t bytes = 0;
         uint64_t last_use = 0;
-        uint64_t fingerprint = 0; // of the host key polynomials the device copy was made from (key_fingerprint below)
+        uint64_t fingerprint = 0; // of the host key polynomials the device copy was made from (key_fingerprint below): the quick look
+        uint64_t content = 0;     // full mode: hash of EVERY coefficient that was uploaded (key_content_hash below)
     };
     std::map<const waffle::proving_key*, Entry> entries;
     // proofs a host drives round by round (execute_preamble_round ... execute_sixth_round), keyed by the prover object
@@ -56,8 +60,13 @@ struct ResidentCache {
         std::unique_ptr<ProofIface> proof; // null: this prover's current proof runs on the reference rounds
         int next = 0;                      // the round expected next (resident mode)
         const waffle::proving_key* id = nullptr;
+        uint64_t touched = 0;              // cache clock of the last round: abandoned proofs age out (sweep_progress)
+        uint64_t content = 0;              // the key's recorded content hash when the proof began
+        std::future<uint64_t> check;       // full mode: the host key re-hashed while the rounds run; looked at before the last round
     };
     std::map<const void*, Progress> in_progress;
+    static constexpr size_t MAX_IN_PROGRESS = 16;      // round-by-round proofs that may be open at once
+    static constexpr uint64_t PROGRESS_MAX_AGE = 64;   // ... and for how many cache uses an untouched one is kept
     uint64_t clock = 0;
     bool enabled = true;
     size_t budget = 0; // 0 = not initialised yet
@@ -69,11 +78,40 @@ struct ResidentCache {
         if (const char* e = std::getenv("BBG_SHIM_RESIDENT")) enabled = !(e[0] == '0' && e[1] == 0);
         if (const char* b = std::getenv("BBG_SHIM_RESIDENT_MAX_BYTES")) budget = (size_t)std::strtoull(b, nullptr, 10);
     }
+    // device bytes the cache answers for: its entries, plus keys that are no longer entries but are still pinned by a proof in progress
     size_t total() const
     {
         size_t t = 0;
         for (const auto& kv : entries) t += kv.second.bytes;
+        for (const auto& kv : in_progress) {
+            const Progress& pg = kv.second;
+            if (!pg.rk) continue;
+            auto it = entries.find(pg.id);
+            if (it != entries.end() && it->second.rk == pg.rk) continue; // counted above
+            size_t bytes = 0;
+            if (bbg_prover_device_bytes(pg.rk->handle(), &bytes) == BBG_OK) t += bytes;
+        }
         return t;
+    }
+    // Round-by-round proofs nobody will finish (round-5 advisor finding): the prover was destroyed after an error, the proof abandoned.
+    // Such an entry pins its key's device memory outside the LRU budget and keeps a reference to a dead prover.  Dropped here: proofs whose
+    // proving key only the cache still holds (the prover that shared it is gone -- the rule sweep() applies to entries), proofs not touched
+    // for PROGRESS_MAX_AGE cache uses, and the oldest ones beyond MAX_IN_PROGRESS.
+    void sweep_progress()
+    {
+        for (auto it = in_progress.begin(); it != in_progress.end();) {
+            const Progress& pg = it->second;
+            const bool orphan = pg.rk && pg.rk->key().use_count() == 1; // only the device copy itself still holds the proving key
+            const bool old = clock - pg.touched > PROGRESS_MAX_AGE;
+            if (orphan || old) it = in_progress.erase(it);
+            else ++it;
+        }
+        while (in_progress.size() > MAX_IN_PROGRESS) {
+            auto oldest = in_progress.begin();
+            for (auto it = in_progress.begin(); it != in_progress.end(); ++it)
+                if (it->second.touched < oldest->second.touched) oldest = it;
+            in_progress.erase(oldest);
+        }
     }
     // entries whose proving key only the cache still holds
     size_t sweep()
@@ -142,6 +180,29 @@ uint64_t key_fingerprint(const waffle::proving_key& key)
     return h;
 }
 
+// Full mode (bbg_shim_verify.hpp): every coefficient ResidentKey uploads -- the first n coefficients of each selector and permutation
+// polynomial of the manifest (bbg_resident_prover.hpp: bbg_prover_set_key_poly) -- in one 64-bit digest.  Recorded when the device copy is
+// made; recomputed on host threads WHILE each later proof over the cached copy runs on the GPU and compared before the proof is handed
+// back: one poked coefficient anywhere gives a re-upload and a repeated proof, never a proof over the stale copy.  The Lagrange / coset
+// forms the reference keeps beside the coefficient forms are derived on the device from what was uploaded; a host that edits ONLY those
+// has a key whose forms contradict each other (compute_proving_key's invariant, composer_base.cpp:180-262) -- not covered, not coverable.
+uint64_t key_content_hash(const waffle::proving_key& key)
+{
+    std::vector<bbg_shim_verify::Span> spans;
+    for (const auto& info : key.polynomial_manifest) {
+        if (info.source == waffle::PolynomialSource::WITNESS) continue;
+        const std::string label(info.polynomial_label);
+        const auto& table = info.source == waffle::PolynomialSource::SELECTOR ? key.constraint_selectors : key.permutation_selectors;
+        auto it = table.find(label);
+        if (it == table.end() || it->second.get_size() == 0) {
+            spans.push_back({ nullptr, 0 });
+            continue;
+        }
+        spans.push_back({ reinterpret_cast<const uint64_t*>(&it->second[0]), std::min<size_t>(key.n, it->second.get_size()) * 4 });
+    }
+    return bbg_shim_verify::hash_spans(spans) ^ (uint64_t)key.n;
+}
+
 barretenberg::fr draw_adapter(void*)
 {
     ResidentCache& c = cache();
@@ -149,13 +210,32 @@ barretenberg::fr draw_adapter(void*)
     c.draw(c.draw_user, reinterpret_cast<uint64_t*>(&v));
     return v;
 }
+// The blinding scalars of a proof, recorded while it is made so that a proof that has to be REPEATED (the full check found the cached key
+// stale) draws the same ones: the repeated proof is the proof the first attempt would have been over the key as it is now.
+struct BlindingTape {
+    std::vector<barretenberg::fr> drawn;
+    size_t next = 0;
+    bool replay = false;
+    static barretenberg::fr draw(void* user)
+    {
+        BlindingTape& t = *static_cast<BlindingTape*>(user);
+        if (t.replay && t.next < t.drawn.size()) return t.drawn[t.next++];
+        ResidentCache& c = cache();
+        const barretenberg::fr v = c.draw ? draw_adapter(nullptr) : bbg_shim::os_random_fr();
+        t.drawn.push_back(v);
+        return v;
+    }
+};
 
 // The device copy of self's proving key: cached, re-uploaded when the host polynomials changed (key_fingerprint), created (evicting every
 // other key once if the first attempt fails: most likely device memory) -- or null, counted as a fallback, when it cannot be had.
 // Called with the cache locked.
-template <typename settings> ResidentCache::Entry* acquire_key(ResidentCache& c, waffle::ProverBase<settings>* self, const char* what)
+template <typename settings>
+ResidentCache::Entry* acquire_key(ResidentCache& c, waffle::ProverBase<settings>* self, const char* what, bool* fresh = nullptr)
 {
+    if (fresh) *fresh = false;
     c.sweep();
+    c.sweep_progress();
     if (c.budget == 0) {
         bbg_memory_info info;
         c.budget = bbg_memory_report(bbg_shim_context(), &info) == BBG_OK && info.device_total ? info.device_total / 2 : ((size_t)64 << 30);
@@ -189,8 +269,10 @@ template <typename settings> ResidentCache::Entry* acquire_key(ResidentCache& c,
         if (bbg_prover_device_bytes(rk->handle(), &bytes) != BBG_OK) bytes = 0;
         e.bytes = bytes;
         e.fingerprint = fingerprint;
+        if (bbg_shim_verify::full_mode()) e.content = key_content_hash(*self->key);
         e.rk = std::move(rk);
         it = c.entries.emplace(id, std::move(e)).first;
+        if (fresh) *fresh = true;
     }
     it->second.last_use = ++c.clock;
     c.evict_to_budget(id);
@@ -218,7 +300,8 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
         ReferenceScope rs;
         return real(self);
     }
-    ResidentCache::Entry* entry = acquire_key(c, self, "construct_proof()");
+    bool fresh = false;
+    ResidentCache::Entry* entry = acquire_key(c, self, "construct_proof()", &fresh);
     if (!entry) {
         lk.unlock();
         ReferenceScope rs;
@@ -226,12 +309,36 @@ waffle::plonk_proof& resident_or_real(waffle::ProverBase<settings>* self, waffle
     }
     const waffle::proving_key* id = self->key.get();
     std::shared_ptr<ResidentKey> rk = entry->rk;
+    BlindingTape tape;
     bbg_shim::ResidentOptions opt;
-    if (c.draw) opt.random = &draw_adapter;
+    opt.random = &BlindingTape::draw;
+    opt.user = &tape;
     c.proofs++;
     // the lock is held for the whole proof: the reference's prover is not re-entrant either (process-global FFT scratch,
     // polynomial_arithmetic.cpp:13-34), and the shim's device context is one stream
     try {
+        // a cached device copy: the host key is re-hashed on other host threads while the GPU makes the proof (this thread mostly waits for
+        // it), and the proof is handed back only if every uploaded coefficient is still what it was
+        std::future<uint64_t> check;
+        if (!fresh && bbg_shim_verify::full_mode()) check = std::async(std::launch::async, [key = self->key]() { return key_content_hash(*key); });
+        const uint64_t recorded = entry->content;
+        waffle::plonk_proof& proof = bbg_shim::construct_proof(*self, *rk, opt);
+        if (!check.valid() || check.get() == recorded) return proof;
+        // the host polynomials changed under the cached copy: upload the key as it is now and make the proof again, with the same blinding
+        c.entries.erase(id);
+        c.reuploads++;
+        rk.reset();
+        entry = acquire_key(c, self, "construct_proof()", &fresh);
+        if (!entry) {
+            lk.unlock();
+            self->reset();
+            ReferenceScope rs;
+            return real(self);
+        }
+        rk = entry->rk;
+        self->reset();
+        tape.replay = true;
+        tape.next = 0;
         return bbg_shim::construct_proof(*self, *rk, opt);
     } catch (const std::exception& e) {
         // A device error in the middle of a proof (out of memory, a HIP failure): the reference's construct_proof() never throws for
@@ -281,14 +388,19 @@ template <typename settings> void resident_round(waffle::ProverBase<settings>* s
     if (round == 0) { // a new proof begins on this prover (first use, or after ProverBase::reset())
         c.in_progress.erase(self);
         if (!c.enabled || !self->key || !bbg_shim::resident_supported(*self)) return reference();
-        ResidentCache::Entry* entry = acquire_key(c, self, "execute_preamble_round()");
+        bool fresh = false;
+        ResidentCache::Entry* entry = acquire_key(c, self, "execute_preamble_round()", &fresh);
         if (!entry) {
-            c.in_progress[self]; // reference mode for the rest of this proof
+            c.in_progress[self].touched = c.clock; // reference mode for the rest of this proof
             return reference();
         }
         ResidentCache::Progress& pg = c.in_progress[self];
         pg.rk = entry->rk;
         pg.id = self->key.get();
+        pg.touched = c.clock;
+        pg.content = entry->content;
+        // a cached device copy: the host key is re-hashed while the rounds run and looked at before the last one (below)
+        if (!fresh && bbg_shim_verify::full_mode()) pg.check = std::async(std::launch::async, [key = self->key]() { return key_content_hash(*key); });
         bbg_shim::ResidentOptions opt;
         if (c.draw) opt.random = &draw_adapter;
         pg.proof = std::make_unique<ProofImpl<settings>>(*self, *pg.rk, opt);
@@ -298,12 +410,19 @@ template <typename settings> void resident_round(waffle::ProverBase<settings>* s
     auto it = c.in_progress.find(self);
     if (it == c.in_progress.end() || !it->second.proof) return reference(); // not begun here, or on the reference rounds already
     ResidentCache::Progress& pg = it->second;
-    if (round != pg.next) { // out of order: the resident state is abandoned, the reference does whatever it does with such a call
+    // out of order, or this prover object is not the one the proof began on (an abandoned proof whose prover was destroyed and another
+    // allocated at the same address, over another key): the resident state is abandoned, the reference does whatever it does with such a call
+    if (round != pg.next || self->key.get() != pg.id) {
         pg.proof.reset();
         pg.rk.reset();
         return reference();
     }
+    pg.touched = ++c.clock;
     try {
+        if (round == 6 && pg.check.valid() && pg.check.get() != pg.content) {
+            c.reuploads++;
+            throw std::runtime_error("the proving key's host polynomials changed under its cached device copy");
+        }
         pg.proof->step(round);
         pg.next = round + 1;
         if (round == 6) c.in_progress.erase(it); // the proof is in the transcript: export_proof() is the reference's

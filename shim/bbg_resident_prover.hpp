@@ -164,10 +164,19 @@ class ResidentKey {
     const std::shared_ptr<waffle::proving_key>& key() const { return key_; }
     size_t program_width() const { return width_; }
 
+    // The device state of a proof in progress (wires, z, quotient, the round reached) belongs to the KEY's device copy, and a host may begin
+    // a second proof over the same key between two rounds of the first (another prover's construct_proof(), another round-by-round proof).
+    // Each ResidentProof claims the key when it begins (its preamble) and every later round checks that it still holds the claim: a proof
+    // whose device state was overwritten fails with an exception (the wrap then repeats it on the reference rounds) instead of going on
+    // over the other proof's polynomials (round-5 advisor finding).
+    uint64_t claim() { return ++claim_; }
+    bool claimed_by(uint64_t token) const { return claim_ == token; }
+
   private:
     std::shared_ptr<waffle::proving_key> key_;
     size_t width_;
     bbg_prover* handle_ = nullptr;
+    uint64_t claim_ = 0;
 };
 
 namespace detail {
@@ -291,6 +300,7 @@ template <typename settings> class ResidentProof {
     ResidentProof(waffle::ProverBase<settings>& prover, ResidentKey& rk, const ResidentOptions& options = ResidentOptions())
         : p(prover)
         , opt(options)
+        , rkey(rk)
         , dev(rk.handle())
         , key(prover.key.get())
         , witness(prover.witness.get())
@@ -450,6 +460,9 @@ template <typename settings> class ResidentProof {
     // step k of the seven (0 = preamble ... 6 = sixth round)
     void step(int k)
     {
+        if (k == 0) token = rkey.claim();
+        else if (!rkey.claimed_by(token))
+            throw std::runtime_error("bbg_shim::ResidentProof: another proof over the same proving key began between two rounds of this one");
         switch (k) {
         case 0: preamble(); break;
         case 1: first(); break;
@@ -466,6 +479,8 @@ template <typename settings> class ResidentProof {
     fr random() { return opt.random ? opt.random(opt.user) : os_random_fr(); }
     waffle::ProverBase<settings>& p;
     ResidentOptions opt;
+    ResidentKey& rkey;
+    uint64_t token = 0;
     bbg_prover* dev;
     waffle::proving_key* key;
     waffle::program_witness* witness;

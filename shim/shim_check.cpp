@@ -13,6 +13,7 @@
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include <ecc/curves/bn254/scalar_multiplication/pippenger.hpp>
@@ -23,6 +24,7 @@
 using namespace barretenberg;
 
 extern "C" size_t bbg_shim_cached_tables(void);
+extern "C" uint64_t bbg_shim_stale_tables(void);
 extern "C" void bbg_shim_register_point_table(const void* endo_table, size_t num_points);
 extern "C" void bbg_shim_unregister_point_table(const void* endo_table);
 
@@ -231,6 +233,33 @@ int main(int argc, char** argv)
         g = scalar_multiplication::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs);
         c = real::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs);
         expect(g1::affine_element(g) == g1::affine_element(c), "a table rewritten in place is re-uploaded (sampled validation inside the call's own range)");
+        // ONE point rewritten, one the samples do not look at (they take every (n / 1024)-th point and the last): the full content check of
+        // the call's range (bbg_shim_verify.hpp) must find it -- the commitment is the one over the memory as it is now, and the stale copy
+        // is counted.  With BBG_SHIM_VERIFY=sample this is exactly the silent-wrong case rounds 4-5 documented as a tripwire's limit.
+        {
+            const bool full = !(std::getenv("BBG_SHIM_VERIFY") && std::string(std::getenv("BBG_SHIM_VERIFY")) == "sample");
+            const uint64_t stale0 = bbg_shim_stale_tables();
+            const size_t poke = reg_n > 2048 ? 1 : reg_n; // an unsampled index where the table has them
+            if (poke < reg_n) {
+                const g1::affine_element keep = reg_table[2 * poke], keep_endo = reg_table[2 * poke + 1];
+                reg_table[2 * poke] = reg_table[2 * (poke + 2)];
+                reg_table[2 * poke + 1] = reg_table[2 * (poke + 2) + 1];
+                g = scalar_multiplication::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs);
+                c = real::pippenger_unsafe(scalars.data(), reg_table, reg_n, reg_rs);
+                if (full) {
+                    expect(g1::affine_element(g) == g1::affine_element(c), "ONE unsampled point rewritten in a cached table: the MSM is over the table as it is now");
+                    expect(bbg_shim_stale_tables() == stale0 + 1, "... and the stale device copy was found by the full check, once");
+                    g = scalar_multiplication::pippenger_unsafe(scalars.data(), reg_table + 2 * 3, reg_n - 3, reg_rs); // the fresh copy, a sub-range
+                    c = real::pippenger_unsafe(scalars.data(), reg_table + 2 * 3, reg_n - 3, reg_rs);
+                    expect(g1::affine_element(g) == g1::affine_element(c) && bbg_shim_stale_tables() == stale0 + 1, "the re-uploaded copy verifies (no second upload)");
+                } else {
+                    std::printf("note  BBG_SHIM_VERIFY=sample: a single unsampled point goes unnoticed (%s)\n",
+                                g1::affine_element(g) == g1::affine_element(c) ? "noticed here" : "stale result, as documented");
+                }
+                reg_table[2 * poke] = keep;
+                reg_table[2 * poke + 1] = keep_endo;
+            }
+        }
         // many tables without hooks: the implicit cache stays bounded
         std::vector<g1::affine_element*> many;
         for (int t = 0; t < 7; t++) {

@@ -13,6 +13,9 @@ TOOLS = os.path.join(ROOT, "tests", "tools")
 if TOOLS not in sys.path:
     sys.path.insert(0, TOOLS)
 
+# the library's fault-injection option (prover_fail_round) exists only in a process started with test hooks on (bbg_capi.hip): this is one
+os.environ.setdefault("BBG_TEST_HOOKS", "1")
+
 import __graft_entry__ as ge  # noqa: E402
 
 

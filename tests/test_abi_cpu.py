@@ -158,7 +158,7 @@ def test_bench_launches_its_own_ranks_and_always_leaves_a_line():
         rc, line, _ = run(["--gpus", "2"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_GRACE_S="2")
         assert rc != 0 and line["value"] is None and "exited with code" in line["error"] and line["exit_codes"] == [1, 1], line
         # rank 1 never answers, rank 0 dies: after the grace period the parent stops rank 1 (SIGKILL to the group it started) and reports
-        rc, line, el = run(["--gpus", "2"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="1", BBG_BENCH_GRACE_S="2")
+        rc, line, el = run(["--gpus", "2"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="1", BBG_TEST_HOOKS="1", BBG_BENCH_GRACE_S="2")
         assert rc != 0 and "rank 0 exited with code 1" in line["error"] and line["exit_codes"] == [1, -9] and el < 60, (line, el)
     if not torch.cuda.is_available():
         # started by a launcher (WORLD_SIZE set) on a node with fewer devices than ranks: every rank leaves before any rendezvous, rank 0 with a line
@@ -170,7 +170,7 @@ def test_bench_launches_its_own_ranks_and_always_leaves_a_line():
             if rank == 0:
                 assert "ranks on this node" in json.loads(lines[0])["error"]
     # nobody answers at all: the hard limit
-    rc, line, el = run(["--gpus", "2", "--no-config5"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="0", BBG_BENCH_LAUNCH_TIMEOUT="4",
+    rc, line, el = run(["--gpus", "2", "--no-config5"], BBG_BENCH_SKIP_DEVICE_CHECK="1", BBG_BENCH_TEST_HANG_RANK="0", BBG_TEST_HOOKS="1", BBG_BENCH_LAUNCH_TIMEOUT="4",
                        BBG_BENCH_GRACE_S="1")
     assert rc != 0 and line["value"] is None and line["error"] and el < 60, (line, el)
 

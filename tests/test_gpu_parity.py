@@ -1364,6 +1364,7 @@ def test_ntt_above_2_24_vs_reference(pkg, oracle, lg):
     recs = [r for r in _ntt_large_golden() if r["log2n"] == lg]
     assert recs, "no reference digests for 2^%d" % lg
     ctx = pkg.Bbg(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # torch stages the buffers (copy_) on its stream: the library must run behind them
     try:
         a = pkg.synthetic_scalars(900 + lg, n)
         ta = torch.from_numpy(a.view(np.int64).reshape(-1)).cuda()
@@ -1848,6 +1849,46 @@ def test_wrapped_construct_proof_reuploads_a_rewritten_key(pkg, oracle, bbg):
         proof = B.prove_reference(replay=blind, reset=True)
         assert B.wrap_reuploads() == re0 + 1 and B.wrap_cached_keys() == keys
         assert proof == proof_cpu, "stale device copy of a rewritten proving key"
+    finally:
+        A.free()
+        B.free()
+
+
+@pytest.mark.parametrize("rounds", [False, True])
+def test_wrapped_proof_over_a_key_with_one_poked_coefficient(pkg, oracle, bbg, rounds):
+    """The silent-wrong path rounds 4-5 left open: ONE coefficient of a cached proving key rewritten at a row the sampled fingerprint does not
+    look at (16 evenly spaced rows per polynomial).  Round 6 (shim/bbg_shim_verify.hpp): while the GPU makes the proof, host threads re-hash
+    EVERY coefficient the device copy was made from; a mismatch drops the copy, uploads the key as it is now and repeats the proof with the
+    same blinding scalars -- the wrapped construct_proof() returns the proof the CPU prover makes over the rewritten key, byte for byte
+    (`rounds`: the same through the seven wrapped execute_*_round symbols, where the stale copy sends the proof to the reference rounds: a
+    valid-shape proof that the verifier rejects like the CPU prover's, since the circuit no longer matches the key).
+    Reference anchor: a proving_key is a plain struct of host polynomials with no change hook (proving_key.cpp:18-27)."""
+    from oracle.oracle import RefProver, prover_available, PROVER_WRAP_SO
+    if not prover_available() or not os.path.exists(PROVER_WRAP_SO):
+        pytest.skip("oracle/_ref/libbbprover_wrap.so absent on this machine")
+    x, pts = _powers_srs(oracle, (2 << 10) + 2)
+    A = RefProver(1 << 10, 63, pts, x, flavour=0)
+    B = RefProver(1 << 10, 63, pts, x, wrap_linked=True, flavour=0)
+    try:
+        B.prove_reference()
+        assert B.verify() == 1
+        re0, keys = B.wrap_reuploads(), B.wrap_cached_keys()
+        A.key_selector_poke("q_m", 1)  # row 1 of 1024: the samples sit at rows (n - 1) k / 15
+        B.key_selector_poke("q_m", 1)
+        proof_cpu, blind = A.prove_recording()
+        if rounds:
+            proof, _, _ = B.prove_round_by_round(reset=True)
+            assert B.wrap_reuploads() == re0 + 1, "the full check did not see the rewritten coefficient"
+            # (the reference rounds that replaced the resident ones left B's witness in coefficient form, as the reference prover does:
+            # B is not proved with again -- test_wrapped_construct_proof_survives_a_device_error covers the proof after a fallback)
+            assert len(proof) == len(proof_cpu) and B.verify() == A.verify()
+            assert B.wrap_cached_keys() == keys - 1, "the stale device copy is gone"
+        else:
+            proof = B.prove_reference(replay=blind, reset=True)
+            assert B.wrap_reuploads() == re0 + 1 and B.wrap_cached_keys() == keys
+            assert proof == proof_cpu, "proof over the stale device copy of a key with one rewritten coefficient"
+            again = B.prove_reference(replay=blind, reset=True)  # the fresh copy verifies: no further upload
+            assert again == proof_cpu and B.wrap_reuploads() == re0 + 1
     finally:
         A.free()
         B.free()
