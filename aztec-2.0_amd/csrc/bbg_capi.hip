@@ -151,6 +151,7 @@ void bbg_destroy(bbg_ctx* ctx)
     if (ctx->gp_totals) (void)hipFree(ctx->gp_totals);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->msm.buf) (void)hipFree(ctx->msm.buf);
+    if (ctx->msm_tiny.buf) (void)hipFree(ctx->msm_tiny.buf);
     if (ctx->poly_scratch) (void)hipFree(ctx->poly_scratch);
     if (ctx->aux_stream) {
         for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
@@ -379,7 +380,7 @@ int bbg_memory_report(bbg_ctx* ctx, bbg_memory_info* out)
         out->ntt_domains++;
     }
     for (const auto& kv : ctx->dpv_tables) out->ntt_tables += (size_t)32 << ((kv.first >> 8) & 0xff); // poly_dpv_table: one Fr per target-domain point
-    out->msm_arena = ctx->msm.bytes;
+    out->msm_arena = ctx->msm.bytes + ctx->msm_tiny.bytes;
     out->scratch = ctx->ntt_scratch_bytes + ctx->staging_bytes + ctx->poly_scratch_bytes + ctx->gp_totals_bytes + ctx->quot_setup_bytes +
                    ctx->dpv_consts.size() * (size_t)DPV_CONSTS_BYTES;
     prover_report(ctx, &out->prover_keys, &out->live_provers);
@@ -414,6 +415,7 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
         drop(&ctx->gp_totals, &ctx->gp_totals_bytes);
         drop(&ctx->quot_setup, &ctx->quot_setup_bytes);
         drop(&ctx->msm.buf, &ctx->msm.bytes);
+        drop(&ctx->msm_tiny.buf, &ctx->msm_tiny.bytes);
         ctx->msm_layout_n = 0; // the arena's counters are re-initialised with the next layout
         ctx->msm_zero_buf = nullptr;
         ctx->msm_zero_c = 0;

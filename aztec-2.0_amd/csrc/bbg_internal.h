@@ -49,7 +49,7 @@ struct NttDomain {
 struct Srs {
     size_t n = 0;          // number of (plain) points
     void* points = nullptr; // device: n affine points, 64 B each, Montgomery, canonical (= window 0 of a table below)
-    static constexpr int MAX_WIDTHS = 6;
+    static constexpr int MAX_WIDTHS = 7; // BBG_MSM_TABLE_WIDTHS (msm_cfg.h)
     void* tables[MAX_WIDTHS] = {}; // window tables T[w][i] = 2^(MsmCfg<C>::table_offset(w)) P_i (balanced windows, halved weight for the narrow ones: msm_cfg.h) per compiled width C (slot = msm_width_slot(C), msm.hip); built on first use
     int home_slot = -1;    // the table built at registration: its window 0 IS `points`, so it is never released before the handle
     int device = 0;
@@ -87,6 +87,8 @@ struct bbg_ctx {
     void* staging = nullptr; // device staging for host-pointer entry points
     size_t staging_bytes = 0;
     bbg::MsmScratch msm;
+    bbg::MsmScratch msm_tiny; // digit bytes, sign words and per-block bucket sums of the small-circuit MSM path (msm_tiny.hip)
+    uint64_t msm_tiny_layout = 0; // (n_pad, sets, slices) the buffer was last laid out for: another shape moves the double-buffered bucket sums
     void* poly_scratch = nullptr; // evaluate / kate partial sums, pow tables
     size_t poly_scratch_bytes = 0;
     // MSM reduce phase may run on an auxiliary stream so that it overlaps the next MSM's sort / accumulation

@@ -10,8 +10,27 @@
 // instead of 8.5.  Results are the same group elements as curve.hip.h's serial formulas (possibly another coarse representative).
 #pragma once
 #include "curve.hip.h"
+#include "field29.hip.h"
+
+// The products of the quad operations.  These kernels are chains of dependent products run by a wave that is alone on its SIMD: what counts is
+// the time of ONE product, not products per second.  BBG_QUAD_MUL29 = 1 (round 6): the product through the 29-bit multiplier with a column
+// accumulator per column (field29.hip.h fe_mul29_ilp: the a*b products wait for nothing, the digit steps add nine independent products each) --
+// 473 against 557 ns per dependent product (bench_micro/mul_latency.hip, profiles/r06_mul_latency.txt); same residues, same contract as fe_mul
+// (operands < 2p, or < 4p and < p; result < 1.76p).  0: field.hip.h fe_mul (A/B).
+#ifndef BBG_QUAD_MUL29
+#define BBG_QUAD_MUL29 0
+#endif
 
 namespace bbg {
+
+__device__ __forceinline__ Fq quad_mul(const Fq& a, const Fq& b)
+{
+#if BBG_QUAD_MUL29
+    return fe_mul29_ilp(a, b);
+#else
+    return fe_mul(a, b);
+#endif
+}
 
 // value held by lane K of the caller's quad, in every lane of the quad (v_mov_b32 with DPP quad_perm:[K,K,K,K])
 template <int K> __device__ __forceinline__ Fq quad_bcast(const Fq& v)
@@ -64,16 +83,16 @@ __device__ __forceinline__ Xyzz xyzz_dbl_q4(const Xyzz& p, int q)
     const Fq U = fe_dbl(p.y);
     // step 1: U^2 | x^2
     const Fq ux = quad_pick2(w.odd, U, p.x);
-    Fq m = fe_mul(ux, ux);
+    Fq m = quad_mul(ux, ux);
     const Fq V = quad_bcast<0>(m), xx = quad_bcast<1>(m);
     const Fq M = fe_add(fe_dbl(xx), xx);
     // step 2: U V | x V | M^2 | V zz
-    m = fe_mul(quad_pick(w, U, p.x, M, V), quad_pick(w, V, V, M, p.zz));
+    m = quad_mul(quad_pick(w, U, p.x, M, V), quad_pick(w, V, V, M, p.zz));
     const Fq W = quad_bcast<0>(m), S = quad_bcast<1>(m), MM = quad_bcast<2>(m), ZZ3 = quad_bcast<3>(m);
     Xyzz r;
     r.x = fe_sub(MM, fe_dbl(S));
     // step 3: M (S - X3) | W y | W zzz | -
-    m = fe_mul(quad_pick(w, M, W, W, W), quad_pick(w, fe_sub(S, r.x), p.y, p.zzz, p.zzz));
+    m = quad_mul(quad_pick(w, M, W, W, W), quad_pick(w, fe_sub(S, r.x), p.y, p.zzz, p.zzz));
     r.y = fe_sub(quad_bcast<0>(m), quad_bcast<1>(m));
     r.zz = ZZ3;
     r.zzz = quad_bcast<2>(m);
@@ -87,7 +106,7 @@ __device__ __forceinline__ Xyzz xyzz_add_q4(const Xyzz& a, const Xyzz& b, int q)
     if (xyzz_is_inf(a)) return b;
     const QuadRole w = quad_role(q);
     // step 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
-    Fq m = fe_mul(quad_pick(w, a.x, b.x, a.y, b.y), quad_pick(w, b.zz, a.zz, b.zzz, a.zzz));
+    Fq m = quad_mul(quad_pick(w, a.x, b.x, a.y, b.y), quad_pick(w, b.zz, a.zz, b.zzz, a.zzz));
     const Fq U1 = quad_bcast<0>(m), U2 = quad_bcast<1>(m), S1 = quad_bcast<2>(m), S2 = quad_bcast<3>(m);
     const Fq P = fe_sub(U2, U1), R = fe_sub(S2, S1);
     if (fe_is_zero(P)) {
@@ -95,15 +114,15 @@ __device__ __forceinline__ Xyzz xyzz_add_q4(const Xyzz& a, const Xyzz& b, int q)
         return xyzz_inf();
     }
     // step 2: P^2 | R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
-    m = fe_mul(quad_pick(w, P, R, a.zz, a.zzz), quad_pick(w, P, R, b.zz, b.zzz));
+    m = quad_mul(quad_pick(w, P, R, a.zz, a.zzz), quad_pick(w, P, R, b.zz, b.zzz));
     const Fq PP = quad_bcast<0>(m), RR = quad_bcast<1>(m);
     // step 3: PPP = P PP | Q = U1 PP | ZZ3 = (ZZ1 ZZ2) PP | T = (ZZZ1 ZZZ2) P      (lanes 2, 3 continue from their own step-2 product)
-    m = fe_mul(quad_pick(w, P, U1, m, m), quad_pick(w, PP, PP, PP, P));
+    m = quad_mul(quad_pick(w, P, U1, m, m), quad_pick(w, PP, PP, PP, P));
     const Fq PPP = quad_bcast<0>(m), Q = quad_bcast<1>(m), ZZ3 = quad_bcast<2>(m);
     Xyzz r;
     r.x = fe_sub(fe_sub(RR, PPP), fe_dbl(Q));
     // step 4: R (Q - X3) | S1 PPP | - | ZZZ3 = T PP
-    m = fe_mul(quad_pick(w, R, S1, S1, m), quad_pick(w, fe_sub(Q, r.x), PPP, PPP, PP));
+    m = quad_mul(quad_pick(w, R, S1, S1, m), quad_pick(w, fe_sub(Q, r.x), PPP, PPP, PP));
     r.y = fe_sub(quad_bcast<0>(m), quad_bcast<1>(m));
     r.zz = ZZ3;
     r.zzz = quad_bcast<3>(m);
@@ -120,7 +139,7 @@ __device__ __forceinline__ Xyzz xyzz_madd_q4(const Xyzz& a, const Affine& p, int
     if (xyzz_is_inf(a)) return xyzz_from_affine(p);
     const QuadRole w = quad_role(q);
     // step 1: U2 | S2 | U2 | S2
-    Fq m = fe_mul(quad_pick2(w.odd, p.x, p.y), quad_pick2(w.odd, a.zz, a.zzz));
+    Fq m = quad_mul(quad_pick2(w.odd, p.x, p.y), quad_pick2(w.odd, a.zz, a.zzz));
     const Fq U2 = quad_bcast<0>(m), S2 = quad_bcast<1>(m);
     const Fq P = fe_sub(U2, a.x), R = fe_sub(S2, a.y);
     if (fe_is_zero(P)) {
@@ -129,15 +148,15 @@ __device__ __forceinline__ Xyzz xyzz_madd_q4(const Xyzz& a, const Affine& p, int
     }
     // step 2: P^2 | R^2 | P^2 | R^2
     const Fq pr = quad_pick2(w.odd, P, R);
-    m = fe_mul(pr, pr);
+    m = quad_mul(pr, pr);
     const Fq PP = quad_bcast<0>(m), RR = quad_bcast<1>(m);
     // step 3: PPP = P PP | Q = X1 PP | ZZ3 = ZZ1 PP | (Q again)
-    m = fe_mul(quad_pick(w, P, a.x, a.zz, a.x), PP);
+    m = quad_mul(quad_pick(w, P, a.x, a.zz, a.x), PP);
     const Fq PPP = quad_bcast<0>(m), Q = quad_bcast<1>(m), ZZ3 = quad_bcast<2>(m);
     Xyzz r;
     r.x = fe_sub(fe_sub(RR, PPP), fe_dbl(Q));
     // step 4: R (Q - X3) | Y1 PPP | ZZZ3 = ZZZ1 PPP | (Y1 PPP again)
-    m = fe_mul(quad_pick(w, R, a.y, a.zzz, a.y), quad_pick(w, fe_sub(Q, r.x), PPP, PPP, PPP));
+    m = quad_mul(quad_pick(w, R, a.y, a.zzz, a.y), quad_pick(w, fe_sub(Q, r.x), PPP, PPP, PPP));
     r.y = fe_sub(quad_bcast<0>(m), quad_bcast<1>(m));
     r.zz = ZZ3;
     r.zzz = quad_bcast<2>(m);

@@ -338,6 +338,52 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul29(const Fe<P>& a, con
     return f29_to_fe(f29_mul(f29_from_fe<P, 5>(a), f29_from_fe<P, 0>(b)));
 }
 
+// ---- the product for LATENCY-bound callers (a wave alone on its SIMD running a chain of dependent products: the MSM reduce chains).  f29_mul
+// above is written for throughput: ONE accumulator runs through all seventeen columns, so each of its 162 + 26 instructions waits for the one
+// before it (other waves fill the gaps where there are any).  Here every column sums in an accumulator of its own -- the 81 a*b products depend on
+// nothing but the operands -- and each of the nine digit steps adds nine m*p products to nine different columns; only the digit chain
+// (column sum -> digit -> carry -> next column) is serial.  Plain C++, so that the compiler may interleave the columns.  Same result as f29_mul
+// (same columns, same digits).  Measured: bench_micro/mul_latency.hip.
+template <class P> __device__ __forceinline__ F29<P> f29_mul_ilp(const F29<P>& a, const F29<P>& b)
+{
+    uint64_t t[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j <= 8) s += (uint64_t)a.v[i] * b.v[j];
+        }
+        t[k] = s;
+    }
+    constexpr uint32_t pl[9] = { P29<P, 0>::value, P29<P, 1>::value, P29<P, 2>::value, P29<P, 3>::value, P29<P, 4>::value,
+                                 P29<P, 5>::value, P29<P, 6>::value, P29<P, 7>::value, P29<P, 8>::value };
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint64_t ti = t[i] + carry;
+        const uint32_t m = ((uint32_t)ti * (P::INV & M29)) & M29;
+        carry = (ti + (uint64_t)m * pl[0]) >> 29; // the low 29 bits are zero by the choice of m
+#pragma unroll
+        for (int j = 1; j < 9; j++) t[i + j] += (uint64_t)m * pl[j];
+    }
+    F29<P> r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t v = t[9 + k] + carry;
+        r.v[k] = (uint32_t)v & M29;
+        carry = v >> 29;
+    }
+    r.v[8] = (uint32_t)carry;
+    return r;
+}
+// fe_mul29 with it: a * b / 2^256 for 8 x u32 operands, same contract as field.hip.h fe_mul
+template <class P> __device__ __forceinline__ Fe<P> fe_mul29_ilp(const Fe<P>& a, const Fe<P>& b)
+{
+    return f29_to_fe(f29_mul_ilp(f29_from_fe<P, 5>(a), f29_from_fe<P, 0>(b)));
+}
+
 // ---- two independent products, columns interleaved.  hipcc cannot see inside an asm statement and puts an `s_nop 0` behind every one whose
 // result the NEXT instruction reads (gfx940's trans-use hazard, assumed for any inline asm): ~45 per multiplication, 1.2 clocks each at three
 // waves per SIMD (bench_micro/issue_rates.hip) -- 5 % of the bucket accumulation.  With two products in flight every statement is followed by

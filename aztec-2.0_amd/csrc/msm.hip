@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(128) k_normalize(const Jacobian* __restrict__ 
 // ---------------------------------------------------------------------------------- host side: width dispatch
 static const int MSM_WIDTHS[] = {
 #define X(c) c,
-    BBG_MSM_WIDTHS(X)
+    BBG_MSM_TABLE_WIDTHS(X)
 #undef X
 };
 constexpr int MSM_NUM_WIDTHS = (int)(sizeof(MSM_WIDTHS) / sizeof(MSM_WIDTHS[0]));
@@ -251,7 +251,7 @@ int msm_windows_for(int c)
 {
     switch (c) {
 #define X(c) case c: return MsmCfg<c>::windows;
-        BBG_MSM_WIDTHS(X)
+        BBG_MSM_TABLE_WIDTHS(X)
 #undef X
     }
     return 0;
@@ -260,7 +260,7 @@ int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipSt
 {
     switch (c) {
 #define X(c) case c: return srs_build_tables_c<c>(d_points, n, d_table, st);
-        BBG_MSM_WIDTHS(X)
+        BBG_MSM_TABLE_WIDTHS(X)
 #undef X
     }
     set_error("srs_build_tables: window width not compiled");
@@ -274,6 +274,10 @@ int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipSt
 #ifndef MSM_SMALL_WINDOW_MAX_LOG2N
 #define MSM_SMALL_WINDOW_MAX_LOG2N 14 // the 13-bit configuration is the automatic choice up to 2^14 terms (profiles/r04_window13_sweep.txt: it wins by 4-10 % there, ties at 2^13-2^14, loses from 2^15 -- its four-bin second sort level serialises on LDS counters once partitions hold a thousand entries)
 #endif
+#ifndef MSM_TINY_MAX_LOG2N
+#define MSM_TINY_MAX_LOG2N 12 // the 8-bit-window path (msm_tiny.hip) is the automatic choice up to this many terms (profiles/r06_tiny_msm.txt: stand-alone it wins
+                              // up to 2^13, 0.218 vs 0.247 ms; in a burst of independent MSMs up to 2^12)
+#endif
 int msm_auto_window(size_t n)
 {
     if (n >= ((size_t)1 << 23)) return 22; // 2^23: 9.8 vs 10.1 ms, 2^24: 18.3 vs 19.1 ms (22 vs 20 bits, pipelined); 2^22: 5.25 vs 4.94
@@ -282,6 +286,7 @@ int msm_auto_window(size_t n)
                                            // an entry cheaper, so one more window and half the buckets pay (20 bits won with the 32-bit limbs)
     // (+ 1024: StandardPLONK commits to n + 1 coefficients over an SRS of n + 1 points -- the same configuration as its n-term MSMs)
     if (n > ((size_t)1 << MSM_SMALL_WINDOW_MAX_LOG2N) + 1024) return 16; // 2^19: 0.80 (16) / 0.85 (19); 2^18: 0.51 vs 0.55 (17); 2^16: 0.233 vs 0.235 (17)
+    if (n <= ((size_t)1 << MSM_TINY_MAX_LOG2N) + 1024) return MSM_TINY_WIDTH; // r6: 8-bit windows, three launches, no sort (msm_tiny.hip; profiles/r06_tiny_msm.txt)
     return 13;                             // small circuits: 2^12 buckets instead of 2^15 (r4; profiles/r04_window13_sweep.txt)
 }
 int msm_pick_window(const bbg_ctx* ctx, size_t n)
@@ -391,6 +396,7 @@ int msm_run_batch(bbg_ctx* ctx, Srs& srs, int sets, const void* const* d_scalars
     int rc = msm_choose(ctx, srs, max_n, true, st, &c);
     if (rc) return rc;
     const void* table = srs.tables[msm_width_slot(c)];
+    if (c == MSM_TINY_WIDTH) return msm_run_tiny(ctx, srs, table, sets, d_scalars, from, n, d_out_jac, st, h_scalars);
     switch (c) {
 #define X(c) case c: return msm_run_c<c>(ctx, srs, table, sets, d_scalars, from, n, d_out_jac, st, h_scalars);
         BBG_MSM_WIDTHS(X)

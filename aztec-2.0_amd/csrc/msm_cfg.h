@@ -37,13 +37,13 @@ template <int C> struct MsmCfg {
     static constexpr int scale(int w) { return w < nwide ? 0 : 1; }                 // bucket = |digit| << scale(w)
     static constexpr int table_offset(int w) { return offset(w) - scale(w); }       // table[w][i] = 2^table_offset(w) P_i
     static constexpr int buckets = 1 << (C - 1);       // |digit| in [1, 2^(C-1)]
-    static constexpr int lo_bits = C - 11;             // sort partitions = buckets >> lo_bits (+1) = 1025; bins per partition = 2^lo_bits
+    static constexpr int lo_bits = C > 11 ? C - 11 : 0; // sort partitions = buckets >> lo_bits (+1) = 1025; bins per partition = 2^lo_bits (C = 8, msm_tiny.hip, has no sort)
     static constexpr int parts = (buckets >> lo_bits) + 1;
     static constexpr int log_cols = C / 2;             // bucket index (0-based) = hi * cols + lo
     static constexpr int log_rows = C - 1 - log_cols;
     static constexpr int planes = C - 1;               // bit planes of the weight idx + 1 <= 2^(C-1)
 };
-constexpr int MSM_MAX_WINDOWS = 20;
+constexpr int MSM_MAX_WINDOWS = 32; // (C = 8, the small-circuit path msm_tiny.hip: 32 windows)
 // The widest point index a sorted value carries (MsmCfg<C>::idx_bits of the configurations with up to 16 windows): up to 2^27 points per
 // device -- the whole 100.8 M-point Ignition SRS (2^26.6) fits one device's format, as it fits its HBM (12 windows x 64 B x 2^27 = 103 GB).
 // Beyond 2^27 points an SRS is sharded by point range across devices (bbg_multi_*).  (Round 3: 26 bits -- a bit was left unused between the
@@ -53,12 +53,19 @@ constexpr int MSM_MAX_PLANES = 32;
 
 // every width with a translation unit msm_wNN.hip (X-macro: dispatch tables in msm.hip, option parsing, table slots in Srs)
 #define BBG_MSM_WIDTHS(X) X(13) X(16) X(17) X(19) X(20) X(22)
+// every width an SRS may hold window tables for: the bucket pipeline's widths and the 8-bit windows of the small-circuit path (msm_tiny.hip:
+// three launches, no sort -- its own entry point msm_run_tiny, not an instantiation of msm_run_c)
+constexpr int MSM_TINY_WIDTH = 8;
+#define BBG_MSM_TABLE_WIDTHS(X) X(8) BBG_MSM_WIDTHS(X)
 
 // a batch of `sets` MSMs (1 .. BBG_MSM_BATCH_MAX; MSM k: n[k] terms from point from[k], result at d_out_jac + 96 k) with C-bit windows over
 // `table` (window tables of this width) through one launch set; defined in msm_kernels.hip.h, instantiated in msm_wNN.hip
 template <int C>
 int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table, int sets, const void* const* d_scalars, const size_t* from, const size_t* n,
               void* d_out_jac, hipStream_t st, const void* h_scalars);
+// the same contract on 8-bit windows without a sort (msm_tiny.hip); `table` = window tables of width MSM_TINY_WIDTH
+int msm_run_tiny(bbg_ctx* ctx, const Srs& srs, const void* table, int sets, const void* const* d_scalars, const size_t* from, const size_t* n,
+                 void* d_out_jac, hipStream_t st, const void* h_scalars);
 // table[w * n + i] = 2^(MsmCfg<C>::table_offset(w)) P_i
 template <int C> int srs_build_tables_c(const void* d_points, size_t n, void* d_table, hipStream_t st);
 // the last reduce stage (sum of the bit planes -> Jacobian), shared by all widths (msm.hip)

@@ -1305,6 +1305,22 @@ template <int C> static int msm_layout(size_t total_n, int sets, int cap_sets, b
 }
 
 static inline char* base_of(bbg_ctx* ctx) { return (char*)ctx->msm.buf; }
+// the auxiliary streams the reduce phases run on (one per reduce slot) and their events; created with the context's first MSM
+static inline int msm_ensure_aux_streams(bbg_ctx* ctx)
+{
+    if (ctx->aux_stream) return BBG_OK;
+    // the reduce phase is latency work that only has to finish before its result is consumed: a LOW-priority stream, so that what
+    // the caller queues next on the main stream (the following MSM's sort / accumulation, an NTT) is dispatched first
+    int least = 0, greatest = 0;
+    BBG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
+        BBG_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[k], hipStreamNonBlocking, ctx->msm_reduce_low_priority ? least : (least + greatest) / 2));
+        BBG_HIP(hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming));
+        BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
+    }
+    ctx->aux_stream = ctx->aux_streams[0];
+    return BBG_OK;
+}
 
 template <int C>
 int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const void* const* d_scalars_v, const size_t* from_v, const size_t* n_v,
@@ -1345,18 +1361,8 @@ int msm_run_c(bbg_ctx* ctx, const Srs& srs, const void* table_v, int sets, const
     rc = ensure_buffer(&ctx->msm.buf, &ctx->msm.bytes, L.total);
     if (rc) return rc;
     if (ctx->msm.bytes != arena_had) ctx->msm_zero_buf = nullptr;
-    if (!ctx->aux_stream) {
-        // the reduce phase is latency work that only has to finish before its result is consumed: a LOW-priority stream, so that what
-        // the caller queues next on the main stream (the following MSM's sort / accumulation, an NTT) is dispatched first
-        int least = 0, greatest = 0;
-        BBG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int k = 0; k < bbg_ctx::MSM_SLOTS; k++) {
-            BBG_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[k], hipStreamNonBlocking, ctx->msm_reduce_low_priority ? least : (least + greatest) / 2));
-            BBG_HIP(hipEventCreateWithFlags(&ctx->ev_acc[k], hipEventDisableTiming));
-            BBG_HIP(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
-        }
-        ctx->aux_stream = ctx->aux_streams[0];
-    }
+    rc = msm_ensure_aux_streams(ctx);
+    if (rc) return rc;
     if (ctx->msm_layout_n != total_n || ctx->msm_layout_sets != sets || ctx->msm_layout_c != C || ctx->msm_layout_sort != ctx->msm_sort) {
         // a different (n, sets, C) lays the arena out differently: a reduce phase still running on the auxiliary stream reads
         // regions this call is about to overwrite, so the main stream first waits for both slots (no host sync)

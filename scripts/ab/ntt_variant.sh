@@ -8,5 +8,5 @@ tag=$1; shift
 mkdir -p ../../build_ab
 FAST=-DBBG_NTT_FAST_AB; [ -n "${FULL:-}" ] && FAST=
 /opt/rocm/bin/hipcc $FAST "$@" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I/opt/rocm/include -c ntt.hip -o ../../build_ab/ntt_$tag.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_ab/libbbg_$tag.so ../../build_ab/ntt_$tag.o msm.o msm_w13.o msm_w16.o msm_w17.o msm_w19.o msm_w20.o msm_w22.o poly.o quotient.o prover.o multi.o bbg_capi.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_ab/libbbg_$tag.so ../../build_ab/ntt_$tag.o msm.o msm_tiny.o msm_w13.o msm_w16.o msm_w17.o msm_w19.o msm_w20.o msm_w22.o poly.o quotient.o prover.o multi.o bbg_capi.o
 echo built $tag

@@ -1,0 +1,8 @@
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "msm or smoke or prover or wrapped or memory" 2>&1 | tail -4
+python tests/tools/msm_window_sweep.py 8 14 8 13 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_tiny_sweep.txt
+python tests/tools/r04_batch_ab.py 2>&1 | grep -v amdgpu.ids | head -7
+for lg in 10 12 13; do
+python bench.py --log2n $lg --steps 10 --warmup 2 --blocks 1 --no-cpu-baseline --no-config5 --no-sweeps 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('prover_shaped 2^$lg', d['extra']['prover_shaped'].get('proof_ms'), 'step ms', d['ms_per_step'])"
+done

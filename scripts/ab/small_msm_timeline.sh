@@ -22,4 +22,4 @@ for _ in range(20):
 print("standalone ms", (time.perf_counter() - t0) / 20 * 1e3)
 PY
 rm -rf /tmp/kts && rocprofv3 --kernel-trace -d /tmp/kts -o t -- python /tmp/small_msm.py 2>&1 | grep standalone
-python $ROOT/scripts/rocpd_timeline.py $(find /tmp/kts -name "*_results.db" | head -1) k_sortA_count 30 16
+python $ROOT/scripts/rocpd_timeline.py $(find /tmp/kts -name "*_results.db" | head -1) ${2:-k_sortA_count} 30 16

@@ -14,7 +14,7 @@ import callback_engines  # tests/tools: Python stand-ins for work-queue callback
 pytestmark = pytest.mark.gpu
 
 FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
-MSM_WINDOWS = (13, 16, 17, 19, 20, 22)  # every window width libbbg.so compiles (csrc/msm_cfg.h BBG_MSM_WIDTHS; option msm_window)
+MSM_WINDOWS = (8, 13, 16, 17, 19, 20, 22)  # every window width libbbg.so compiles (csrc/msm_cfg.h BBG_MSM_TABLE_WIDTHS; option msm_window); 8 = the small-circuit path without a sort (msm_tiny.hip)
 
 
 # ---------------------------------------------------------------------------------------------- fields
@@ -681,7 +681,7 @@ def test_msm_batch_error_paths_and_plan(pkg, bbg, srs16):
     with pytest.raises(pkg.BbgError):
         bbg.msm_batch(srs16, [sc, sc], [0, (1 << 16) - 3])  # second range leaves the SRS
     # bbg_msm_plan: the automatic rule (msm.hip msm_auto_window), the forced width, the resident-table rule for short MSMs over long SRSs
-    assert bbg.msm_plan(1 << 12) == (13, 20) and bbg.msm_plan(1 << 18) == (16, 16) and bbg.msm_plan(1 << 20) == (19, 14) and bbg.msm_plan(1 << 21) == (20, 13) and bbg.msm_plan(1 << 24) == (22, 12)
+    assert bbg.msm_plan(1 << 12) == (8, 32) and bbg.msm_plan(1 << 14) == (13, 20) and bbg.msm_plan(1 << 18) == (16, 16) and bbg.msm_plan(1 << 20) == (19, 14) and bbg.msm_plan(1 << 21) == (20, 13) and bbg.msm_plan(1 << 24) == (22, 12)
     bbg.set_option("msm_window", 17)
     assert bbg.msm_plan(1 << 20) == (17, 15)
     bbg.set_option("msm_window", 0)
