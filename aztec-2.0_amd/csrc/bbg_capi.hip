@@ -416,6 +416,7 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released)
         drop(&ctx->quot_setup, &ctx->quot_setup_bytes);
         drop(&ctx->msm.buf, &ctx->msm.bytes);
         drop(&ctx->msm_tiny.buf, &ctx->msm_tiny.bytes);
+        ctx->msm_tiny_layout = 0;
         ctx->msm_layout_n = 0; // the arena's counters are re-initialised with the next layout
         ctx->msm_zero_buf = nullptr;
         ctx->msm_zero_c = 0;

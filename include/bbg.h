@@ -141,7 +141,9 @@ enum {
 /* In place on coeffs[2^log2n] (Montgomery Fr, natural order in and out).  generator_size = evaluation_domain::
  * generator_size (0 = whole domain): coset_fft scales only the first generator_size coefficients by g^j
  * (polynomial_arithmetic.cpp:397, proving_key.cpp:21-22).  constant: Montgomery Fr for ops 4-7, else NULL.
- * The per-size twiddle tables (evaluation_domain::compute_lookup_table) are built on first use and cached. */
+ * The per-size twiddle tables (evaluation_domain::compute_lookup_table) are built on first use and cached.
+ * log2n <= 28, the 2-adicity of BN254 Fr (fr.hpp:27-30); every size up to 2^28 is checked against the reference's digests
+ * (tests/golden/ntt_large.json: 2^25 .. 2^28 in round 6; the tables of a 2^28 domain take 5 x 32 n bytes = 40 GiB of HBM). */
 int bbg_ntt(bbg_ctx* ctx, uint64_t* coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant);
 int bbg_ntt_device(bbg_ctx* ctx, void* d_coeffs, unsigned log2n, int op, size_t generator_size, const uint64_t* constant);
 /* Pre-builds the tables for a domain size (outside any timed region, like compute_lookup_table()). */
@@ -365,8 +367,8 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
 
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
- * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [13 bits up to 2^14 terms, 16 below 2^20, 19 at 2^20, 20 from 2^21, 22 from 2^23 -- bbg_msm_plan reports it],
- * or a compiled width 13 / 16 / 17 / 19 / 20 / 22; windows are BALANCED -- 255 bits split as evenly as the window count allows --; a width's window tables
+ * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [8 bits up to 2^12 terms -- the small-circuit path: three launches, no sort --, 13 up to 2^14, 16 below 2^20, 19 at 2^20, 20 from 2^21, 22 from 2^23 -- bbg_msm_plan reports it],
+ * or a compiled width 8 / 13 / 16 / 17 / 19 / 20 / 22; windows are BALANCED -- 255 bits split as evenly as the window count allows --; a width's window tables
  * are built the first time it is used on an SRS), "msm_sort" (1 = fused recode + two-level partition sort, default; 0 = recode + rocPRIM radix sort, only
  * in builds made with `make ROCPRIM_SORT=1`),
  * "msm_reduce_quad" (bit mask 0..15, default 14: reduce-phase stages with four lanes per EC operation -- bit 0 combine, 1 row/column sums, 2 bit

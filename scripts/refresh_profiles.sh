@@ -12,7 +12,7 @@
 #   pass 7  kernel trace of the resident prover rounds (extra.prover_shaped)
 set -u
 TAG=${1:-v1}
-ROUND=${2:-r05}
+ROUND=${2:-r06}
 REV=${3:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
