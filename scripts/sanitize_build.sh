@@ -13,7 +13,7 @@ mkdir -p $OUT/obj
 HIPCC=/opt/rocm/bin/hipcc
 SAN="-fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -g"
 OBJS=""
-for f in ntt msm msm_w13 msm_w16 msm_w17 msm_w19 msm_w20 msm_w22 poly quotient prover multi bbg_capi; do
+for f in ntt msm msm_tiny msm_w13 msm_w16 msm_w17 msm_w19 msm_w20 msm_w22 poly quotient prover multi bbg_capi; do
   ( $HIPCC --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wall -Wno-unused-function -I/opt/rocm/include $SAN -c $CS/$f.hip -o $OUT/obj/$f.o ) &
   OBJS="$OBJS $OUT/obj/$f.o"
 done

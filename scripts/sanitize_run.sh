@@ -1,11 +1,11 @@
 #!/bin/bash
-# Runs the sanitizer configuration built by scripts/sanitize_build.sh on the GPU box and writes gpurun_out/r05_sanitizers.txt:
+# Runs the sanitizer configuration built by scripts/sanitize_build.sh on the GPU box and writes gpurun_out/r06_sanitizers.txt:
 #   gpurun --timeout 1500 -- 'bash scripts/sanitize_run.sh'
 # protect_shadow_gap=0: the HIP runtime maps device memory into the range ASan's shadow gap covers.  Leak checking is on for the C-ABI driver
 # (suppressing the runtime's own exit-time allocations), off under Python.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r05_sanitizers.txt
+OUT=$ROOT/gpurun_out/r06_sanitizers.txt
 S=$ROOT/build_san
 mkdir -p $ROOT/gpurun_out
 cat > /tmp/lsan.supp <<EOS

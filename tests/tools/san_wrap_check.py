@@ -98,4 +98,15 @@ proof_cpu, blind_r = A.prove_recording()
 assert B.prove_reference(replay=blind_r, reset=True) == proof_cpu and B.wrap_reuploads() == re0 + 1
 A.free(); B.free()
 print("rewritten proving key: re-uploaded, byte-identical", flush=True)
+# r6: ONE coefficient at a row the sampled fingerprint does not look at -- found by the full-content check that runs on host threads beside the proof
+A = RefProver(1 << 9, 63, pts, x, flavour=0)
+B = RefProver(1 << 9, 63, pts, x, wrap_linked=True, flavour=0)
+B.prove_reference()
+re0 = B.wrap_reuploads()
+A.key_selector_poke("q_m", 1); B.key_selector_poke("q_m", 1)
+proof_cpu, blind_r = A.prove_recording()
+assert B.prove_reference(replay=blind_r, reset=True) == proof_cpu and B.wrap_reuploads() == re0 + 1
+assert B.prove_reference(replay=blind_r, reset=True) == proof_cpu and B.wrap_reuploads() == re0 + 1
+A.free(); B.free()
+print("one poked coefficient of a cached key: found by the full check, proof repeated over the key as it is", flush=True)
 print("san_wrap_check PASS")

@@ -43,7 +43,7 @@ for c in range(cases):
         n = max(2, n & ~1)
         sc = sc[:n].copy()
         sc[1::2] = sc[0::2]
-    B.set_option("msm_window", int(rng.choice([0, 13, 16, 17, 19, 20, 22])))
+    B.set_option("msm_window", int(rng.choice([0, 8, 13, 16, 17, 19, 20, 22])))
     B.set_option("msm_accumulate_quad", int(rng.integers(0, 2)))
     B.set_option("msm_limbs29", int(rng.integers(0, 4) != 0))  # mostly the default 29-bit-limb accumulation, sometimes the 32-bit one
     B.set_option("msm_async_reduce", int(rng.integers(0, 2)))

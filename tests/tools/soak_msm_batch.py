@@ -49,7 +49,7 @@ for c in range(cases):
             sc[1::2] = sc[0::2]
         scs.append(np.ascontiguousarray(sc.reshape(-1, 4)))
         starts.append(start)
-    B.set_option("msm_window", int(rng.choice([0, 13, 16, 17, 19])))
+    B.set_option("msm_window", int(rng.choice([0, 8, 13, 16, 17, 19])))
     B.set_option("msm_limbs29", int(rng.integers(0, 4) != 0))
     B.set_option("msm_async_reduce", int(rng.integers(0, 2)))
     res = B.msm_batch(srs_dup if dup else srs, scs, starts=starts)
