@@ -275,8 +275,9 @@ int srs_build_tables(const void* d_points, size_t n, void* d_table, int c, hipSt
 #define MSM_SMALL_WINDOW_MAX_LOG2N 14 // the 13-bit configuration is the automatic choice up to 2^14 terms (profiles/r04_window13_sweep.txt: it wins by 4-10 % there, ties at 2^13-2^14, loses from 2^15 -- its four-bin second sort level serialises on LDS counters once partitions hold a thousand entries)
 #endif
 #ifndef MSM_TINY_MAX_LOG2N
-#define MSM_TINY_MAX_LOG2N 12 // the 8-bit-window path (msm_tiny.hip) is the automatic choice up to this many terms (profiles/r06_tiny_msm.txt: stand-alone it wins
-                              // up to 2^13, 0.218 vs 0.247 ms; in a burst of independent MSMs up to 2^12)
+#define MSM_TINY_MAX_LOG2N 13 // the 8-bit-window path (msm_tiny.hip) is the automatic choice up to this many terms (profiles/r06_tiny_msm.txt: at 2^13 it wins
+                              // stand-alone, 0.204 vs 0.256 ms, and ties in a burst of independent MSMs, 0.156 vs 0.153; a 2^13-gate proof 2.15 -> 2.05 ms;
+                              // at 2^14 it still wins stand-alone, 0.255 vs 0.274, but loses the burst, 0.222 vs 0.171)
 #endif
 int msm_auto_window(size_t n)
 {

@@ -367,7 +367,7 @@ int bbg_memory_trim(bbg_ctx* ctx, int tables, size_t* released);
 
 /* ---- tuning / introspection ---- */
 /* key: "ntt_tile_log" (log2 elements per LDS tile, 9..12), "ntt_max_logr" (max radix per pass, 4..10),
- * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [8 bits up to 2^12 terms -- the small-circuit path: three launches, no sort --, 13 up to 2^14, 16 below 2^20, 19 at 2^20, 20 from 2^21, 22 from 2^23 -- bbg_msm_plan reports it],
+ * "msm_async_reduce" (0/1, see bbg_join), "msm_window" (widest bucket window: 0 = automatic [8 bits up to 2^13 terms -- the small-circuit path: three launches, no sort --, 13 up to 2^14, 16 below 2^20, 19 at 2^20, 20 from 2^21, 22 from 2^23 -- bbg_msm_plan reports it],
  * or a compiled width 8 / 13 / 16 / 17 / 19 / 20 / 22; windows are BALANCED -- 255 bits split as evenly as the window count allows --; a width's window tables
  * are built the first time it is used on an SRS), "msm_sort" (1 = fused recode + two-level partition sort, default; 0 = recode + rocPRIM radix sort, only
  * in builds made with `make ROCPRIM_SORT=1`),

@@ -681,7 +681,7 @@ def test_msm_batch_error_paths_and_plan(pkg, bbg, srs16):
     with pytest.raises(pkg.BbgError):
         bbg.msm_batch(srs16, [sc, sc], [0, (1 << 16) - 3])  # second range leaves the SRS
     # bbg_msm_plan: the automatic rule (msm.hip msm_auto_window), the forced width, the resident-table rule for short MSMs over long SRSs
-    assert bbg.msm_plan(1 << 12) == (8, 32) and bbg.msm_plan(1 << 14) == (13, 20) and bbg.msm_plan(1 << 18) == (16, 16) and bbg.msm_plan(1 << 20) == (19, 14) and bbg.msm_plan(1 << 21) == (20, 13) and bbg.msm_plan(1 << 24) == (22, 12)
+    assert bbg.msm_plan(1 << 12) == (8, 32) and bbg.msm_plan(1 << 13) == (8, 32) and bbg.msm_plan(1 << 14) == (13, 20) and bbg.msm_plan(1 << 18) == (16, 16) and bbg.msm_plan(1 << 20) == (19, 14) and bbg.msm_plan(1 << 21) == (20, 13) and bbg.msm_plan(1 << 24) == (22, 12)
     bbg.set_option("msm_window", 17)
     assert bbg.msm_plan(1 << 20) == (17, 15)
     bbg.set_option("msm_window", 0)
