@@ -1,4 +1,4 @@
-// The MSM of SMALL circuits (n up to ~2^14 terms per MSM): 8-bit windows and three launches.
+// The MSM of SMALL circuits (automatic up to 2^13 terms per MSM, msm.hip MSM_TINY_MAX_LOG2N): 8-bit windows and three launches.
 //
 // The bucket pipeline of msm_kernels.hip.h (count -> scan -> scatter -> second sort level -> accumulate -> combine -> long buckets -> redo ->
 // row / column sums -> bit planes -> plane sum: eleven launches) is built for millions of entries.  At n = 2^12 every one of its stages runs for
@@ -18,7 +18,7 @@
 //   k_tiny_final    one block per MSM: slices summed, then sum_b b B_b WITHOUT bit planes and their doublings: it equals the sum of all suffix
 //                   sums sum_j (sum_{b >= j} B_b) -- a parallel suffix scan (6 levels) and a tree (6 levels) over 64 quads, two buckets per quad
 //                   -> the reference's Jacobian.
-// ~80 us for a 2^12-term MSM or a batch of four (the launches of a batch run side by side), against 0.24 / 0.32 ms.
+// Measured (profiles/r06_tiny_msm.txt; a level of these chains = one quad addition, ~4 us): 2^12 terms 0.159 ms stand-alone against 0.251 through the 13-bit configuration, 2^10 0.127 vs 0.233, a batch of four 2^12-term MSMs 0.249 vs 0.315.
 //
 // Results are the same group elements as the bucket pipeline's (tests: every golden and oracle case at the sizes this path takes, batches,
 // ragged n, `from`, all-equal scalars, points at infinity, P and -P).  Selected by msm_auto_window (msm.hip) as window width 8.
