@@ -363,6 +363,11 @@ template <int LOGR, bool ROW, int TL = P8_TILE_LOG> __global__ void __launch_bou
             if (have_outmul) { Fr t; for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)pj * 40503u + i + c; t.v[7] &= 0x0fffffffu; v = n29_finish_mul(x[j], t, red); }
             else v = n29_finish(x[j], red);
             if (v.v[0] == 0x12345678u && v.v[1] == 0x9abcdef0u && v.v[5] == 77u) fe_store<FrP>(p.out + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false), v);
+#elif defined(BBG_NTT29_EXP) && (BBG_NTT29_EXP & 4) // timing experiment only (round 6, wrong results): the output multipliers made up in registers -- what the
+            // inter-pass twiddle / post tables cost a transform, i.e. the most ANY on-chip generation could gain before its own products are paid for
+            if (have_outmul) { Fr t; for (int i = 0; i < 8; i++) t.v[i] = (uint32_t)pj * 40503u + i + c; t.v[7] &= 0x0fffffffu; v = n29_finish_mul(x[j], t, red); }
+            else v = n29_finish(x[j], red);
+            fe_store<FrP>(p.out + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, false), v);
 #else
             if (have_outmul)
                 v = n29_finish_mul(x[j], (BBG_NTT29_PREFETCH == 1 || LATE_PREFETCH) ? outmul[j] : fe_load<FrP>(mul_table + p8_out_index<LOGR, ROW>(p, pj, c, base, lo0, d1_0, rest, true)), red);
