@@ -219,3 +219,23 @@ def test_bench_promotes_the_strong_scaling_workload_at_n_gt_1():
     bad = copy.deepcopy(base)
     bench.promote_config5(bad, {"error": "timeout after 600 s"}, args, 4, FakeDist(), False)
     assert bad == base
+
+
+@pytest.mark.parametrize("threads", ["1", "8"])
+def test_shim_content_hash_host_logic(tmp_path, threads):
+    """shim/bbg_shim_verify.hpp -- the hash behind the shim's full-content verification of cached point tables and proving keys (round 6) -- is
+    plain host C++: the digest is a function of the contents alone (not of which thread hashed which piece, nor of the thread count), every
+    single-bit change changes it (piece borders included), polynomial order and length are part of it, a point's hash depends on its index.
+    Built with g++ and run here; the GPU suite exercises it through the shim (shim_check, test_wrapped_proof_over_a_key_with_one_poked_coefficient).
+    What it guards has no hook in the reference: pippenger.cpp:33-36 frees the table, proving_key.cpp:18-27 is a plain struct."""
+    import subprocess
+    exe = str(tmp_path / "verify_hash_check")
+    src = os.path.join(ROOT, "tests", "tools", "verify_hash_check.cpp")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    outs = []
+    for t in (threads, "3"):
+        r = subprocess.run([exe], env=dict(os.environ, BBG_SHIM_VERIFY_THREADS=t), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0 and "verify_hash_check PASS" in r.stdout.decode(), r.stdout.decode()
+        outs.append([ln for ln in r.stdout.decode().splitlines() if ln.startswith("digest ")])
+    assert outs[0] and outs[0] == outs[1], "the digest depends on the thread count"
