@@ -239,3 +239,49 @@ def test_shim_content_hash_host_logic(tmp_path, threads):
         assert r.returncode == 0 and "verify_hash_check PASS" in r.stdout.decode(), r.stdout.decode()
         outs.append([ln for ln in r.stdout.decode().splitlines() if ln.startswith("digest ")])
     assert outs[0] and outs[0] == outs[1], "the digest depends on the thread count"
+
+
+def test_small_msm_final_stage_dataflow_model():
+    """csrc/msm_tiny.hip k_tiny_final on INTEGERS (any abelian group will do): 64 quads, two buckets per quad, slices summed, pair sums,
+    Hillis-Steele suffix scan, contribution 2 (tail + y) + x, tree -- must equal sum_b b * B_b, the bucket-weighted sum the reference takes with
+    running sums (scalar_multiplication.cpp:773-783).  Also the digit recoding of MsmCfg<8>: 31 windows of 8 bits + one of 7, signed digits with
+    carry, the narrow window filed under bucket 2 d against a table point of half the weight (msm_cfg.h) -- sum_w sign_w * bucket_w * 2^table_offset(w) = k."""
+    import random
+    rng = random.Random(6)
+    NB, S = 128, 4
+    for _ in range(20):
+        parts = [[rng.randrange(-10**9, 10**9) for _ in range(S)] for _ in range(NB)]
+        B = [sum(p) for p in parts]
+        want = sum((b + 1) * B[b] for b in range(NB))
+        NQ = NB // 2
+        x = [B[2 * t] for t in range(NQ)]
+        y = [B[2 * t + 1] for t in range(NQ)]
+        v = [x[t] + y[t] for t in range(NQ)]
+        d = 1
+        while d < NQ:
+            v = [v[t] + (v[t + d] if t + d < NQ else 0) for t in range(NQ)]
+            d <<= 1
+        c = [2 * ((v[t + 1] if t + 1 < NQ else 0) + y[t]) + x[t] for t in range(NQ)]
+        assert sum(c) == want
+    # MsmCfg<8>
+    C = 8
+    windows = (254 + C) // C
+    nwide = 255 - windows * (C - 1)
+    assert (windows, nwide) == (32, 31)
+    width = lambda w: C if w < nwide else C - 1
+    offset = lambda w: w * (C - 1) + min(w, nwide)
+    scale = lambda w: 0 if w < nwide else 1
+    assert offset(windows) == 255
+    r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    for k in [0, 1, r - 1, (1 << 253) + 12345, (1 << 254) - 1 if (1 << 254) - 1 < r else r - 2] + [rng.randrange(r) for _ in range(200)]:
+        carry, total = 0, 0
+        for w in range(windows):
+            full = 1 << width(w)
+            dgt = ((k >> offset(w)) & (full - 1)) + carry
+            neg = dgt > full // 2
+            mag = (full - dgt) if neg else dgt
+            carry = 1 if neg else 0
+            bucket = mag << scale(w)
+            assert 0 <= bucket <= 128
+            total += (-1 if neg else 1) * bucket * (1 << (offset(w) - scale(w)))
+        assert carry == 0 and total == k
